@@ -1,0 +1,217 @@
+/* xck.h - C-ABI of the MI355X-native cell x feature / cell x SNP counting engine (libxck.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of hxj5/xcltk:
+ *   - RDR `basefc`  : per-region UMI/read counting        (reference xcltk/rdr/fc/core.py:69-178)
+ *   - BAF  pileup   : per-region allele-specific counting (reference xcltk/baf/fc/core.py:42-247)
+ * The reference has no FFI; its seams are the Python functions fc_features()/fc_fet1()/plp_snp().
+ * Each entry point below names the reference interface it replaces.  A reference-side binding
+ * (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions: plain C, plain pointers and sizes, no torch / HIP types.  Every call returns an
+ * int status (0 = ok, <0 = error; xck_last_error() gives the text) unless stated otherwise.
+ * One engine handle drives one GPU; calls on one handle must be serialised by the caller;
+ * different handles may be used from different host threads.  No global state, no callbacks.
+ * There is NO CPU fallback: if no HIP device is usable xck_create() fails.
+ */
+#ifndef XCK_H
+#define XCK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XCK_ABI_VERSION 1
+
+/* status codes */
+#define XCK_OK            0
+#define XCK_E_ARG        -1   /* invalid argument / configuration            */
+#define XCK_E_DEVICE     -2   /* HIP runtime error, or no device             */
+#define XCK_E_NOMEM      -3
+#define XCK_E_IO         -4   /* file / BGZF / BAM format error              */
+#define XCK_E_STATE      -5   /* call sequence error                         */
+#define XCK_E_CAPACITY   -6   /* key space exhausted (too many interned UMIs)*/
+
+/* counting modes */
+#define XCK_MODE_BASEFC   1   /* feature x cell counts        (xcltk basefc)        */
+#define XCK_MODE_BAF      2   /* feature x cell AD / DP / OTH (xcltk baf, step 3)   */
+
+/* UMI / read-name key code meaning "no usable key" (tag missing or empty string;
+ * reference: check_read() -12, rdr/fc/mcount.py:41, baf/fc/mcount.py:116-117) */
+#define XCK_UMI_NONE  0xFFFFFFFFFFFFFFFFull
+
+/* A region ("feature"): 1-based inclusive start/end exactly as in the region TSV
+ * (reference load_region_from_txt, rdr/fc/utils.py:10-45).  `contig` indexes the caller's
+ * contig table (names with any leading "chr" stripped, utils/grange.py:263).
+ * Output row index of a region == its index in this array. */
+typedef struct xck_region {
+    int32_t contig;
+    int32_t start;      /* 1-based inclusive */
+    int32_t end;        /* 1-based inclusive */
+} xck_region;
+
+/* A phased het SNP (reference SNP class, baf/fc/gfeature.py:8-39). ref/alt are upper-case
+ * ASCII in "ACGTN"; ref_hap/alt_hap in {0,1} are the haplotype index of each allele. */
+typedef struct xck_snp {
+    int32_t contig;
+    int32_t pos;        /* 1-based */
+    uint8_t ref, alt;
+    uint8_t ref_hap, alt_hap;
+} xck_snp;
+
+/* Engine configuration.  Replaces the fields of the reference Config objects that the hot
+ * path reads (rdr/fc/config.py:5-41, baf/fc/config.py:8-60). */
+typedef struct xck_config {
+    uint32_t struct_size;       /* sizeof(xck_config), for ABI checking                      */
+    int32_t  mode;              /* XCK_MODE_*                                                */
+    int32_t  device;            /* HIP device ordinal                                        */
+    /* read filter = check_read(), rdr/fc/core.py:46-62 == baf/fc/core.py:18-34 */
+    double   min_mapq;          /* drop if mapq < min_mapq                                   */
+    int32_t  min_len;           /* drop if #aligned (M/=/X) bases < min_len                  */
+    uint32_t incl_flag;         /* if non-zero: drop unless flag & incl_flag                 */
+    uint32_t excl_flag;         /* if non-zero: drop if flag & excl_flag                     */
+    int32_t  no_orphan;         /* drop paired reads that are not proper pairs               */
+    /* basefc include criterion, rdr/fc/core.py:160-165: 0 < v < 1 -> fraction (IEEE double
+     * m/float(n) < v drops), otherwise length (m < v drops).                                */
+    double   min_include;
+    /* BAF: per-SNP filters (baf/fc/core.py:238-246) and haplotype rule (:181-192) */
+    double   min_count;
+    double   min_maf;
+    int32_t  no_dup_hap;
+    /* tables */
+    int32_t  n_cells;           /* number of matrix columns (barcodes or sample ids)         */
+    int32_t  n_contigs;
+    int32_t  n_regions;
+    const xck_region* regions;
+    int32_t  n_snps;            /* BAF only                                                  */
+    const xck_snp*    snps;
+    /* decoder side (used only by xck_ingest_bam / xck_bam_next_batch) */
+    const char* const* barcodes;  /* n_cells NUL-terminated barcodes, or NULL = well mode
+                                     (column = sample index of the BAM)                      */
+    char     cell_tag[4];       /* e.g. "CB"; "" when barcodes == NULL                       */
+    char     umi_tag[4];        /* e.g. "UB"; "" = key is the read name                      */
+    /* sizing */
+    int64_t  max_batch_reads;   /* upper bound on reads per xck_push_batch (0 = default)     */
+    int32_t  n_threads;         /* host decode threads (0 = hardware concurrency)            */
+    int32_t  flags;             /* XCK_F_*                                                   */
+} xck_config;
+
+#define XCK_F_FORCE_KEY128   1  /* always use 128-bit sort keys (testing)                    */
+#define XCK_F_VERIFY_CRC     2  /* verify BGZF CRC32 while decoding                          */
+
+/* One batch of decoded alignment records, structure-of-arrays, all reads on ONE contig,
+ * in file order.  This is what the reference obtains record by record from
+ * pysam.AlignmentFile.fetch() (utils/sam.py:85-118).  Host pointers (ideally pinned). */
+typedef struct xck_batch {
+    int32_t  contig;            /* engine contig id; <0 : batch is skipped                   */
+    int32_t  n_reads;
+    uint64_t ordinal_base;      /* fetch-order ordinal of read 0: (bam_index << 40) | record#;
+                                   read i has ordinal_base + i  (baf/fc/mcount.py:118-119:
+                                   first read of a UMI in fetch order decides the allele)    */
+    const int32_t*  pos;        /* [n]   0-based leftmost reference coordinate               */
+    const uint16_t* flag;       /* [n]   BAM FLAG                                            */
+    const uint8_t*  mapq;       /* [n]                                                       */
+    const int32_t*  cell;       /* [n]   column index; <0 = tag missing / not in list        */
+    const uint64_t* umi;        /* [n]   key code (see xck_umi_bits) or XCK_UMI_NONE         */
+    const uint32_t* cig_off;    /* [n+1] offsets into cigar[]                                */
+    const uint32_t* cigar;      /* BAM CIGAR words (len << 4 | op)                           */
+    const uint32_t* seq_off;    /* [n+1] BYTE offsets into seq[] (BAF only, else NULL)       */
+    const uint8_t*  seq;        /* BAM 4-bit packed bases, each read starts on a byte        */
+} xck_batch;
+
+/* Sparse result in coordinate form, sorted by (row, col), no zero entries.
+ * row = region index (0-based, input order), col = cell index (0-based). Engine-owned
+ * host memory, valid until xck_destroy(). */
+typedef struct xck_coo {
+    int64_t nnz;
+    const int32_t* row;
+    const int32_t* col;
+    const int32_t* val;
+} xck_coo;
+
+typedef struct xck_result {
+    xck_coo count;              /* XCK_MODE_BASEFC: matrix.mtx  (rdr/fc/core.py:109-116)     */
+    xck_coo ad, dp, oth;        /* XCK_MODE_BAF: AD/DP/OTH.mtx  (baf/fc/core.py:84-99)       */
+} xck_result;
+
+typedef struct xck_stats {
+    int64_t n_batches;
+    int64_t n_reads;            /* records pushed (every decoded BAM record counts)          */
+    int64_t n_hits;             /* (read,region) or (read,SNP) pairs emitted by the join     */
+    int64_t n_hits_unique;      /* after de-duplication                                      */
+    double  ms_h2d;             /* host-measured, cumulative                                 */
+    double  ms_device;          /* HIP-event time of all kernels, cumulative                 */
+    double  ms_join;            /* HIP-event time of the join/pileup kernels only            */
+    double  ms_sort;            /* HIP-event time of sort + reduce kernels                   */
+    int64_t algo_bytes_join;    /* algorithmic bytes of the join kernels         */
+    int32_t key_bits;           /* 64 or 128                                                 */
+    int32_t umi_bits;
+} xck_stats;
+
+typedef struct xck_engine xck_engine;     /* opaque: one per GPU */
+typedef struct xck_bam    xck_bam;        /* opaque: one open BAM file */
+
+/* -- library ------------------------------------------------------------------------------- */
+const char* xck_version(void);
+int         xck_abi_version(void);
+int         xck_device_count(void);              /* number of usable HIP devices (0 if none) */
+const char* xck_last_error(const xck_engine* e); /* e may be NULL: last error of the creating thread */
+
+/* -- engine (replaces fc_features()/fc_fet1()/plp_snp(): the per-region fetch loops) -------- */
+int  xck_create(const xck_config* cfg, xck_engine** out);
+void xck_destroy(xck_engine* e);
+/* number of bits available for a UMI / read-name key code in xck_batch.umi (26..64):
+ *   ACGT-only key of L bases with 2L+1 <= bits-1  ->  (1 << 2L) | 2-bit packed bases (A0 C1 G2 T3)
+ *   anything else                                   ->  (1 << (bits-1)) | interned id            */
+int  xck_umi_bits(const xck_engine* e);
+/* Copy one batch to the GPU (async, overlapped with kernels of the previous batch) and run
+ * the join / pileup kernels on it.  The batch arrays may be reused once the call returns. */
+int  xck_push_batch(xck_engine* e, const xck_batch* b);
+/* Same, but the arrays are DEVICE pointers already resident in HBM (benchmarks, pipelines
+ * that decode on the GPU side); no copy is made and they must stay valid until xck_flush(). */
+int  xck_push_batch_device(xck_engine* e, const xck_batch* b);
+int  xck_flush(xck_engine* e);                    /* wait for all queued device work */
+/* Fold all hits into the final sparse matrices (radix sort + segmented reduce on the GPU). */
+int  xck_finish(xck_engine* e, xck_result* out);
+/* Forget all pushed reads, keep tables and buffers (lets one engine be re-used per step). */
+int  xck_reset(xck_engine* e);
+int  xck_get_stats(const xck_engine* e, xck_stats* out);
+
+/* -- host ingest (replaces pysam.AlignmentFile + fetch(): own BGZF/BAM reader) --------------- */
+int  xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen);
+void xck_bam_close(xck_bam* b);
+int  xck_bam_n_refs(const xck_bam* b);
+const char* xck_bam_ref_name(const xck_bam* b, int tid);
+int64_t     xck_bam_ref_len(const xck_bam* b, int tid);
+
+typedef struct xck_ingest_opts {
+    uint32_t struct_size;
+    int32_t  sample;            /* index of this BAM in the BAM list (ordinal high bits; column
+                                   index in well mode)                                       */
+    const int32_t* tid_to_contig; /* [n_refs] engine contig id per BAM tid, -1 = not used    */
+    int32_t  use_index;         /* 1: seek with the .bai to the first/last wanted tid        */
+    int64_t  max_records;       /* stop after this many records (0 = all)                    */
+} xck_ingest_opts;
+
+/* Decode the BAM with the engine's decoder settings and push every batch; returns the number
+ * of records decoded through *n_records. */
+int  xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records);
+/* Pull-style decoding for tests / other consumers: fills *out with the next batch (arrays are
+ * owned by the xck_bam and valid until the next call); returns 1 if a batch was produced,
+ * 0 at end of file, <0 on error. */
+int  xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out);
+
+/* -- output (replaces merge_mtx(), rdr/fc/utils.py:54-93) ------------------------------------ */
+/* Write a MatrixMarket file byte-identical to the reference: header
+ * "%%MatrixMarket matrix coordinate integer general\n%%\n{nrow}\t{ncol}\t{nnz}\n" then
+ * "row\tcol\tval\n" lines (1-based).  row_map[r] gives the 1-based output row of region r
+ * (0 = region not written). */
+int  xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map,
+                   int32_t n_rows_out, int32_t n_cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XCK_H */

@@ -1,0 +1,77 @@
+#!/opt/conda/bin/python3.9
+"""run_reference.py - CONTAINER-ONLY golden-vector generator (test infrastructure).
+
+Runs the *unmodified* reference (hxj5/xcltk, mounted read-only at /root/reference)
+on inputs produced by this repo's synthetic generator and prints/stores its outputs.
+The reference is pure Python but imports two third-party packages that do not exist
+in this image: `pysam` (BAM access) and `anndata` (only touched when cellsnp_dir is
+given).  As recorded in SURVEY.md section 8c they are replaced by stand-ins:
+
+  * pysam   -> oracle/pybam.py (AlignmentFile.fetch + AlignedSegment accessors restated
+               from the SAM spec / pysam documentation);
+  * anndata -> empty module (never touched on the paths exercised here).
+
+`intervaltree` (xcltk/utils/grange.py:4) exists only for /opt/conda/bin/python3.9, hence
+the interpreter.  Nothing from the reference is copied: it is imported in place with
+sys.dont_write_bytecode = True (the tree is read-only) and only its *outputs* are kept
+as fixtures under tests/golden/.
+
+usage: run_reference.py <job.json>
+  job = {"kind": "basefc"|"baf", "out_dir": ..., "kwargs": {...}}   (kwargs of fc_wrapper /
+  afc_wrapper, xcltk/rdr/fc/main.py:142 and xcltk/baf/fc/main.py:32)
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))          # oracle/ -> pybam
+REF = os.environ.get("XCLTK_REFERENCE", "/root/reference")
+
+
+def install_standins():
+    import pybam
+    m = types.ModuleType("pysam")
+    m.AlignmentFile = pybam.AlignmentFile
+    m.BGZFile = pybam.BGZFile
+    m.__version__ = "0.0-standin"
+    sys.modules["pysam"] = m
+    sys.modules["anndata"] = types.ModuleType("anndata")
+
+
+def main():
+    with open(sys.argv[1]) as fp:
+        job = json.load(fp)
+    install_standins()
+    sys.path.insert(0, REF)
+    import logging
+    logging.disable(logging.CRITICAL)
+    if job["kind"] == "basefc":
+        from xcltk.rdr.fc.main import fc_wrapper
+        # NOTE reference quirk (rdr/fc/main.py:177-178): a non-None excl_flag is never
+        # copied into conf.  To exercise explicit exclude flags we go through the CLI
+        # entry point instead when "argv" is given.
+        if "argv" in job:
+            from xcltk.rdr.fc.main import fc_main
+            ret = fc_main(["xcltk", "basefc"] + job["argv"])
+        else:
+            ret = fc_wrapper(**job["kwargs"])
+    elif job["kind"] == "baf":
+        from xcltk.baf.fc.main import afc_wrapper
+        ret = afc_wrapper(**job["kwargs"])
+    elif job["kind"] == "fet1":
+        # direct per-region call used for the known-answer tests of SURVEY 8c
+        raise SystemExit("fet1 jobs are handled by kat.py")
+    else:
+        raise SystemExit("unknown job kind")
+    sys.stdout.write(json.dumps({"ret": ret}) + "\n")
+    return 0 if ret == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
