@@ -100,6 +100,9 @@ typedef struct xck_config {
 
 #define XCK_F_FORCE_KEY128   1  /* always use 128-bit sort keys (testing)                    */
 #define XCK_F_VERIFY_CRC     2  /* verify BGZF CRC32 while decoding                          */
+#define XCK_F_DECODE_ONLY    4  /* handle drives the BAM decoder only: no GPU is touched, and
+                                   xck_push_batch / xck_finish fail (used to run the host
+                                   ingest on machines without a device; NOT a compute path)  */
 
 /* One batch of decoded alignment records, structure-of-arrays, all reads on ONE contig,
  * in file order.  This is what the reference obtains record by record from

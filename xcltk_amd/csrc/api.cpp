@@ -1,0 +1,86 @@
+// api.cpp - C-ABI entry points of libxck.so (include/xck.h) except the BAM functions (bam.cpp).
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include "xck_internal.h"
+
+using namespace xck;
+
+extern "C" {
+
+const char* xck_version(void) { return XCK_VERSION_STR; }
+int xck_abi_version(void) { return XCK_ABI_VERSION; }
+
+int xck_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* xck_last_error(const xck_engine* e) { return e ? e->err.c_str() : get_thread_error(); }
+
+int xck_create(const xck_config* cfg, xck_engine** out) {
+    if (!cfg || !out) { set_thread_error("null argument"); return XCK_E_ARG; }
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(xck_config)) { set_thread_error("xck_config.struct_size mismatch (ABI)"); return XCK_E_ARG; }
+    if (cfg->mode != XCK_MODE_BASEFC && cfg->mode != XCK_MODE_BAF) { set_thread_error("invalid mode"); return XCK_E_ARG; }
+    if (cfg->n_cells <= 0 || cfg->n_contigs < 0 || cfg->n_regions < 0 || cfg->n_snps < 0) { set_thread_error("invalid table sizes"); return XCK_E_ARG; }
+    if ((cfg->n_regions > 0 && !cfg->regions) || (cfg->n_snps > 0 && !cfg->snps)) { set_thread_error("null table pointer"); return XCK_E_ARG; }
+    xck_engine* e = new xck_engine();
+    e->umi_bits = key_layout(cfg).ubits;
+    if (!(cfg->flags & XCK_F_DECODE_ONLY)) {
+        int rc = engine_create(cfg, e);
+        if (rc) { set_thread_error(e->err); engine_destroy(e); delete e; return rc; }
+    }
+    // decoder settings
+    DecodeCfg& d = e->dec;
+    d.use_barcodes = cfg->barcodes != nullptr;
+    if (d.use_barcodes) { d.build_barcodes(cfg->barcodes, cfg->n_cells); d.cell_tag[0] = cfg->cell_tag[0]; d.cell_tag[1] = cfg->cell_tag[1]; }
+    d.use_umi = cfg->umi_tag[0] != 0;
+    if (d.use_umi) { d.umi_tag[0] = cfg->umi_tag[0]; d.umi_tag[1] = cfg->umi_tag[1]; }
+    d.umi_bits = e->umi_bits;
+    d.want_seq = cfg->mode == XCK_MODE_BAF;
+    d.verify_crc = (cfg->flags & XCK_F_VERIFY_CRC) != 0;
+    d.n_threads = cfg->n_threads;
+    d.max_batch_reads = cfg->max_batch_reads;
+    *out = e;
+    return XCK_OK;
+}
+
+void xck_destroy(xck_engine* e) { if (!e) return; engine_destroy(e); delete e; }
+int xck_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }
+
+int xck_push_batch(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; return engine_push(e, b, false); }
+int xck_push_batch_device(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; return engine_push(e, b, true); }
+int xck_flush(xck_engine* e) { if (!e) return XCK_E_ARG; return engine_flush(e); }
+int xck_finish(xck_engine* e, xck_result* out) { if (!e || !out) return XCK_E_ARG; return engine_finish(e, out); }
+int xck_reset(xck_engine* e) { if (!e) return XCK_E_ARG; return engine_reset(e); }
+int xck_get_stats(const xck_engine* e, xck_stats* out) { if (!e || !out) return XCK_E_ARG; return engine_stats(e, out); }
+
+// merge_mtx() header + body, rdr/fc/utils.py:54-93 (byte-identical text)
+int xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map, int32_t n_rows_out, int32_t n_cols) {
+    if (!path || !m || !row_map) return XCK_E_ARG;
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { set_thread_error(std::string("cannot open ") + path); return XCK_E_IO; }
+    static const size_t BUF = 1 << 22;
+    std::string buf; buf.reserve(BUF + 64);
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < m->nnz; i++) if (row_map[m->row[i]] > 0) nnz++;
+    char line[96];
+    int k = snprintf(line, sizeof line, "%%%%MatrixMarket matrix coordinate integer general\n%%%%\n%d\t%d\t%lld\n", n_rows_out, n_cols, (long long)nnz);
+    buf.append(line, (size_t)k);
+    auto put_int = [&](int64_t v) { char t[24]; int n = 0; if (v == 0) t[n++] = '0'; bool neg = v < 0; if (neg) v = -v;
+        while (v) { t[n++] = char('0' + v % 10); v /= 10; } if (neg) buf.push_back('-'); while (n) buf.push_back(t[--n]); };
+    for (int64_t i = 0; i < m->nnz; i++) {
+        int32_t r = row_map[m->row[i]];
+        if (r <= 0) continue;
+        put_int(r); buf.push_back('\t'); put_int((int64_t)m->col[i] + 1); buf.push_back('\t'); put_int(m->val[i]); buf.push_back('\n');
+        if (buf.size() >= BUF) { if (fwrite(buf.data(), 1, buf.size(), fp) != buf.size()) { fclose(fp); return XCK_E_IO; } buf.clear(); }
+    }
+    if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), fp) != buf.size()) { fclose(fp); return XCK_E_IO; }
+    if (fclose(fp) != 0) return XCK_E_IO;
+    return XCK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,532 @@
+// bam.cpp - host ingest: multithreaded BGZF inflate + BAM record parse into pinned SoA batches.
+//
+// Replaces pysam.AlignmentFile / fetch() of the reference (xcltk/rdr/fc/core.py:73-76,
+// xcltk/utils/sam.py:85-118): instead of one indexed fetch per region / SNP (every read
+// overlapping k features is decompressed k times) the file is decoded ONCE,
+// in file order, and handed to the GPU as structure-of-arrays batches (include/xck.h xck_batch).
+//
+// Written from the SAM/BAM specification (SAMv1 section 4); htslib is not available here.
+// Pipeline per chunk of BGZF blocks:  inflate (parallel over blocks) -> record walk (serial,
+// touches 24 B per record) -> field/tag parse into SoA (parallel over records).  The inflate of
+// chunk i+1 runs while chunk i is walked and parsed.
+#include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <thread>
+#include "xck_internal.h"
+
+namespace xck {
+
+// ---------------------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string t_err;
+void set_thread_error(const std::string& s) { t_err = s; }
+const char* get_thread_error() { return t_err.c_str(); }
+
+uint64_t hash_bytes(const char* s, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) { h ^= (uint8_t)s[i]; h *= 0x100000001b3ull; }
+    h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+    return h;
+}
+
+uint64_t InternTable::intern(const char* s, size_t n) {
+    uint64_t h = hash_bytes(s, n);
+    Shard& sh = shards_[h & (NSHARD - 1)];
+    std::lock_guard<std::mutex> lk(sh.mu);
+    auto it = sh.map.find(std::string(s, n));
+    if (it != sh.map.end()) return it->second;
+    uint64_t id = ((uint64_t)sh.map.size() << 6) | (h & (NSHARD - 1));
+    sh.map.emplace(std::string(s, n), id);
+    return id;
+}
+uint64_t InternTable::size() const { uint64_t n = 0; for (auto& s : shards_) n += s.map.size(); return n; }
+void InternTable::clear() { for (auto& s : shards_) { std::lock_guard<std::mutex> lk(s.mu); s.map.clear(); } }
+
+uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, bool* overflow) {
+    if (n == 0) return XCK_UMI_NONE;
+    if (2 * (int)n + 1 <= umi_bits - 1) {
+        uint64_t v = 1; bool ok = true;
+        for (size_t i = 0; i < n; i++) {
+            uint64_t c;
+            switch (s[i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = 4; }
+            if (c > 3) { ok = false; break; }
+            v = (v << 2) | c;
+        }
+        if (ok) return v;
+    }
+    uint64_t id = tab.intern(s, n);
+    uint64_t lim = umi_bits >= 64 ? (1ull << 63) - 1 : (1ull << (umi_bits - 1)) - 1;
+    if (id >= lim) { if (overflow) *overflow = true; return XCK_UMI_NONE; }
+    return (1ull << (umi_bits - 1)) | id;
+}
+
+void DecodeCfg::build_barcodes(const char* const* names, int n) {
+    barcodes.clear();
+    for (int i = 0; i < n; i++) barcodes.emplace_back(names[i]);
+    size_t cap = 16; while (cap < (size_t)n * 2) cap <<= 1;
+    bc_slots.assign(cap, -1); bc_mask = cap - 1;
+    for (int i = 0; i < n; i++) {
+        uint64_t h = hash_bytes(barcodes[i].data(), barcodes[i].size()) & bc_mask;
+        while (bc_slots[h] >= 0) h = (h + 1) & bc_mask;
+        bc_slots[h] = i;
+    }
+}
+int32_t DecodeCfg::lookup_cell(const char* s, size_t n) const {
+    if (bc_slots.empty()) return -1;
+    uint64_t h = hash_bytes(s, n) & bc_mask;
+    while (bc_slots[h] >= 0) {
+        const std::string& b = barcodes[bc_slots[h]];
+        if (b.size() == n && memcmp(b.data(), s, n) == 0) return bc_slots[h];
+        h = (h + 1) & bc_mask;
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// thread pool
+// ---------------------------------------------------------------------------------------------
+class Pool {
+public:
+    explicit Pool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
+    ~Pool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); } cv_.notify_one(); }
+    int size() const { return (int)th_.size(); }
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+              if (q_.empty()) return; f = std::move(q_.front()); q_.pop_front(); }
+            f();
+        }
+    }
+    std::vector<std::thread> th_; std::deque<std::function<void()>> q_; std::mutex mu_; std::condition_variable cv_; bool stop_ = false;
+};
+
+struct TaskGroup {
+    std::mutex mu; std::condition_variable cv; int pending = 0;
+    void add(Pool& p, std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu); pending++; }
+        p.submit([this, f] { f(); { std::lock_guard<std::mutex> lk(mu); pending--; } cv.notify_all(); });
+    }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return pending == 0; }); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BGZF
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+struct BlockRef { uint64_t coff; uint32_t clen; uint32_t isize; uint32_t data_off; uint32_t data_len; uint64_t uoff; };
+
+// parse one BGZF block header at file offset `coff`; returns false at EOF / on malformed data
+static bool bgzf_peek(const uint8_t* map, uint64_t fsize, uint64_t coff, BlockRef* out, std::string* err) {
+    if (coff + 18 > fsize) { if (coff != fsize && err) *err = "truncated BGZF block header"; return false; }
+    const uint8_t* p = map + coff;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { if (err) *err = "not a BGZF block (bad gzip magic)"; return false; }
+    uint32_t xlen = le16(p + 10);
+    if (coff + 12 + xlen > fsize) { if (err) *err = "truncated BGZF extra field"; return false; }
+    const uint8_t* x = p + 12; const uint8_t* xe = x + xlen;
+    int64_t bsize = -1;
+    while (x + 4 <= xe) { uint32_t sl = le16(x + 2); if (x[0] == 'B' && x[1] == 'C' && sl == 2) { bsize = le16(x + 4); } x += 4 + sl; }
+    if (bsize < 0) { if (err) *err = "BGZF block without BC subfield"; return false; }
+    uint32_t total = (uint32_t)bsize + 1;
+    if (coff + total > fsize || total < 12 + xlen + 8) { if (err) *err = "truncated BGZF block"; return false; }
+    out->coff = coff; out->clen = total; out->data_off = 12 + xlen; out->data_len = total - (12 + xlen) - 8;
+    out->isize = le32(p + total - 4); out->uoff = 0;
+    return true;
+}
+
+static bool bgzf_inflate(const uint8_t* map, const BlockRef& b, uint8_t* dst, bool verify_crc, z_stream* zs, std::string* err) {
+    if (b.isize == 0) return true;
+    inflateReset(zs);
+    zs->next_in = const_cast<Bytef*>(map + b.coff + b.data_off); zs->avail_in = b.data_len;
+    zs->next_out = dst; zs->avail_out = b.isize;
+    int rc = inflate(zs, Z_FINISH);
+    if (rc != Z_STREAM_END || zs->avail_out != 0) { if (err) *err = "BGZF inflate failed"; return false; }
+    if (verify_crc) {
+        uint32_t want = le32(map + b.coff + b.clen - 8);
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) != want) { if (err) *err = "BGZF CRC mismatch"; return false; }
+    }
+    return true;
+}
+
+struct ZStream { z_stream zs; bool ok; ZStream() { memset(&zs, 0, sizeof zs); ok = inflateInit2(&zs, -15) == Z_OK; } ~ZStream() { if (ok) inflateEnd(&zs); } };
+static thread_local ZStream t_zs;
+
+}  // namespace xck
+
+using namespace xck;
+
+// ---------------------------------------------------------------------------------------------
+// the BAM file object
+// ---------------------------------------------------------------------------------------------
+struct HostSoA {
+    int32_t* pos = nullptr; uint16_t* flag = nullptr; uint8_t* mapq = nullptr; int32_t* cell = nullptr; uint64_t* umi = nullptr;
+    uint32_t* cig_off = nullptr; uint32_t* cigar = nullptr; uint32_t* seq_off = nullptr; uint8_t* seq = nullptr;
+    size_t cap_reads = 0, cap_cig = 0, cap_seq = 0; bool pinned = false;
+};
+
+struct Chunk {
+    std::vector<BlockRef> blocks;
+    std::vector<uint8_t> ubuf; size_t usize = 0;
+    TaskGroup tg; std::atomic<bool> failed{false}; std::string err; std::mutex emu;
+    bool valid = false;
+};
+
+struct RecRef { const uint8_t* p; uint32_t len; };
+
+struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
+
+struct xck_bam {
+    std::string path; int fd = -1; const uint8_t* map = nullptr; uint64_t fsize = 0;
+    std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
+    uint64_t next_coff = 0;            // next BGZF block to schedule
+    uint32_t first_skip = 0;           // bytes of the first scheduled block that precede the first record
+    bool eof_sched = false;
+    Pool* pool = nullptr; int n_threads = 1;
+    Chunk ch[2]; int cur = 0; bool primed = false;
+    std::vector<uint8_t> carry;        // partial record from the previous chunk
+    std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
+    std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // walk output
+    HostSoA soa;
+    std::deque<PendingBatch> pending;
+    int64_t n_records = 0;             // records walked so far (all, including unused contigs)
+    bool done = false;
+    size_t chunk_target = 48u << 20;   // uncompressed bytes per chunk
+    std::string err;
+};
+
+static void soa_free(HostSoA& s) {
+    void* p[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.cigar, s.seq_off, s.seq };
+    for (void* q : p) if (q) { if (s.pinned) pinned_free(q); else free(q); }
+    s = HostSoA();
+}
+static void* soa_alloc(HostSoA& s, size_t bytes, bool first) {
+    if (first) { void* p = pinned_alloc(bytes); if (p) { s.pinned = true; return p; } s.pinned = false; return malloc(bytes); }
+    return s.pinned ? pinned_alloc(bytes) : malloc(bytes);
+}
+static bool soa_reserve(HostSoA& s, size_t n_reads, size_t n_cig, size_t n_seq) {
+    bool first = s.pos == nullptr && s.cigar == nullptr && s.seq == nullptr;
+    if (n_reads > s.cap_reads) {
+        size_t c = std::max(n_reads, s.cap_reads * 3 / 2);
+        void* old[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.seq_off };
+        for (void* q : old) if (q) { if (s.pinned) pinned_free(q); else free(q); }
+        s.pos = (int32_t*)soa_alloc(s, c * 4, first); first = false;
+        s.flag = (uint16_t*)soa_alloc(s, c * 2, false); s.mapq = (uint8_t*)soa_alloc(s, c, false);
+        s.cell = (int32_t*)soa_alloc(s, c * 4, false); s.umi = (uint64_t*)soa_alloc(s, c * 8, false);
+        s.cig_off = (uint32_t*)soa_alloc(s, (c + 1) * 4, false); s.seq_off = (uint32_t*)soa_alloc(s, (c + 1) * 4, false);
+        s.cap_reads = c;
+        if (!s.pos || !s.flag || !s.mapq || !s.cell || !s.umi || !s.cig_off || !s.seq_off) return false;
+    }
+    if (n_cig > s.cap_cig) { size_t c = std::max(n_cig, s.cap_cig * 3 / 2); if (s.cigar) { if (s.pinned) pinned_free(s.cigar); else free(s.cigar); }
+        s.cigar = (uint32_t*)soa_alloc(s, c * 4, first); first = false; s.cap_cig = c; if (!s.cigar) return false; }
+    if (n_seq > s.cap_seq) { size_t c = std::max(n_seq, s.cap_seq * 3 / 2); if (s.seq) { if (s.pinned) pinned_free(s.seq); else free(s.seq); }
+        s.seq = (uint8_t*)soa_alloc(s, c, first); s.cap_seq = c; if (!s.seq) return false; }
+    return true;
+}
+
+// sequential reader used only for the header
+struct SeqReader {
+    xck_bam* b; uint64_t coff = 0; std::vector<uint8_t> buf; size_t pos = 0; uint64_t blk_coff = 0; size_t blk_start = 0; std::string err;
+    bool fill(size_t need) {
+        while (buf.size() - pos < need) {
+            BlockRef br;
+            if (!bgzf_peek(b->map, b->fsize, coff, &br, &err)) { if (err.empty()) err = "unexpected end of file in BAM header"; return false; }
+            size_t old = buf.size();
+            buf.resize(old + br.isize);
+            if (!t_zs.ok || !bgzf_inflate(b->map, br, buf.data() + old, false, &t_zs.zs, &err)) { if (err.empty()) err = "inflate init failed"; return false; }
+            blk_coff = coff; blk_start = old; coff += br.clen;
+        }
+        return true;
+    }
+};
+
+extern "C" {
+
+int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen) {
+    auto fail = [&](const std::string& m, xck_bam* b) { if (err && errlen) { snprintf(err, errlen, "%s: %s", path ? path : "(null)", m.c_str()); } set_thread_error(m); if (b) xck_bam_close(b); return XCK_E_IO; };
+    if (!path || !out) return fail("null argument", nullptr);
+    xck_bam* b = new xck_bam();
+    b->path = path;
+    b->fd = open(path, O_RDONLY);
+    if (b->fd < 0) return fail("cannot open file", b);
+    struct stat st; if (fstat(b->fd, &st) != 0 || st.st_size < 28) return fail("cannot stat file / file too small", b);
+    b->fsize = (uint64_t)st.st_size;
+    void* m = mmap(nullptr, b->fsize, PROT_READ, MAP_PRIVATE, b->fd, 0);
+    if (m == MAP_FAILED) return fail("mmap failed", b);
+    b->map = (const uint8_t*)m;
+    madvise(m, b->fsize, MADV_SEQUENTIAL);
+    SeqReader r; r.b = b;
+    if (!r.fill(12)) return fail(r.err, b);
+    if (memcmp(r.buf.data(), "BAM\1", 4) != 0) return fail("not a BAM file (bad magic)", b);
+    uint32_t l_text = le32(r.buf.data() + 4);
+    if (!r.fill(12 + (size_t)l_text)) return fail(r.err, b);
+    r.pos = 8 + l_text;
+    uint32_t n_ref = le32(r.buf.data() + r.pos); r.pos += 4;
+    for (uint32_t i = 0; i < n_ref; i++) {
+        if (!r.fill(4)) return fail(r.err, b);
+        uint32_t l_name = le32(r.buf.data() + r.pos); r.pos += 4;
+        if (!r.fill((size_t)l_name + 4)) return fail(r.err, b);
+        b->ref_names.emplace_back((const char*)r.buf.data() + r.pos, l_name ? l_name - 1 : 0); r.pos += l_name;
+        b->ref_lens.push_back((int64_t)le32(r.buf.data() + r.pos)); r.pos += 4;
+    }
+    // first alignment record: inside the last inflated block at offset (r.pos - r.blk_start), or at the next block
+    if (r.pos == r.buf.size()) { b->next_coff = r.coff; b->first_skip = 0; }
+    else { b->next_coff = r.blk_coff; b->first_skip = (uint32_t)(r.pos - r.blk_start); }
+    if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 4; }
+    b->n_threads = n_threads;
+    b->pool = new Pool(n_threads);
+    *out = b;
+    return XCK_OK;
+}
+
+void xck_bam_close(xck_bam* b) {
+    if (!b) return;
+    for (auto& c : b->ch) c.tg.wait();
+    delete b->pool;
+    soa_free(b->soa);
+    if (b->map) munmap((void*)b->map, b->fsize);
+    if (b->fd >= 0) close(b->fd);
+    delete b;
+}
+
+int xck_bam_n_refs(const xck_bam* b) { return b ? (int)b->ref_names.size() : 0; }
+const char* xck_bam_ref_name(const xck_bam* b, int tid) { return (b && tid >= 0 && tid < (int)b->ref_names.size()) ? b->ref_names[tid].c_str() : nullptr; }
+int64_t xck_bam_ref_len(const xck_bam* b, int tid) { return (b && tid >= 0 && tid < (int)b->ref_lens.size()) ? b->ref_lens[tid] : -1; }
+
+}  // extern "C"
+
+// schedule the inflate of the next chunk into c (asynchronous)
+static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc) {
+    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear();
+    if (b->eof_sched) return;
+    uint64_t coff = b->next_coff; size_t usz = 0;
+    while (usz < b->chunk_target) {
+        BlockRef br; std::string e;
+        if (!bgzf_peek(b->map, b->fsize, coff, &br, &e)) { b->eof_sched = true; if (!e.empty()) { c.failed = true; c.err = e; } break; }
+        br.uoff = usz; usz += br.isize; coff += br.clen;
+        c.blocks.push_back(br);
+    }
+    b->next_coff = coff;
+    if (c.blocks.empty() && !c.failed) return;
+    c.valid = true; c.usize = usz;
+    if (c.ubuf.size() < usz + 8) c.ubuf.resize(usz + 8);
+    const size_t nb = c.blocks.size();
+    const size_t per = std::max<size_t>(1, (nb + (size_t)b->n_threads * 4 - 1) / ((size_t)b->n_threads * 4));
+    for (size_t i0 = 0; i0 < nb; i0 += per) {
+        size_t i1 = std::min(nb, i0 + per);
+        Chunk* cp = &c; const uint8_t* map = b->map;
+        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc] {
+            if (!t_zs.ok) { cp->failed = true; return; }
+            for (size_t i = i0; i < i1; i++) {
+                std::string e;
+                if (!bgzf_inflate(map, cp->blocks[i], cp->ubuf.data() + cp->blocks[i].uoff, verify_crc, &t_zs.zs, &e)) {
+                    std::lock_guard<std::mutex> lk(cp->emu); cp->failed = true; cp->err = e; return;
+                }
+            }
+        });
+    }
+}
+
+// locate a 2-character aux tag; returns pointer to the type byte or nullptr
+static inline const uint8_t* aux_skip(const uint8_t* p, const uint8_t* e) {       // p at type byte; returns next tag or nullptr
+    if (p >= e) return nullptr;
+    uint8_t t = *p++;
+    switch (t) {
+        case 'A': case 'c': case 'C': p += 1; break;
+        case 's': case 'S': p += 2; break;
+        case 'i': case 'I': case 'f': p += 4; break;
+        case 'Z': case 'H': while (p < e && *p) p++; p++; break;
+        case 'B': { if (p + 5 > e) return nullptr; uint8_t st = *p; uint32_t n = le32(p + 1); p += 5;
+                    size_t sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; p += (size_t)n * sz; break; }
+        default: return nullptr;
+    }
+    return p <= e ? p : nullptr;
+}
+
+static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, int64_t r1, std::atomic<int>* flags) {
+    const DecodeCfg& dc = e->dec;
+    HostSoA& s = b->soa;
+    for (int64_t r = r0; r < r1; r++) {
+        int64_t o = b->rec_out[r];
+        if (o < 0) continue;
+        const uint8_t* p = b->recs[r].p; const uint8_t* end = p + b->recs[r].len;
+        uint32_t l_name = p[8], n_cig = le16(p + 12), l_seq = le32(p + 16);
+        s.pos[o] = (int32_t)le32(p + 4);
+        s.mapq[o] = p[9];
+        s.flag[o] = le16(p + 14);
+        const uint8_t* q = p + 32;
+        const char* qname = (const char*)q; size_t qlen = l_name ? l_name - 1 : 0;
+        q += l_name;
+        if (q + (size_t)n_cig * 4 + (l_seq + 1) / 2 + l_seq > end) { flags->fetch_or(1); s.cell[o] = -1; s.umi[o] = XCK_UMI_NONE; continue; }
+        memcpy(s.cigar + s.cig_off[o], q, (size_t)n_cig * 4);
+        q += (size_t)n_cig * 4;
+        if (dc.want_seq) memcpy(s.seq + s.seq_off[o], q, (l_seq + 1) / 2);
+        q += (l_seq + 1) / 2 + l_seq;
+        // aux tags: first occurrence wins (htslib bam_aux_get)
+        const uint8_t* cb = nullptr; const uint8_t* ub = nullptr;
+        bool need_cb = dc.use_barcodes, need_ub = dc.use_umi;
+        const uint8_t* a = q;
+        while ((need_cb || need_ub) && a && a + 3 <= end) {
+            if (need_cb && a[0] == (uint8_t)dc.cell_tag[0] && a[1] == (uint8_t)dc.cell_tag[1]) { cb = a + 2; need_cb = false; }
+            else if (need_ub && a[0] == (uint8_t)dc.umi_tag[0] && a[1] == (uint8_t)dc.umi_tag[1]) { ub = a + 2; need_ub = false; }
+            a = aux_skip(a + 2, end);
+        }
+        int32_t cell = -1;
+        if (dc.use_barcodes) {
+            if (cb && (*cb == 'Z' || *cb == 'A' || *cb == 'H')) {         // get_tag() returns str only for these
+                const char* v = (const char*)cb + 1; size_t n = (*cb == 'A') ? 1 : strnlen(v, (size_t)(end - (cb + 1)));
+                cell = dc.lookup_cell(v, n);
+            }
+        } else cell = sample;
+        s.cell[o] = cell;
+        uint64_t key = XCK_UMI_NONE; bool ovf = false;
+        if (dc.use_umi) {
+            if (ub) {
+                if (*ub == 'Z' || *ub == 'A' || *ub == 'H') {
+                    const char* v = (const char*)ub + 1; size_t n = (*ub == 'A') ? 1 : strnlen(v, (size_t)(end - (ub + 1)));
+                    key = encode_key(v, n, dc.umi_bits, e->intern, &ovf);
+                } else {                                                   // numeric tag: a non-string key; intern its bytes
+                    const uint8_t* nx = aux_skip(ub, end);
+                    std::string t("\1num:"); if (nx) t.append((const char*)ub, (size_t)(nx - ub));
+                    key = encode_key(t.data(), t.size(), dc.umi_bits, e->intern, &ovf);
+                }
+            }
+        } else key = encode_key(qname, qlen, dc.umi_bits, e->intern, &ovf);
+        if (ovf) flags->fetch_or(2);
+        s.umi[o] = key;
+    }
+}
+
+// decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
+static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
+    const bool crc = e->dec.verify_crc;
+    if (!b->primed) { schedule_chunk(b, b->ch[0], crc); b->cur = 0; b->primed = true; }
+    Chunk& c = b->ch[b->cur];
+    if (!c.valid && !c.failed) {
+        if (!b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
+        return 0;
+    }
+    c.tg.wait();
+    if (c.failed) { b->err = c.err.empty() ? "BGZF decode error" : c.err; return XCK_E_IO; }
+    // start inflating the following chunk while this one is walked and parsed
+    Chunk& nx = b->ch[b->cur ^ 1];
+    schedule_chunk(b, nx, crc);
+    // ---- record walk (serial) ----
+    b->recs.clear(); b->rec_contig.clear();
+    const uint8_t* u = c.ubuf.data(); size_t usz = c.usize; size_t off = 0;
+    if (b->first_skip) { off = b->first_skip; b->first_skip = 0; if (off > usz) { b->err = "corrupt BAM header offset"; return XCK_E_IO; } }
+    b->stitch.clear();
+    if (!b->carry.empty()) {
+        b->stitch = b->carry; b->carry.clear();
+        while (b->stitch.size() < 4 && off < usz) b->stitch.push_back(u[off++]);
+        if (b->stitch.size() >= 4) {
+            uint32_t bs = le32(b->stitch.data());
+            size_t need = 4 + (size_t)bs - b->stitch.size();
+            if (need <= usz - off) { b->stitch.insert(b->stitch.end(), u + off, u + off + need); off += need; }
+            else { b->stitch.insert(b->stitch.end(), u + off, u + usz); off = usz; b->carry.swap(b->stitch); }   // record larger than a chunk
+        } else { b->carry.swap(b->stitch); }
+    }
+    const int n_refs = (int)b->ref_names.size();
+    auto add_rec = [&](const uint8_t* p, uint32_t len) -> bool {
+        if (len < 32) return false;
+        int32_t tid = (int32_t)le32(p);
+        int32_t ctg = (tid >= 0 && tid < n_refs && o->tid_to_contig) ? o->tid_to_contig[tid] : -1;
+        b->recs.push_back({p, len}); b->rec_contig.push_back(ctg);
+        return true;
+    };
+    if (!b->stitch.empty()) { if (!add_rec(b->stitch.data() + 4, (uint32_t)b->stitch.size() - 4)) { b->err = "corrupt BAM record"; return XCK_E_IO; } }
+    while (off + 4 <= usz) {
+        uint32_t bs = le32(u + off);
+        if (off + 4 + (size_t)bs > usz) break;
+        if (!add_rec(u + off + 4, bs)) { b->err = "corrupt BAM record (block_size < 32)"; return XCK_E_IO; }
+        off += 4 + (size_t)bs;
+    }
+    if (off < usz) b->carry.insert(b->carry.end(), u + off, u + usz);
+    // ---- output layout: prefix sums + batch segmentation ----
+    const int64_t nrec = (int64_t)b->recs.size();
+    int64_t limit = nrec;
+    if (o->max_records > 0 && b->n_records + nrec > o->max_records) { limit = std::max<int64_t>(0, o->max_records - b->n_records); }
+    b->rec_out.assign(nrec, -1);
+    size_t n_out = 0, n_cig = 0, n_seq = 0;
+    for (int64_t r = 0; r < limit; r++) if (b->rec_contig[r] >= 0) {
+        const uint8_t* p = b->recs[r].p; n_out++; n_cig += le16(p + 12); n_seq += (le32(p + 16) + 1) / 2; }
+    if (n_cig >= (size_t(1) << 32) || n_seq >= (size_t(1) << 32)) { b->err = "chunk too large"; return XCK_E_IO; }
+    if (!soa_reserve(b->soa, n_out + 1, n_cig + 1, e->dec.want_seq ? n_seq + 1 : 1)) { b->err = "out of host memory"; return XCK_E_NOMEM; }
+    HostSoA& s = b->soa;
+    b->pending.clear();
+    { size_t oi = 0; uint32_t co = 0, so = 0; int32_t cur_c = -1; int64_t seg0 = 0, seg_r = 0;
+      const uint64_t ord_hi = (uint64_t)(uint32_t)o->sample << ORD_REC_BITS;
+      s.cig_off[0] = 0; s.seq_off[0] = 0;
+      for (int64_t r = 0; r < limit; r++) {
+          int32_t ctg = b->rec_contig[r];
+          if (ctg != cur_c) {                                     // a run of records on one contig = one batch
+              if (cur_c >= 0 && (int64_t)oi > seg0) b->pending.push_back({cur_c, seg0, (int64_t)oi, ord_hi | (uint64_t)(b->n_records + seg_r)});
+              cur_c = ctg; seg0 = (int64_t)oi; seg_r = r;
+          }
+          if (ctg < 0) continue;
+          const uint8_t* p = b->recs[r].p;
+          b->rec_out[r] = (int64_t)oi;
+          co += le16(p + 12); so += e->dec.want_seq ? (le32(p + 16) + 1) / 2 : 0; oi++;
+          s.cig_off[oi] = co; s.seq_off[oi] = so;
+      }
+      if (cur_c >= 0 && (int64_t)oi > seg0) b->pending.push_back({cur_c, seg0, (int64_t)oi, ord_hi | (uint64_t)(b->n_records + seg_r)});
+    }
+    // ---- parse (parallel) ----
+    std::atomic<int> flags{0};
+    { TaskGroup tg; const int64_t per = std::max<int64_t>(4096, (limit + b->n_threads * 4 - 1) / (b->n_threads * 4));
+      for (int64_t r0 = 0; r0 < limit; r0 += per) { int64_t r1 = std::min(limit, r0 + per); int32_t smp = o->sample;
+          tg.add(*b->pool, [b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }); }
+      tg.wait(); }
+    if (flags.load() & 1) { b->err = "corrupt BAM record (fields exceed block_size)"; return XCK_E_IO; }
+    if (flags.load() & 2) { b->err = "too many distinct non-ACGT keys for the key width"; return XCK_E_CAPACITY; }
+    b->n_records += limit;
+    b->cur ^= 1;
+    if (limit < nrec) { b->done = true; nx.tg.wait(); }
+    return 1;
+}
+
+extern "C" {
+
+int xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) {
+    if (!e || !b || !o || !out) return XCK_E_ARG;
+    while (b->pending.empty()) {
+        if (b->done) return 0;
+        int rc = decode_next_chunk(e, b, o);
+        if (rc < 0) { e->err = b->path + ": " + b->err; return rc; }
+        if (rc == 0) { b->done = true; return 0; }
+    }
+    PendingBatch pb = b->pending.front(); b->pending.pop_front();
+    HostSoA& s = b->soa;
+    memset(out, 0, sizeof *out);
+    out->contig = pb.contig; out->n_reads = (int32_t)(pb.r1 - pb.r0); out->ordinal_base = pb.ordinal_base;
+    out->pos = s.pos + pb.r0; out->flag = s.flag + pb.r0; out->mapq = s.mapq + pb.r0; out->cell = s.cell + pb.r0; out->umi = s.umi + pb.r0;
+    out->cig_off = s.cig_off + pb.r0; out->cigar = s.cigar;
+    if (e->dec.want_seq) { out->seq_off = s.seq_off + pb.r0; out->seq = s.seq; }
+    return 1;
+}
+
+int xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) {
+    if (!e || !b || !o) return XCK_E_ARG;
+    xck_batch bt;
+    int rc;
+    while ((rc = xck_bam_next_batch(e, b, o, &bt)) == 1) {
+        int prc = engine_push(e, &bt, false);
+        if (prc) return prc;
+    }
+    if (n_records) *n_records = b->n_records;
+    return rc < 0 ? rc : XCK_OK;
+}
+
+}  // extern "C"

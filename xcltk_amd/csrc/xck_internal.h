@@ -1,0 +1,101 @@
+// xck_internal.h - shared declarations between the HIP engine, the BAM decoder and the C-ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <mutex>
+#include "../../include/xck.h"
+
+#define XCK_VERSION_STR "0.1.0 (gfx950)"
+
+namespace xck {
+
+// BAM flag bits used by check_read (reference xcltk/utils/sam.py:120-121)
+constexpr uint32_t BAM_FPAIRED = 1, BAM_FPROPER_PAIR = 2, BAM_FUNMAP = 4;
+
+// ordinal layout: (bam_index << 40) | record number ; value word of a pileup hit:
+// (ordinal << 5) | (allele nibble + 1), 0 in the low 5 bits = "read has no base at the SNP"
+constexpr int ORD_REC_BITS = 40;
+constexpr int ALLELE_BITS = 5;
+
+// Host-side string -> dense id table for keys that cannot be 2-bit coded (IUPAC UMIs,
+// read names in UMI-less mode).  Sharded so decoder threads can intern concurrently.
+class InternTable {
+public:
+    static constexpr int NSHARD = 64;
+    uint64_t intern(const char* s, size_t n);
+    uint64_t size() const;
+    void clear();
+private:
+    struct Shard { std::mutex mu; std::unordered_map<std::string, uint64_t> map; };
+    Shard shards_[NSHARD];
+    // id = (local index << 6) | shard  -> unique without a global counter
+};
+
+// Decoder settings derived from xck_config at xck_create()
+struct DecodeCfg {
+    bool use_barcodes = false;
+    bool use_umi = false;
+    char cell_tag[2] = {0, 0};
+    char umi_tag[2] = {0, 0};
+    int  umi_bits = 64;
+    bool want_seq = false;
+    bool verify_crc = false;
+    int  n_threads = 0;
+    int64_t max_batch_reads = 0;
+    // barcode hash (open addressing over the barcode strings)
+    std::vector<std::string> barcodes;
+    std::vector<int32_t> bc_slots;       // size pow2, -1 empty
+    uint64_t bc_mask = 0;
+    int32_t lookup_cell(const char* s, size_t n) const;
+    void build_barcodes(const char* const* names, int n);
+};
+
+uint64_t hash_bytes(const char* s, size_t n);
+// 2-bit / interned key code, see include/xck.h xck_umi_bits()
+uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, bool* overflow);
+
+// key layout rule shared by engine and decoder: 64-bit keys (row | cell | umi) when the UMI code
+// gets >= 26 bits, otherwise 128-bit keys with a 64-bit UMI code.
+struct KeyBits { int key_bits, ubits, cbits, rbits; };
+inline int bits_for_count(int64_t n) { int b = 1; while ((int64_t(1) << b) < n) b++; return b; }
+inline KeyBits key_layout(const xck_config* cfg) {
+    KeyBits k;
+    k.cbits = bits_for_count(cfg->n_cells > 2 ? cfg->n_cells : 2);
+    k.rbits = bits_for_count(cfg->n_regions > 2 ? cfg->n_regions : 2);
+    if (cfg->mode == XCK_MODE_BAF) { int sb = bits_for_count(cfg->n_snps > 2 ? cfg->n_snps : 2); if (sb > k.rbits) k.rbits = sb; }
+    int ub = 64 - k.rbits - k.cbits;
+    if ((cfg->flags & XCK_F_FORCE_KEY128) || ub < 26) { k.key_bits = 128; k.ubits = 64; }
+    else { k.key_bits = 64; k.ubits = ub; }
+    return k;
+}
+
+void set_thread_error(const std::string& s);
+const char* get_thread_error();
+
+}  // namespace xck
+
+// The engine object behind the opaque C handle.
+struct xck_engine {
+    std::string err;
+    xck::DecodeCfg dec;
+    xck::InternTable intern;
+    void* impl = nullptr;                // xck::EngineImpl (engine.hip); null for decode-only handles
+    int umi_bits = 64;
+    // host pinned batch staging used by xck_ingest_bam lives in the xck_bam
+};
+
+// implemented in engine.hip
+namespace xck {
+int  engine_create(const xck_config* cfg, xck_engine* e);
+void engine_destroy(xck_engine* e);
+int  engine_push(xck_engine* e, const xck_batch* b, bool device_resident);
+int  engine_flush(xck_engine* e);
+int  engine_finish(xck_engine* e, xck_result* out);
+int  engine_reset(xck_engine* e);
+int  engine_stats(const xck_engine* e, xck_stats* out);
+int  engine_umi_bits(const xck_engine* e);
+void* pinned_alloc(size_t bytes);        // hipHostMalloc, falls back to malloc when no device
+void  pinned_free(void* p);
+}

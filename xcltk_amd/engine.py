@@ -1,0 +1,221 @@
+"""engine.py - Python handle on the HIP counting engine (libxck.so) through the C-ABI.
+
+One `Engine` drives one GPU.  It owns the region / SNP tables, the decoder settings
+(barcode list, tag names) and the device-side hit accumulators; BAM files are streamed
+through it once (`ingest_bam`) or record batches are pushed directly (`push`), and
+`finish()` returns the sparse matrices as COO triplets.
+
+There is no CPU compute path here: constructing an Engine without a usable HIP device
+raises (the only exception is `decode_only=True`, which gives access to the host BAM
+decoder alone and refuses push/finish).
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import XCK_MODE_BAF, XCK_MODE_BASEFC
+
+
+class XckError(RuntimeError):
+    pass
+
+
+def resolve_contigs(bam_refs, contig_names):
+    """tid -> engine contig id, with the reference's chr-prefix tolerance
+    (sam_fetch, xcltk/utils/sam.py:105-118: try the name, then the name with 'chr'
+    added / removed)."""
+    tid_of = {}
+    for i, n in enumerate(bam_refs):
+        tid_of.setdefault(n, i)
+    t2c = np.full(len(bam_refs), -1, dtype=np.int32)
+    for ci, x in enumerate(contig_names):
+        if x in tid_of:
+            t2c[tid_of[x]] = ci
+        else:
+            y = x[3:] if x.startswith("chr") else "chr" + x
+            if y in tid_of:
+                t2c[tid_of[y]] = ci
+    return t2c
+
+
+class Engine(object):
+    def __init__(self, mode, contig_names, regions, n_cells, snps=(), barcodes=None,
+                 cell_tag=None, umi_tag=None, device=0, min_mapq=20, min_len=30,
+                 incl_flag=0, excl_flag=772, no_orphan=True, min_include=0.9, min_count=1,
+                 min_maf=0, no_dup_hap=True, n_threads=0, flags=0, decode_only=False):
+        """regions: iterable of (chrom, start1, end1_incl[, name]); snps: iterable of
+        (chrom, pos1, ref, alt, ref_hap, alt_hap); chrom names must already be stripped of
+        'chr' and present in contig_names."""
+        self.lib = capi.load()
+        self.mode = mode
+        self.contig_names = list(contig_names)
+        cidx = {n: i for i, n in enumerate(self.contig_names)}
+        regions = list(regions)
+        snps = list(snps)
+        self._reg = np.zeros(len(regions), dtype=capi.REGION_DTYPE)
+        for i, r in enumerate(regions):
+            self._reg[i] = (cidx[r[0]], r[1], r[2])
+        self._snp = np.zeros(len(snps), dtype=capi.SNP_DTYPE)
+        for i, s in enumerate(snps):
+            self._snp[i] = (cidx[s[0]], s[1], ord(s[2]), ord(s[3]), s[4], s[5])
+        cfg = capi.Config()
+        cfg.struct_size = C.sizeof(capi.Config)
+        cfg.mode = mode
+        cfg.device = device
+        cfg.min_mapq = float(min_mapq)
+        cfg.min_len = int(min_len)
+        cfg.incl_flag = int(incl_flag)
+        cfg.excl_flag = int(excl_flag)
+        cfg.no_orphan = 1 if no_orphan else 0
+        cfg.min_include = float(min_include)
+        cfg.min_count = float(min_count)
+        cfg.min_maf = float(min_maf)
+        cfg.no_dup_hap = 1 if no_dup_hap else 0
+        cfg.n_cells = int(n_cells)
+        cfg.n_contigs = len(self.contig_names)
+        cfg.n_regions = len(regions)
+        cfg.regions = self._reg.ctypes.data_as(C.POINTER(capi.Region))
+        cfg.n_snps = len(snps)
+        cfg.snps = self._snp.ctypes.data_as(C.POINTER(capi.Snp))
+        self._bc = None
+        if barcodes is not None:
+            assert len(barcodes) == n_cells
+            self._bc = (C.c_char_p * len(barcodes))(*[b.encode("ascii") for b in barcodes])
+            cfg.barcodes = C.cast(self._bc, C.POINTER(C.c_char_p))
+            if not cell_tag or len(cell_tag) != 2:
+                raise ValueError("cell_tag must be a 2-character tag when barcodes are given")
+            cfg.cell_tag = cell_tag.encode("ascii")
+        if umi_tag:
+            if len(umi_tag) != 2:
+                raise ValueError("umi_tag must be a 2-character tag")
+            cfg.umi_tag = umi_tag.encode("ascii")
+        cfg.n_threads = int(n_threads)
+        cfg.flags = int(flags) | (capi.XCK_F_DECODE_ONLY if decode_only else 0)
+        self.cfg = cfg
+        self.n_cells = int(n_cells)
+        self.n_regions = len(regions)
+        h = C.c_void_p()
+        rc = self.lib.xck_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise XckError("xck_create failed (%d): %s" % (rc, self.lib.xck_last_error(None).decode()))
+        self.h = h
+        self.umi_bits = self.lib.xck_umi_bits(self.h)
+        self._result = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.xck_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise XckError("%s failed (%d): %s" % (what, rc, self.lib.xck_last_error(self.h).decode()))
+
+    # ------------------------------------------------------------------ data path
+    def push(self, batch, device_resident=False):
+        fn = self.lib.xck_push_batch_device if device_resident else self.lib.xck_push_batch
+        self._check(fn(self.h, C.byref(batch)), "xck_push_batch")
+
+    def flush(self):
+        self._check(self.lib.xck_flush(self.h), "xck_flush")
+
+    def reset(self):
+        self._check(self.lib.xck_reset(self.h), "xck_reset")
+        self._result = None
+
+    def _open(self, path, n_threads=0):
+        b = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self.lib.xck_bam_open(path.encode(), n_threads, C.byref(b), err, 512)
+        if rc != 0:
+            raise XckError("xck_bam_open failed (%d): %s" % (rc, err.value.decode()))
+        refs = [self.lib.xck_bam_ref_name(b, i).decode() for i in range(self.lib.xck_bam_n_refs(b))]
+        return b, refs
+
+    def _opts(self, refs, sample, max_records=0):
+        t2c = resolve_contigs(refs, self.contig_names)
+        o = capi.IngestOpts()
+        o.struct_size = C.sizeof(capi.IngestOpts)
+        o.sample = sample
+        o.tid_to_contig = t2c.ctypes.data_as(C.POINTER(C.c_int32))
+        o.max_records = max_records
+        return o, t2c
+
+    def ingest_bam(self, path, sample=0, n_threads=0, max_records=0):
+        """Decode one BAM file and run the join kernels on every batch. Returns #records."""
+        b, refs = self._open(path, n_threads or self.cfg.n_threads)
+        try:
+            o, keep = self._opts(refs, sample, max_records)
+            n = C.c_int64(0)
+            self._check(self.lib.xck_ingest_bam(self.h, b, C.byref(o), C.byref(n)), "xck_ingest_bam")
+            return int(n.value)
+        finally:
+            self.lib.xck_bam_close(b)
+
+    def decode_bam(self, path, sample=0, n_threads=0, max_records=0):
+        """Pull-style decode (tests / inspection): yields dicts of numpy copies per batch."""
+        b, refs = self._open(path, n_threads or self.cfg.n_threads)
+        try:
+            o, keep = self._opts(refs, sample, max_records)
+            bt = capi.Batch()
+            while True:
+                rc = self.lib.xck_bam_next_batch(self.h, b, C.byref(o), C.byref(bt))
+                if rc == 0:
+                    break
+                if rc < 0:
+                    self._check(rc, "xck_bam_next_batch")
+                n = bt.n_reads
+                as_np = np.ctypeslib.as_array
+                d = dict(contig=bt.contig, n_reads=n, ordinal_base=int(bt.ordinal_base),
+                         pos=as_np(bt.pos, (n,)).copy(), flag=as_np(bt.flag, (n,)).copy(),
+                         mapq=as_np(bt.mapq, (n,)).copy(), cell=as_np(bt.cell, (n,)).copy(),
+                         umi=as_np(bt.umi, (n,)).copy(), cig_off=as_np(bt.cig_off, (n + 1,)).copy())
+                c_hi = int(d["cig_off"][-1])
+                d["cigar"] = as_np(bt.cigar, (max(c_hi, 1),)).copy()
+                if bt.seq_off:
+                    d["seq_off"] = as_np(bt.seq_off, (n + 1,)).copy()
+                    d["seq"] = as_np(bt.seq, (max(int(d["seq_off"][-1]), 1),)).copy()
+                yield d
+        finally:
+            self.lib.xck_bam_close(b)
+
+    def finish(self):
+        """-> {"count": (row, col, val)} or {"ad": .., "dp": .., "oth": ..}; rows are 0-based
+        region indices (input order), cols 0-based cell indices, sorted by (row, col)."""
+        res = capi.Result()
+        self._check(self.lib.xck_finish(self.h, C.byref(res)), "xck_finish")
+        self._result = res
+        if self.mode == XCK_MODE_BASEFC:
+            return {"count": res.count.to_numpy()}
+        return {"ad": res.ad.to_numpy(), "dp": res.dp.to_numpy(), "oth": res.oth.to_numpy()}
+
+    def write_mtx(self, path, name, row_map, n_rows_out):
+        """Write matrix `name` of the last finish() in the reference's exact text format."""
+        if self._result is None:
+            raise XckError("finish() first")
+        coo = getattr(self._result, name)
+        rm = np.ascontiguousarray(row_map, dtype=np.int32)
+        rc = self.lib.xck_write_mtx(path.encode(), C.byref(coo), rm.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    int(n_rows_out), self.n_cells)
+        if rc != 0:
+            raise XckError("xck_write_mtx failed (%d)" % rc)
+
+    def stats(self):
+        st = capi.Stats()
+        self._check(self.lib.xck_get_stats(self.h, C.byref(st)), "xck_get_stats")
+        return {k: getattr(st, k) for k, _ in capi.Stats._fields_}
