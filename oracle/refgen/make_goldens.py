@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""make_goldens.py - CONTAINER-ONLY: build tests/golden/ by running the unmodified reference.
+
+For every case: inputs come from this repo's seeded generator (xcltk_amd/synth) or are
+hand-built with its BAM writer; expected outputs are what hxj5/xcltk v0.5.2 itself writes
+(fc_wrapper / afc_wrapper / `xcltk basefc` CLI) when run through oracle/refgen/run_reference.py.
+Only data is stored: input files, the reference's output files, and a case.json with the
+call arguments.  Re-run with:  python oracle/refgen/make_goldens.py
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from xcltk_amd.synth.bamwriter import BamWriter            # noqa: E402
+from xcltk_amd.synth.generate import make_10x_dataset, make_smartseq_dataset, write_tables  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+PY39 = "/opt/conda/bin/python3.9"
+RUNNER = os.path.join(HERE, "run_reference.py")
+
+
+def md5(fn):
+    return hashlib.md5(open(fn, "rb").read()).hexdigest()
+
+
+def keep_only(d, names):
+    for f in os.listdir(d):
+        if f not in names:
+            p = os.path.join(d, f)
+            shutil.rmtree(p) if os.path.isdir(p) else os.remove(p)
+
+
+# ------------------------------------------------------------------------------- datasets
+def ds_c1(d):
+    p = make_10x_dataset(d, n_reads=10000, n_barcodes=1000, n_snps=500, n_genes=200,
+                         contigs=(("chr1", 2000000),), seed=1)
+    return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
+
+
+def ds_dense(d):
+    # BAM contigs are bare ("1") while regions / SNPs say "chr1": exercises sam_fetch's fallback
+    p = make_10x_dataset(d, n_reads=6000, n_barcodes=40, n_snps=400, n_genes=30,
+                         contigs=(("chr1", 300000),), seed=7, bam_contig_prefix="",
+                         align_records=False, frac_cb_outside=0.04)
+    return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
+
+
+def ds_multibam(d):
+    p = make_10x_dataset(d, n_reads=5000, n_barcodes=50, n_snps=300, n_genes=40,
+                         contigs=(("chr1", 400000), ("chr2", 300000)), seed=9, n_bams=2)
+    return dict(bams=["possorted_0.bam", "possorted_1.bam"], barcodes="barcodes.tsv")
+
+
+def ds_well(d):
+    p = make_smartseq_dataset(d, n_cells=6, reads_per_cell=800, n_snps=300, n_genes=40,
+                              contigs=(("1", 400000),), seed=5)
+    # relative BAM list so the fixture is relocatable
+    names = [os.path.basename(x) for x in p["bams"]]
+    return dict(bams=names, sample_ids=p["sample_ids"])
+
+
+def ds_special(d):
+    """Hand-built corner cases: H/P/=/X ops, leading I, N/IUPAC/'=' bases at SNPs, empty UB,
+    integer-typed UB, CB missing / not in list, low MAPQ, duplicates, secondary, unmapped-with-pos,
+    reads with no CIGAR, reads spanning a region only through an N gap, nested regions,
+    duplicate SNP positions, SNP with ref == alt, chrom naming CHR1 / chr1 / 1."""
+    os.makedirs(d, exist_ok=True)
+    contigs = [("chr1", 100000), ("chr2", 50000), ("chrUn", 1000)]
+    bw = BamWriter(os.path.join(d, "possorted.bam"), contigs, align_records=False, block_payload=700)
+    cells = ["AAAC-1", "AAAG-1", "AACT-1", "CCGT-1"]
+    R = []
+
+    def rd(tid, pos, cig, seq, cb="AAAC-1", ub="ACGTACGTAC", flag=0, mapq=255, extra=()):
+        tags = []
+        if cb is not None:
+            tags.append(("CB", cb))
+        if ub is not None:
+            tags.append(ub if isinstance(ub, tuple) else ("UB", ub))
+        tags += list(extra)
+        R.append((tid, pos, "q%04d" % len(R), flag, mapq, cig, seq, tags))
+
+    A, C, G, T = "A" * 200, "C" * 200, "G" * 200, "T" * 200
+    # --- region g1 chr1:1001-2000 ; SNPs at 1100 (A>G 0|1), 1150 (C>T 1|0), 1150 dup (C>T 0|1), 1200 (N>A)
+    rd(0, 1050, "100M", A[:100], ub="AAAAAAAAAA")                       # covers 1100(A) 1150? pos0 1050..1149 -> snp 1100 only
+    rd(0, 1060, "100M", G[:100], ub="AAAAAAAAAA")                       # same UMI, later read: ignored for 1100; first for 1150 (G)
+    rd(0, 1090, "5H20M5H", "G" * 20, ub="CCCCCCCCCC")                   # hard clips
+    rd(0, 1095, "3S10=2X5M", "TTT" + "G" * 17, ub="GGGGGGGGGG")         # '=' and X ops, soft clip
+    rd(0, 1080, "10M30N10M", C[:20], ub="TTTTTTTTTT")                   # N gap skips 1100 -> allele None, holds UMI
+    rd(0, 1096, "20M", G[:20], ub="TTTTTTTTTT")                         # ignored (UMI already seen at 1100)
+    rd(0, 1098, "2I18M", "AA" + "G" * 18, ub="ACACACACAC")              # leading insertion
+    rd(0, 1090, "9M2D9M", "G" * 18, ub="AGAGAGAGAG")                    # deletion covering 1100? ref 1090..1098,D 1099-1100,...
+    rd(0, 1099, "1M", "N", ub="ATATATATAT", mapq=255)                   # too short (min_len)
+    rd(0, 1070, "40M", "A" * 29 + "N" + "A" * 10, ub="CACACACACA")      # N base at SNP 1100 (pos0 1099 = offset 29)
+    rd(0, 1070, "40M", "A" * 29 + "R" + "A" * 10, ub="CGCGCGCGCG")      # IUPAC base
+    rd(0, 1070, "40M", "A" * 29 + "=" + "A" * 10, ub="CTCTCTCTCT")      # '=' base
+    rd(0, 1070, "40M", "A" * 40, ub="")                                 # empty UB -> ignored
+    rd(0, 1070, "40M", "A" * 40, ub=("UB", 7, "i"))                     # integer UB
+    rd(0, 1070, "40M", "A" * 40, cb=None)                               # no CB
+    rd(0, 1070, "40M", "A" * 40, cb="ZZZZ-1")                           # CB not in list
+    rd(0, 1070, "40M", "G" * 40, ub="GAGAGAGAGA", mapq=3)               # low MAPQ
+    rd(0, 1070, "40M", "G" * 40, ub="GCGCGCGCGC", flag=1024)            # duplicate flag
+    rd(0, 1070, "40M", "G" * 40, ub="GTGTGTGTGT", flag=256)             # secondary
+    rd(0, 1070, "40M", "G" * 40, ub="TATATATATA", flag=4)               # unmapped flag with coordinates
+    rd(0, 1070, "*", "G" * 40, ub="TCTCTCTCTC")                         # no CIGAR
+    rd(0, 1070, "40M", "G" * 40, ub="TGTGTGTGTG", flag=1)               # paired, not proper (orphan)
+    rd(0, 1070, "40M", "G" * 40, ub="TGTGTGTGTA", flag=3)               # proper pair
+    rd(0, 1120, "60M", "T" * 60, cb="AAAG-1", ub="AAAAAAAAAA")          # other cell, covers 1150 (T = alt)
+    rd(0, 1120, "60M", "C" * 60, cb="AAAG-1", ub="AAAAAAAAAC")
+    rd(0, 1120, "60M", "T" * 60, cb="AACT-1", ub="AAAAAAAAAG")
+    rd(0, 1180, "40M", "A" * 40, cb="AACT-1", ub="AAAAAAAAAT")          # covers 1200 (N>A): A = alt
+    rd(0, 1180, "40M", "N" * 40, cb="AACT-1", ub="AAAAAAAACA")          # N = ref of that SNP
+    # --- read spanning g2 (chr1:3001-3100) only through an N gap; g3 nested in g4
+    rd(0, 2950, "40M200N40M", A[:80], ub="CCCCCCCCCA")
+    rd(0, 5000, "91M", A[:91], ub="CCCCCCCCCG")
+    rd(0, 5040, "91M", A[:91], ub="CCCCCCCCCG")
+    rd(0, 5040, "91M", A[:91], ub="CCCCCCCCCT", cb="CCGT-1")
+    rd(0, 5950, "91M", A[:91], ub="CCCCCCCCAA")                          # 51 bases inside g4 end (6000)
+    rd(0, 5905, "91M", A[:91], ub="CCCCCCCCAC")                          # 96 -> all inside? ends 5995
+    rd(0, 5918, "91M", A[:91], ub="CCCCCCCCAG")                          # 82/91 = 0.901 inside
+    rd(0, 5919, "91M", A[:91], ub="CCCCCCCCAT")                          # 81/91 = 0.890 inside
+    # --- chr2 (regions file says "CHR2" / "2")
+    rd(1, 100, "50M", C[:50], cb="CCGT-1", ub="GGGGGGGGGA")
+    rd(1, 120, "50M", C[:50], cb="CCGT-1", ub="GGGGGGGGGA")
+    rd(1, 120, "50M", "C" * 30 + "T" + "C" * 19, cb="CCGT-1", ub="GGGGGGGGGC")   # SNP chr2:151 C>T at offset 30
+    rd(1, 40000, "50M", C[:50], cb="AAAC-1", ub="GGGGGGGGGT")
+    rd(2, 10, "50M", C[:50], cb="AAAC-1", ub="GGGGGGGGTA")
+    R.sort(key=lambda r: (r[0], r[1]))
+    for (tid, pos, qn, flag, mapq, cig, seq, tags) in R:
+        bw.write(tid, pos, qn, flag, mapq, None if cig == "*" else cig, seq, tags)
+    bw.close()
+    bw.write_index()
+    with open(os.path.join(d, "barcodes.tsv"), "w") as fp:
+        fp.write("".join(c + "\n" for c in reversed(cells)))             # unsorted on purpose
+    with open(os.path.join(d, "regions.tsv"), "w") as fp:
+        fp.write("chr1\t1001\t2000\tg1\tplus\n"
+                 "1\t3001\t3100\tg2\n"
+                 "CHR1\t5051\t5100\tg3_nested\n"
+                 "chr1\t5001\t6000\tg4\n"
+                 "chr1\t1001\t2000\tg1_dup\n"
+                 "CHR2\t101\t200\tg5\n"
+                 "2\t30000\t45000\tg6\n"
+                 "chr3\t1\t1000\tg7_nocontig\n"
+                 "chr1\t90000\t99000\tg8_empty\n")
+    with open(os.path.join(d, "snps.tsv"), "w") as fp:
+        fp.write("chrom\tpos\tref\talt\tref_hap\talt_hap\n"
+                 "chr1\t1100\tA\tG\t0\t1\n"
+                 "chr1\t1150\tC\tT\t1\t0\n"
+                 "chr1\t1150\tC\tT\t0\t1\n"
+                 "1\t1200\tn\ta\t0\t1\n"
+                 "chr1\t1210\tA\tA\t0\t1\n"
+                 "chr1\t1220\tAC\tG\t0\t1\n"
+                 "chr1\t1230\tA\tG\t1\t1\n"
+                 "chr1\t5060\tA\tC\t0\t1\n"
+                 "CHR2\t151\tC\tT\t0\t1\n"
+                 "chr2\t40010\tC\tG\t1\t0\n"
+                 "chr1\t95000\tA\tC\t0\t1\n")
+    return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
+
+
+DATASETS = {"c1": ds_c1, "dense": ds_dense, "multibam": ds_multibam, "well": ds_well, "special": ds_special}
+
+# ------------------------------------------------------------------------------- cases
+# kwargs use "$D/" for the dataset directory and "$O" for the output directory.
+def fc(ds, name, **kw):
+    return dict(name=name, dataset=ds, kind="basefc", kwargs=kw)
+
+
+def baf(ds, name, **kw):
+    return dict(name=name, dataset=ds, kind="baf", kwargs=kw)
+
+
+def _10x(ds, bam="possorted.bam"):
+    return dict(sam_fn="$D/" + bam, barcode_fn="$D/barcodes.tsv", region_fn="$D/regions.tsv", out_dir="$O")
+
+
+def _baf10x(ds, bam="possorted.bam", snp="snps.tsv"):
+    d = _10x(ds, bam)
+    d["phased_snp_fn"] = "$D/" + snp
+    return d
+
+
+CASES = [
+    fc("c1", "c1_basefc_default", ncores=2, **_10x("c1")),
+    fc("c1", "c1_basefc_noumi", umi_tag="None", **_10x("c1")),
+    baf("c1", "c1_baf_allreg", output_all_reg=True, ncores=2, **_baf10x("c1")),
+    baf("c1", "c1_baf_default_vcf", **_baf10x("c1", snp="snps.vcf")),
+    baf("c1", "c1_baf_noumi", umi_tag="None", output_all_reg=True, **_baf10x("c1")),
+    fc("dense", "dense_basefc_default", **_10x("dense")),
+    fc("dense", "dense_basefc_inc05", min_include=0.5, **_10x("dense")),
+    fc("dense", "dense_basefc_inc30", min_include=30, **_10x("dense")),
+    fc("dense", "dense_basefc_inc0", min_include=0, **_10x("dense")),
+    fc("dense", "dense_basefc_sparse_rows", output_all_reg=False, min_mapq=30, min_len=80, **_10x("dense")),
+    dict(name="dense_basefc_cli_flags", dataset="dense", kind="basefc",
+         argv=["-s", "$D/possorted.bam", "-b", "$D/barcodes.tsv", "-R", "$D/regions.tsv", "-O", "$O",
+               "--exclFLAG", "1024", "--inclFLAG", "16", "--minMAPQ", "2", "--minINCLUDE", "45", "-p", "2"]),
+    baf("dense", "dense_baf_default", **_baf10x("dense")),
+    baf("dense", "dense_baf_allreg_dup", output_all_reg=True, no_dup_hap=False, **_baf10x("dense")),
+    baf("dense", "dense_baf_filters", min_count=11, min_maf=0.1, output_all_reg=True, **_baf10x("dense")),
+    baf("dense", "dense_baf_flags", excl_flag=1024, incl_flag=16, min_mapq=0, min_len=50, **_baf10x("dense")),
+    fc("multibam", "multibam_basefc", sam_fn="$D/possorted_0.bam,$D/possorted_1.bam",
+       barcode_fn="$D/barcodes.tsv", region_fn="$D/regions.tsv", out_dir="$O"),
+    baf("multibam", "multibam_baf", sam_fn="$D/possorted_1.bam,$D/possorted_0.bam",
+        barcode_fn="$D/barcodes.tsv", region_fn="$D/regions.tsv", phased_snp_fn="$D/snps.tsv",
+        out_dir="$O", output_all_reg=True),
+    fc("well", "well_basefc", sam_fn=None, sam_list_fn="$L", barcode_fn=None, sample_id_fn="$D/sample_ids.txt",
+       region_fn="$D/regions.tsv", out_dir="$O", cell_tag="None", umi_tag="None"),
+    fc("well", "well_basefc_orphan", sam_fn=None, sam_list_fn="$L", barcode_fn=None, sample_id_fn="$D/sample_ids.txt",
+       region_fn="$D/regions.tsv", out_dir="$O", cell_tag="None", umi_tag="None", no_orphan=False, min_include=0.5),
+    baf("well", "well_baf", sam_fn=None, sam_list_fn="$L", barcode_fn=None, sample_id_fn="$D/sample_ids.txt",
+        region_fn="$D/regions.tsv", phased_snp_fn="$D/snps.tsv", out_dir="$O", cell_tag="None", umi_tag="None",
+        output_all_reg=True),
+    fc("special", "special_basefc", **_10x("special")),
+    fc("special", "special_basefc_inc0", min_include=0, **_10x("special")),
+    baf("special", "special_baf", output_all_reg=True, **_baf10x("special")),
+    baf("special", "special_baf_dup_sparse", no_dup_hap=False, **_baf10x("special")),
+    baf("special", "special_baf_minlen0", output_all_reg=True, min_len=0, min_mapq=0, **_baf10x("special")),
+]
+
+
+def subst(v, ddir, odir, listfile):
+    if isinstance(v, str):
+        return v.replace("$D/", ddir + "/").replace("$O", odir).replace("$L", listfile or "")
+    return v
+
+
+def main():
+    only = set(sys.argv[1:])
+    os.makedirs(GOLD, exist_ok=True)
+    dsdir = os.path.join(GOLD, "datasets")
+    meta = {}
+    for name, fn in DATASETS.items():
+        d = os.path.join(dsdir, name)
+        if os.path.isdir(d):
+            shutil.rmtree(d)
+        info = fn(d)
+        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv"}
+        keep_only(d, keep)
+        info["md5"] = {f: md5(os.path.join(d, f)) for f in sorted(os.listdir(d))}
+        meta[name] = info
+        with open(os.path.join(d, "dataset.json"), "w") as fp:
+            json.dump(info, fp, indent=1, sort_keys=True)
+    cdir = os.path.join(GOLD, "cases")
+    if os.path.isdir(cdir) and not only:
+        shutil.rmtree(cdir)
+    for case in CASES:
+        if only and case["name"] not in only:
+            continue
+        ddir = os.path.join(dsdir, case["dataset"])
+        with tempfile.TemporaryDirectory() as tmp:
+            odir = os.path.join(tmp, "out")
+            listfile = os.path.join(tmp, "bam_list.txt")
+            with open(listfile, "w") as fp:
+                fp.write("".join(os.path.join(ddir, b) + "\n" for b in meta[case["dataset"]]["bams"]))
+            job = dict(kind=case["kind"])
+            if "argv" in case:
+                job["argv"] = [subst(a, ddir, odir, listfile) for a in case["argv"]]
+            else:
+                job["kwargs"] = {k: subst(v, ddir, odir, listfile) for k, v in case["kwargs"].items()}
+            jf = os.path.join(tmp, "job.json")
+            with open(jf, "w") as fp:
+                json.dump(job, fp)
+            r = subprocess.run([PY39, RUNNER, jf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr[-3000:])
+                raise SystemExit("reference failed on case %s" % case["name"])
+            out = os.path.join(cdir, case["name"])
+            if os.path.isdir(out):
+                shutil.rmtree(out)
+            os.makedirs(os.path.join(out, "expected"))
+            for f in sorted(os.listdir(odir)):
+                shutil.copy(os.path.join(odir, f), os.path.join(out, "expected", f))
+            rec = dict(case)
+            rec["expected_md5"] = {f: md5(os.path.join(out, "expected", f)) for f in sorted(os.listdir(odir))}
+            rec["reference"] = "hxj5/xcltk v0.5.2 via oracle/refgen/run_reference.py (pysam/anndata stand-ins)"
+            with open(os.path.join(out, "case.json"), "w") as fp:
+                json.dump(rec, fp, indent=1, sort_keys=True)
+            nnz = {f: open(os.path.join(odir, f)).read().split("\n")[2] for f in os.listdir(odir) if f.endswith(".mtx")}
+            print("%-28s %s" % (case["name"], nnz))
+
+
+if __name__ == "__main__":
+    main()

@@ -49,3 +49,95 @@ def assert_coo_equal(got, exp, names):
         assert len(g[0]) == len(e[0]), "%s: nnz %d != %d" % (k, len(g[0]), len(e[0]))
         for j, what in enumerate(("row", "col", "val")):
             assert np.array_equal(g[j], e[j]), "%s.%s differs" % (k, what)
+
+
+# ----------------------------------------------------------------------------- golden cases
+import json
+
+
+def list_cases():
+    cdir = os.path.join(GOLDEN, "cases")
+    return sorted(os.listdir(cdir)) if os.path.isdir(cdir) else []
+
+
+def load_case(name, tmpdir):
+    """-> (case dict with substituted paths, dataset dir, out dir, expected dir)"""
+    cdir = os.path.join(GOLDEN, "cases", name)
+    with open(os.path.join(cdir, "case.json")) as fp:
+        case = json.load(fp)
+    ddir = os.path.join(GOLDEN, "datasets", case["dataset"])
+    with open(os.path.join(ddir, "dataset.json")) as fp:
+        ds = json.load(fp)
+    odir = os.path.join(str(tmpdir), "out_" + name)
+    listfile = os.path.join(str(tmpdir), "bam_list_%s.txt" % name)
+    with open(listfile, "w") as fp:
+        fp.write("".join(os.path.join(ddir, b) + "\n" for b in ds["bams"]))
+
+    def sub(v):
+        if isinstance(v, str):
+            return v.replace("$D/", ddir + "/").replace("$O", odir).replace("$L", listfile)
+        return v
+    if "argv" in case:
+        case["argv"] = [sub(a) for a in case["argv"]]
+    else:
+        case["kwargs"] = {k: sub(v) for k, v in case["kwargs"].items()}
+    return case, ddir, odir, os.path.join(cdir, "expected")
+
+
+def oracle_params(case):
+    """Translate a case (wrapper kwargs or basefc argv) into oracle.run_files() arguments,
+    applying the defaults of the reference wrappers (rdr/fc/main.py:142-182, baf/fc/main.py:32-77)."""
+    mode = capi.XCK_MODE_BASEFC if case["kind"] == "basefc" else capi.XCK_MODE_BAF
+    if "argv" in case:
+        a = case["argv"]
+        kw = {}
+        names = {"-s": "sam_fn", "-b": "barcode_fn", "-R": "region_fn", "-O": "out_dir",
+                 "--exclFLAG": "excl_flag", "--inclFLAG": "incl_flag", "--minMAPQ": "min_mapq",
+                 "--minINCLUDE": "min_include", "-p": "ncores", "--minLEN": "min_len"}
+        i = 0
+        while i < len(a):
+            k = names[a[i]]
+            v = a[i + 1]
+            if k in ("excl_flag", "incl_flag", "ncores", "min_len"):
+                v = int(v)
+            elif k == "min_mapq":
+                v = float(v)
+            elif k == "min_include":
+                v = float(v) if "." in v else int(v)
+            kw[k] = v
+            i += 2
+        explicit_excl = kw.get("excl_flag")
+    else:
+        kw = dict(case["kwargs"])
+        # fc_wrapper never forwards a non-None excl_flag (reference quirk); afc_wrapper does
+        explicit_excl = kw.get("excl_flag") if mode == capi.XCK_MODE_BAF else None
+    if kw.get("sam_fn"):
+        bams = kw["sam_fn"].split(",")
+    else:
+        with open(kw["sam_list_fn"]) as fp:
+            bams = [x.rstrip() for x in fp]
+    sample_ids = None
+    if not kw.get("barcode_fn"):
+        with open(kw["sample_id_fn"]) as fp:
+            sample_ids = [x.strip() for x in fp]
+    p = dict(mode=mode, bam_fns=bams, region_fn=kw["region_fn"], barcode_fn=kw.get("barcode_fn"),
+             sample_ids=sample_ids, snp_fn=kw.get("phased_snp_fn"), cell_tag=kw.get("cell_tag", "CB"),
+             umi_tag=kw.get("umi_tag", "UB"), excl_flag=explicit_excl,
+             output_all_reg=kw.get("output_all_reg", mode == capi.XCK_MODE_BASEFC),
+             min_mapq=kw.get("min_mapq", 20), min_len=kw.get("min_len", 30), incl_flag=kw.get("incl_flag", 0),
+             no_orphan=kw.get("no_orphan", True))
+    if mode == capi.XCK_MODE_BASEFC:
+        p["min_include"] = kw.get("min_include", 0.9)
+    else:
+        p.update(min_count=kw.get("min_count", 1), min_maf=kw.get("min_maf", 0), no_dup_hap=kw.get("no_dup_hap", True))
+    return p
+
+
+def assert_dirs_equal(got_dir, exp_dir):
+    exp = sorted(os.listdir(exp_dir))
+    got = sorted(f for f in os.listdir(got_dir) if not f.startswith("."))
+    assert got == exp, (got, exp)
+    for f in exp:
+        a = open(os.path.join(got_dir, f), "rb").read()
+        b = open(os.path.join(exp_dir, f), "rb").read()
+        assert a == b, "%s differs from the reference output" % f

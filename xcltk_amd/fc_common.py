@@ -1,0 +1,267 @@
+"""fc_common.py - host logic shared by `basefc` and the BAF feature counting front-ends.
+
+The reference duplicates this logic in xcltk/rdr/fc/main.py:305-431 and
+xcltk/baf/fc/main.py:298-499 (prepare_config) and in the two utils.py (loaders, merge_mtx).
+Here it lives once; behaviour (defaults, error messages, file formats, return codes) follows
+those lines.  The compute itself is delegated to the HIP engine (engine.Engine).
+"""
+
+import os
+import sys
+import time
+from logging import error, info
+from logging import warning as warn
+
+import numpy as np
+
+from .capi import XCK_MODE_BAF, XCK_MODE_BASEFC
+from .engine import Engine
+from .utils.grange import format_chrom
+from .utils.zfile import zopen
+
+EXCL_FLAG_UMI = 772       # reference DefaultConfig, rdr/fc/config.py:108-109
+EXCL_FLAG_XUMI = 1796
+
+
+# ----------------------------------------------------------------------------- input resolution
+def resolve_inputs(conf):
+    """BAM list, barcodes / sample ids, tags, default exclude flag.  Returns 0 or -1 and
+    logs the reference's messages (rdr/fc/main.py:323-373,401-429)."""
+    if conf.sam_fn:
+        if conf.sam_list_fn:
+            error("should not specify 'sam_fn' and 'sam_list_fn' together.")
+            return -1
+        conf.sam_fn_list = conf.sam_fn.split(",")
+    else:
+        if not conf.sam_list_fn:
+            error("one of 'sam_fn' and 'sam_list_fn' should be specified.")
+            return -1
+        with open(conf.sam_list_fn, "r") as fp:
+            conf.sam_fn_list = [x.rstrip() for x in fp.readlines()]
+    for fn in conf.sam_fn_list:
+        if not os.path.isfile(fn):
+            error("sam file '%s' does not exist." % fn)
+            return -1
+
+    if conf.barcode_fn:
+        conf.sample_ids = None
+        if conf.sample_id_str or conf.sample_id_fn:
+            error("should not specify barcodes and sample IDs together.")
+            return -1
+        if not os.path.isfile(conf.barcode_fn):
+            error("barcode file '%s' does not exist." % conf.barcode_fn)
+            return -1
+        with zopen(conf.barcode_fn, "rt") as fp:
+            conf.barcodes = sorted(x.strip() for x in fp)       # column j = j-th SORTED barcode
+        if len(set(conf.barcodes)) != len(conf.barcodes):
+            error("duplicate barcodes!")
+            return -1
+    else:
+        conf.barcodes = None
+        if conf.sample_id_str and conf.sample_id_fn:
+            error("should not specify 'sample_id_str' and 'sample_fn' together.")
+            return -1
+        if conf.sample_id_str:
+            conf.sample_ids = conf.sample_id_str.split(",")
+        elif conf.sample_id_fn:
+            with zopen(conf.sample_id_fn, "rt") as fp:
+                conf.sample_ids = [x.strip() for x in fp]
+        else:
+            warn("use default sample IDs ...")
+            conf.sample_ids = ["Sample%d" % i for i in range(len(conf.sam_fn_list))]
+        if len(conf.sample_ids) != len(conf.sam_fn_list):
+            error("numbers of sam files and sample IDs are different.")
+            return -1
+    conf.samples = conf.barcodes if conf.barcodes else conf.sample_ids
+    return 0
+
+
+def resolve_tags(conf):
+    """'None' strings, barcode/tag consistency, UMI 'Auto', default exclude flag."""
+    if conf.cell_tag and conf.cell_tag.upper() == "NONE":
+        conf.cell_tag = None
+    if (not conf.cell_tag) ^ (not conf.barcodes):
+        error("should not specify cell_tag or barcodes alone.")
+        return -1
+    if conf.umi_tag:
+        up = conf.umi_tag.upper()
+        if up == "AUTO":
+            conf.umi_tag = None if conf.barcodes is None else conf.defaults.UMI_TAG_BC
+        elif up == "NONE":
+            conf.umi_tag = None
+    if conf.excl_flag < 0:
+        conf.excl_flag = EXCL_FLAG_UMI if conf.use_umi() else EXCL_FLAG_XUMI
+    for tag, what in ((conf.cell_tag, "cell"), (conf.umi_tag, "UMI")):
+        if tag and len(tag) != 2:
+            error("%s tag '%s' is not a 2-character BAM tag." % (what, tag))
+            return -1
+    return 0
+
+
+def load_region_from_txt(fn, sep="\t", verbose=False):
+    """Header-free TSV: chrom, start, end (1-based inclusive), name -> list of
+    (chrom_stripped, start, end_incl, name) in file order, or None (rdr/fc/utils.py:10-45)."""
+    func = "load_region_from_txt"
+    out = []
+    if verbose:
+        sys.stderr.write("[I::%s] start to load regions from file '%s' ...\n" % (func, fn))
+    with zopen(fn, "rt") as fp:
+        for nl, line in enumerate(fp, 1):
+            parts = line.rstrip().split(sep)
+            if len(parts) < 4:
+                if verbose:
+                    sys.stderr.write("[E::%s] too few columns of line %d.\n" % (func, nl))
+                return None
+            out.append((format_chrom(parts[0]), int(parts[1]), int(parts[2]), parts[3]))
+    return out
+
+
+def _snp_from_fields(chrom, pos, ref, alt, a1, a2):
+    ref, alt = ref.upper(), alt.upper()
+    if len(ref) != 1 or ref not in "ACGTN":
+        return "invalid REF base"
+    if len(alt) != 1 or alt not in "ACGTN":
+        return "invalid ALT base"
+    if not ((a1 == "0" and a2 == "1") or (a1 == "1" and a2 == "0")):
+        return "invalid GT"
+    return (format_chrom(chrom), int(pos), ref, alt, int(a1), int(a2))
+
+
+def load_snp_from_tsv(fn, verbose=False):
+    """TSV with header: chrom pos ref alt ref_hap alt_hap (baf/fc/utils.py:51-110)."""
+    func = "load_snp_from_tsv"
+    snps = []
+    if verbose:
+        sys.stderr.write("[I::%s] start to load SNPs from tsv '%s' ...\n" % (func, fn))
+    with zopen(fn, "rt") as fp:
+        for nl, line in enumerate(fp, 1):
+            if nl == 1:
+                continue
+            parts = line.rstrip().split("\t")
+            if len(parts) < 6:
+                if verbose:
+                    sys.stderr.write("[W::%s] too few columns of line %d.\n" % (func, nl))
+                continue
+            s = _snp_from_fields(parts[0], parts[1], parts[2], parts[3], parts[4], parts[5])
+            if isinstance(s, str):
+                if verbose:
+                    sys.stderr.write("[W::%s] %s of line %d.\n" % (func, s, nl))
+                continue
+            snps.append(s)
+    return snps
+
+
+def load_snp_from_vcf(fn, verbose=False):
+    """Phased VCF, first sample column; GT must be 0|1, 1|0, 0/1 or 1/0 (baf/fc/utils.py:114-193)."""
+    func = "load_snp_from_vcf"
+    snps = []
+    if verbose:
+        sys.stderr.write("[I::%s] start to load SNPs from vcf '%s' ...\n" % (func, fn))
+    with zopen(fn, "rt") as fp:
+        for nl, line in enumerate(fp, 1):
+            if line[0] in ("#", "\n"):
+                continue
+            parts = line.rstrip().split("\t")
+            if len(parts) < 10:
+                if verbose:
+                    sys.stderr.write("[W::%s] too few columns of line %d.\n" % (func, nl))
+                continue
+            msg = None
+            fields = parts[8].split(":")
+            values = parts[9].split(":")
+            ref, alt = parts[3].upper(), parts[4].upper()
+            if len(ref) != 1 or ref not in "ACGTN":
+                msg = "invalid REF base"
+            elif len(alt) != 1 or alt not in "ACGTN":
+                msg = "invalid ALT base"
+            elif "GT" not in fields:
+                msg = "GT not in"
+            elif len(values) != len(fields):
+                msg = "len(fields) != len(values) in"
+            else:
+                gt = values[fields.index("GT")]
+                sepc = "|" if "|" in gt else ("/" if "/" in gt else None)
+                if sepc is None:
+                    msg = "invalid delimiter of"
+                else:
+                    a1, a2 = gt.split(sepc)[:2]
+                    s = _snp_from_fields(parts[0], parts[1], ref, alt, a1, a2)
+                    if isinstance(s, str):
+                        msg = s + " of"
+                    else:
+                        snps.append(s)
+            if msg and verbose:
+                sys.stderr.write("[W::%s] %s line %d.\n" % (func, msg, nl))
+    return snps
+
+
+def is_vcf_name(fn):
+    return fn.endswith(".vcf") or fn.endswith(".vcf.gz") or fn.endswith(".vcf.bgz")
+
+
+# ----------------------------------------------------------------------------- outputs
+def contig_table(regions, snps=()):
+    names, seen = [], set()
+    for ch in [r[0] for r in regions] + [s[0] for s in snps]:
+        if ch not in seen:
+            seen.add(ch)
+            names.append(ch)
+    return names
+
+
+def row_map_all(n):
+    return np.arange(1, n + 1, dtype=np.int32)
+
+
+def row_map_from_rows(n, *row_arrays):
+    """Rows are numbered over the regions that produced at least one output line
+    (k_reg bookkeeping, rdr/fc/core.py:118-124 and baf/fc/core.py:101-113)."""
+    keep = np.zeros(n, dtype=bool)
+    for r in row_arrays:
+        keep[r] = True
+    rm = np.zeros(n, dtype=np.int32)
+    rm[keep] = np.arange(1, int(keep.sum()) + 1, dtype=np.int32)
+    return rm
+
+
+def write_region_tsv(path, regions, rm):
+    with open(path, "w") as fp:
+        fp.write("".join("%s\t%d\t%d\t%s\n" % (ch, s, e, name)
+                         for (ch, s, e, name), r in zip(regions, rm) if r > 0))
+
+
+def write_samples(path, samples):
+    with open(path, "w") as fp:
+        fp.write("".join(smp + "\n" for smp in samples))
+
+
+# ----------------------------------------------------------------------------- engine driver
+def make_engine(conf, mode, regions, snps=(), device=None, **extra):
+    """Build the per-GPU engine from a resolved Config."""
+    names = contig_table(regions, snps)
+    if device is None:
+        device = int(os.environ.get("XCK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    kw = dict(min_mapq=conf.min_mapq, min_len=conf.min_len, incl_flag=conf.incl_flag,
+              excl_flag=conf.excl_flag, no_orphan=conf.no_orphan, n_threads=max(0, int(conf.nproc)))
+    if mode == XCK_MODE_BASEFC:
+        kw["min_include"] = conf.min_include
+    else:
+        kw.update(min_count=conf.min_count, min_maf=conf.min_maf, no_dup_hap=conf.no_dup_hap)
+    kw.update(extra)
+    return Engine(mode, names, regions, len(conf.samples), snps=snps,
+                  barcodes=conf.barcodes if conf.use_barcodes() else None,
+                  cell_tag=conf.cell_tag, umi_tag=conf.umi_tag, device=device, **kw)
+
+
+def stream_bams(eng, conf, log_prefix="[engine]"):
+    """One streaming pass over every BAM, in list order (= the reference's fetch order)."""
+    t0 = time.time()
+    n_tot = 0
+    for i, fn in enumerate(conf.sam_fn_list):
+        n = eng.ingest_bam(fn, sample=i)
+        n_tot += n
+        if conf.debug > 0:
+            info("%s %s: %d records" % (log_prefix, fn, n))
+    dt = max(time.time() - t0, 1e-9)
+    info("%s %d BAM record(s) decoded and joined in %.2fs (%.0f reads/s)" % (log_prefix, n_tot, dt, n_tot / dt))
+    return n_tot
