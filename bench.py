@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py - reads/sec into the basefc count matrix AND the AD/DP/OTH matrices (BASELINE.json).
+
+One "step" = one full pass of the hot path over one synthetic coordinate-sorted record set
+that is already resident in HBM: read x region join + UMI de-duplication -> count matrix, and
+read x SNP pileup + first-read-per-UMI + haplotype algebra -> AD/DP/OTH matrices, through the
+C-ABI (xck_push_batch_device / xck_finish).  Workload at N=1: BASELINE.json configs[1]
+(50 M reads, 5 k barcodes, 100 k het SNPs, 33,472 genes on the 24 hg38 contigs).
+
+Multi-GPU (N>1, one rank per GPU, launched by torch.distributed.run): contigs are assigned to
+ranks by longest-processing-time; every rank processes --reads reads of ITS contigs (weak
+scaling) with no data-path collective; the per-rank sparse blocks are concatenated on rank 0
+with one RCCL all-gather of sizes plus one padded all-gather of triplets per matrix.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from xcltk_amd import capi
+from xcltk_amd.engine import Engine
+from xcltk_amd.synth import soa, soa_torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def lpt_assign(weights, n_bins):
+    bins = [[] for _ in range(n_bins)]
+    load = [0.0] * n_bins
+    for i in sorted(range(len(weights)), key=lambda i: -weights[i]):
+        b = load.index(min(load))
+        bins[b].append(i)
+        load[b] += weights[i]
+    return bins
+
+
+def gather_coo(coo, world, device):
+    """all-gatherv of (row, col, val) triplets: sizes first, then padded blocks (RCCL)."""
+    import torch.distributed as dist
+    n = torch.tensor([len(coo[0])], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros((3, mx), dtype=torch.int32, device=device)
+    if len(coo[0]):
+        buf[:, :len(coo[0])] = torch.from_numpy(np.stack(coo)).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    parts = [o[:, :s] for o, s in zip(out, sizes)]
+    cat = torch.cat(parts, dim=1)
+    # ranks own disjoint rows: order the concatenation by (row, col) like a single run
+    key = cat[0].to(torch.int64) * (1 << 31) + cat[1].to(torch.int64)
+    return cat[:, torch.argsort(key)].cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
+    ap.add_argument("--cells", type=int, default=5000)
+    ap.add_argument("--snps", type=int, default=100_000)
+    ap.add_argument("--genes", type=int, default=33472)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback of the hot path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- tables (identical on every rank) and this rank's shard of contigs --------------------
+    regions, snps, names = soa.make_tables(args.genes, args.snps, soa.HG38_LENGTHS, seed=2)
+    shard = lpt_assign(soa.HG38_LENGTHS, world)[rank]
+    arrays, batches = soa_torch.gen_reads_device(regions, names, args.reads, args.cells, seed=100 + rank,
+                                                device=device, contig_subset=shard if world > 1 else None)
+    torch.cuda.synchronize()
+    n_reads = arrays["n_reads"]
+    filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
+    eng_fc = Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=local, min_include=0.9, **filt)
+    eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=local,
+                     min_count=1, min_maf=0, no_dup_hap=True, **filt)
+    b_fc = [soa_torch.device_batch(capi, arrays, c, s, e, False) for c, s, e in batches]
+    b_baf = [soa_torch.device_batch(capi, arrays, c, s, e, True) for c, s, e in batches]
+
+    def step():
+        out = {}
+        for eng, bs in ((eng_fc, b_fc), (eng_baf, b_baf)):
+            eng.reset()
+            for b in bs:
+                eng.push(b, device_resident=True)
+            out.update(eng.finish())
+        if world > 1:
+            out = {k: gather_coo(v, world, device) for k, v in out.items()}
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    sync()
+    acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        sfc, sbaf = eng_fc.stats(), eng_baf.stats()     # HIP-event times of this step (reset() clears them)
+        acc["ms_join_fc"] += sfc["ms_join"]; acc["ms_fin_fc"] += sfc["ms_sort"]
+        acc["ms_join_baf"] += sbaf["ms_join"]; acc["ms_fin_baf"] += sbaf["ms_sort"]
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    ms_step = dt / args.steps * 1e3
+    value = n_reads * world / (dt / args.steps)
+
+    # ---- roofline of the dominant hand-written kernel: k_join (one launch per contig batch) ----
+    n_launch = len(batches)
+    L = arrays["read_len"]
+    hits_fc, hits_baf = sfc["n_hits"], sbaf["n_hits"]
+    # SURVEY 8d per-unit figures: 20 B/read + 4 B/CIGAR op (+ ceil(L/4) B bases for pileup);
+    # 16 B per basefc hit written, 24 B per pileup hit written.
+    A_fc = n_reads * 20 + arrays["n_cig"] * 4 + hits_fc * 16
+    A_baf = n_reads * (20 + (L + 3) // 4) + arrays["n_cig"] * 4 + hits_baf * 24
+    k = {name: acc[name] / args.steps for name in acc}
+    dom = max(("k_join<basefc>", k["ms_join_fc"], A_fc), ("k_join<pileup>", k["ms_join_baf"], A_baf), key=lambda x: x[1])
+    avg_ms = dom[1] / n_launch
+    achieved = (dom[2] / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    if os.path.isfile(args.pmc_json):
+        try:
+            traffic = json.load(open(args.pmc_json)).get(dom[0])
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=dom[0], achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    launches_per_step=n_launch, avg_launch_ms=round(avg_ms, 4),
+                    algorithmic_bytes_per_launch=int(dom[2] / n_launch),
+                    stage_ms_per_step={a: round(b, 3) for a, b in k.items()})
+
+    # ---- CPU baseline: the oracle (C restatement of the reference's per-region loops), 1 core ----
+    cpu = None
+    if args.cpu_sample > 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle as O
+        import util
+        take, tot = [], 0
+        for c, s, e in batches:
+            if tot >= args.cpu_sample:
+                break
+            e2 = min(e, s + args.cpu_sample - tot)
+            take.append((c, s, e2)); tot += e2 - s
+        hb = [util.batch_from_dict(soa_torch.host_batch_dict(arrays, c, s, e, True)) for c, s, e in take]
+        tc = 0.0
+        for mode, sn in ((capi.XCK_MODE_BASEFC, []), (capi.XCK_MODE_BAF, snps)):
+            cfg, keep = O.make_config(mode, names, regions, sn, args.cells)
+            t1 = time.perf_counter()
+            O.run_oracle(cfg, [b for b, _ in hb])
+            tc += time.perf_counter() - t1
+        cpu = dict(value=round(tot / tc, 1), unit="reads/s", cores=1, kind="port",
+                   sample="first %d reads (contig-ordered prefix) of the same workload, basefc + pileup, oracle/xck_oracle.c" % tot,
+                   seconds=round(tc, 2))
+
+    line = dict(metric="reads/sec into AD/DP+basefc matrices", value=round(value, 1), unit="reads/s",
+                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3),
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64", data="synthetic",
+                config=dict(workload="BASELINE.json configs[1]: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
+                                     "basefc + pileup per step, SoA resident in HBM" % (n_reads, args.cells, len(snps), len(regions)),
+                            reads_per_gpu=n_reads, parallelism="contig-shard x%d" % world,
+                            nnz={kk: int(len(v[0])) for kk, v in res.items()},
+                            hits=dict(basefc=int(hits_fc), pileup=int(hits_baf))),
+                roofline=roofline, cpu_baseline=cpu)
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
