@@ -27,39 +27,10 @@ import torch
 
 from xcltk_amd import capi
 from xcltk_amd.engine import Engine
+from xcltk_amd.shard import gather_coo, lpt_assign
 from xcltk_amd.synth import soa, soa_torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-
-
-def lpt_assign(weights, n_bins):
-    bins = [[] for _ in range(n_bins)]
-    load = [0.0] * n_bins
-    for i in sorted(range(len(weights)), key=lambda i: -weights[i]):
-        b = load.index(min(load))
-        bins[b].append(i)
-        load[b] += weights[i]
-    return bins
-
-
-def gather_coo(coo, world, device):
-    """all-gatherv of (row, col, val) triplets: sizes first, then padded blocks (RCCL)."""
-    import torch.distributed as dist
-    n = torch.tensor([len(coo[0])], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    buf = torch.zeros((3, mx), dtype=torch.int32, device=device)
-    if len(coo[0]):
-        buf[:, :len(coo[0])] = torch.from_numpy(np.stack(coo)).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    parts = [o[:, :s] for o, s in zip(out, sizes)]
-    cat = torch.cat(parts, dim=1)
-    # ranks own disjoint rows: order the concatenation by (row, col) like a single run
-    key = cat[0].to(torch.int64) * (1 << 31) + cat[1].to(torch.int64)
-    return cat[:, torch.argsort(key)].cpu().numpy()
 
 
 def main():
@@ -112,7 +83,7 @@ def main():
                 eng.push(b, device_resident=True)
             out.update(eng.finish())
         if world > 1:
-            out = {k: gather_coo(v, world, device) for k, v in out.items()}
+            out = {k: gather_coo(v, world, device) for k, v in out.items()}   # RCCL all-gatherv
         return out
 
     def sync():

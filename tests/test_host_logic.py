@@ -1,0 +1,256 @@
+"""CPU-side tests (no GPU): C-ABI surface, BAM decoder vs the oracle's independent reader,
+writers, front-end configuration logic, multi-rank gather (gloo, world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pybam
+import util
+from xcltk_amd import capi
+from xcltk_amd.engine import Engine, XckError, resolve_contigs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "xck.h")).read()
+    declared = set(re.findall(r"\b(xck_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert {n for n, _, _ in capi.SYMBOLS} == declared
+    assert lib.xck_abi_version() == 1 and b"gfx950" in lib.xck_version()
+
+
+def test_struct_layouts_match_header_sizes(lib):
+    # a wrong layout would be rejected by xck_create's struct_size check
+    cfg = capi.Config()
+    cfg.struct_size = C.sizeof(capi.Config) - 4
+    cfg.mode = 1; cfg.n_cells = 1
+    h = C.c_void_p()
+    assert lib.xck_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"struct_size" in lib.xck_last_error(None)
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device the engine must refuse to exist (no silent CPU path)."""
+    if lib.xck_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(XckError) as ei:
+        Engine(capi.XCK_MODE_BASEFC, ["1"], [("1", 1, 100, "g")], 1)
+    assert "no HIP device" in str(ei.value) or "fallback" in str(ei.value)
+    with pytest.raises(capi.XckLibraryError):
+        capi.load("/nonexistent/libxck.so")
+
+
+def test_decode_only_handle_refuses_compute(lib):
+    eng = Engine(capi.XCK_MODE_BASEFC, ["1"], [("1", 1, 100, "g")], 1, decode_only=True)
+    b, keep = capi.make_batch(0, 0, [5], [0], [60], [0], [7], [0, 1], [16])
+    with pytest.raises(XckError):
+        eng.push(b)
+    with pytest.raises(XckError):
+        eng.finish()
+    eng.close()
+
+
+def _decode_compare(ds, mode, n_threads, env_chunk=None, cell_tag="CB", umi_tag="UB", force128=False):
+    ddir = os.path.join(util.GOLDEN, "datasets", ds)
+    regions, snps = util.load_tables(ddir)
+    names = O.contig_table(regions, snps)
+    import json
+    info = json.load(open(os.path.join(ddir, "dataset.json")))
+    if "barcodes" in info:
+        samples = sorted(x.strip() for x in open(os.path.join(ddir, "barcodes.tsv")))
+    else:
+        samples = info["sample_ids"]; cell_tag = None; umi_tag = None
+    if env_chunk:
+        os.environ["XCK_CHUNK_BYTES"] = str(env_chunk)
+    try:
+        eng = Engine(mode, names, regions, len(samples), snps=snps if mode == 2 else (),
+                     barcodes=samples if cell_tag else None, cell_tag=cell_tag, umi_tag=umi_tag,
+                     decode_only=True, n_threads=n_threads, flags=capi.XCK_F_FORCE_KEY128 if force128 else 0)
+        intern = {}
+        cell_index = {s: i for i, s in enumerate(samples)}
+        tot = 0
+        for bi, bam in enumerate(info["bams"]):
+            fn = os.path.join(ddir, bam)
+            got = list(eng.decode_bam(fn, sample=bi))
+            refs, recs = pybam.read_bam(fn)
+            t2c = O.resolve_contigs([n for n, _ in refs], names)
+            exp = O.encode_bam(recs, t2c, bi, cell_index, cell_tag, umi_tag, eng.umi_bits, intern, with_seq=(mode == 2))
+            # the decoder may cut a contig run into several batches (chunk boundaries): concatenate both sides
+            def cat(batches, key, is_dict):
+                out = []
+                for b in batches:
+                    d = b if is_dict else None
+                    out.append(d)
+                return out
+            g_pos = np.concatenate([g["pos"] for g in got]) if got else np.zeros(0, np.int32)
+            e_pos = np.concatenate([k[0] for _, k in exp]) if exp else np.zeros(0, np.int32)
+            assert np.array_equal(g_pos, e_pos)
+            for gi, ki in (("flag", 1), ("mapq", 2), ("cell", 3)):
+                assert np.array_equal(np.concatenate([g[gi] for g in got]), np.concatenate([k[ki] for _, k in exp])), gi
+            # ordinals
+            g_ord = np.concatenate([g["ordinal_base"] + np.arange(g["n_reads"], dtype=np.uint64) for g in got])
+            e_ord = np.concatenate([np.uint64(b.ordinal_base) + np.arange(b.n_reads, dtype=np.uint64) for b, _ in exp])
+            assert np.array_equal(g_ord, e_ord)
+            assert [g["contig"] for g in got if g["n_reads"]][0] == exp[0][0].contig
+            # CIGAR words and sequence bytes per read
+            def per_read(off, data):
+                return [bytes(data[off[i]:off[i + 1]].tobytes()) for i in range(len(off) - 1)]
+            g_c = sum((per_read(g["cig_off"], g["cigar"]) for g in got), [])
+            e_c = sum((per_read(k[5], k[6]) for _, k in exp), [])
+            assert g_c == e_c
+            if mode == 2:
+                g_s = sum((per_read(g["seq_off"], g["seq"]) for g in got), [])
+                e_s = sum((per_read(k[7], k[8]) for _, k in exp), [])
+                assert g_s == e_s
+            # key codes: 2-bit coded ones are equal; interned ids equal up to renaming
+            gu = np.concatenate([g["umi"] for g in got]); eu = np.concatenate([k[4] for _, k in exp])
+            hi = np.uint64(1 << (eng.umi_bits - 1))
+            coded = ((eu & hi) == 0) | (eu == np.uint64(capi.XCK_UMI_NONE))
+            assert np.array_equal(gu[coded], eu[coded])
+            fwd, bwd = {}, {}
+            for a, b in zip(gu[~coded].tolist(), eu[~coded].tolist()):
+                assert fwd.setdefault(a, b) == b and bwd.setdefault(b, a) == a
+            tot += len(g_pos)
+        eng.close()
+        return tot
+    finally:
+        os.environ.pop("XCK_CHUNK_BYTES", None)
+
+
+@pytest.mark.parametrize("ds", ["c1", "dense", "multibam", "well", "special"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_decoder_matches_independent_reader(ds, mode):
+    assert _decode_compare(ds, mode, n_threads=3) > 0
+
+
+def test_decoder_many_chunks_and_record_carry_over():
+    # dense / special were written with records straddling BGZF blocks; tiny chunks force the
+    # carry-over path between chunks as well
+    n1 = _decode_compare("dense", 2, n_threads=4, env_chunk=4096)
+    n2 = _decode_compare("special", 2, n_threads=2, env_chunk=1024)
+    n3 = _decode_compare("c1", 1, n_threads=8, env_chunk=70000, force128=True)
+    assert n1 == 6000 and n2 > 30 and n3 == 10000
+
+
+def test_decoder_rejects_garbage(tmp_path, lib):
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(b"this is not a bam file at all, but it is long enough........")
+    b = C.c_void_p(); err = C.create_string_buffer(256)
+    assert lib.xck_bam_open(str(bad).encode(), 1, C.byref(b), err, 256) == -4
+    assert b"BGZF" in err.value or b"BAM" in err.value
+    # truncated real file
+    src = open(os.path.join(util.GOLDEN, "datasets", "c1", "possorted.bam"), "rb").read()
+    tr = tmp_path / "trunc.bam"
+    tr.write_bytes(src[:len(src) // 2])
+    eng = Engine(capi.XCK_MODE_BASEFC, ["1"], [("1", 1, 100, "g")], 1, decode_only=True)
+    with pytest.raises(XckError):
+        list(eng.decode_bam(str(tr)))
+    eng.close()
+
+
+def test_write_mtx_text(tmp_path, lib):
+    row = np.array([0, 0, 2, 5], dtype=np.int32); col = np.array([1, 3, 0, 2], dtype=np.int32); val = np.array([1, 22, 333, 4], dtype=np.int32)
+    coo = capi.Coo(); coo.nnz = 4
+    coo.row = capi.np_ptr(row, C.c_int32); coo.col = capi.np_ptr(col, C.c_int32); coo.val = capi.np_ptr(val, C.c_int32)
+    rm = np.array([1, 0, 2, 0, 0, 3], dtype=np.int32)
+    fn = str(tmp_path / "m.mtx")
+    assert lib.xck_write_mtx(fn.encode(), C.byref(coo), capi.np_ptr(rm, C.c_int32), 3, 4) == 0
+    assert open(fn).read() == O.mtx_text((row, col, val), rm, 3, 4)
+    assert open(fn).read().startswith("%%MatrixMarket matrix coordinate integer general\n%%\n3\t4\t4\n1\t2\t1\n")
+
+
+def test_resolve_contigs_chr_fallback():
+    assert resolve_contigs(["chr1", "chr2", "3"], ["1", "2", "3", "4"]).tolist() == [0, 1, 2]
+    assert resolve_contigs(["1", "chr1"], ["1"]).tolist() == [0, -1]          # exact name wins
+    assert resolve_contigs(["Chr1"], ["1"]).tolist() == [-1]                  # case-sensitive like sam_fetch
+    assert resolve_contigs(["1"], ["chr1"]).tolist() == [0]                   # 'chr' removed on retry
+
+
+def test_frontend_config_errors(tmp_path, caplog):
+    from xcltk_amd.baf.fc.main import afc_wrapper
+    from xcltk_amd.rdr.fc.main import fc_wrapper
+    d = os.path.join(util.GOLDEN, "datasets", "c1")
+    out = str(tmp_path / "o")
+    assert fc_wrapper(d + "/nope.bam", d + "/barcodes.tsv", d + "/regions.tsv", out) == -1
+    assert fc_wrapper(d + "/possorted.bam", d + "/barcodes.tsv", d + "/nope.tsv", out) == -1
+    assert fc_wrapper(d + "/possorted.bam", None, d + "/regions.tsv", out) == -1              # cell tag without barcodes
+    assert fc_wrapper(d + "/possorted.bam", d + "/barcodes.tsv", d + "/regions.tsv", None) == -1
+    assert fc_wrapper(d + "/possorted.bam", d + "/barcodes.tsv", d + "/regions.tsv", out, sample_ids="a") == -1
+    assert afc_wrapper(d + "/possorted.bam", d + "/barcodes.tsv", d + "/regions.tsv", d + "/nope.tsv", out) == -1
+    dup = tmp_path / "dup.tsv"; dup.write_text("AAA-1\nAAA-1\n")
+    assert fc_wrapper(d + "/possorted.bam", str(dup), d + "/regions.tsv", out) == -1
+
+
+def test_cli_usage_and_dispatch(capsys):
+    from xcltk_amd.rdr.fc.main import fc_main
+    from xcltk_amd.xcltk import main
+    with pytest.raises(SystemExit) as e:
+        fc_main(["xcltk", "basefc"])
+    assert e.value.code == 0
+    txt = capsys.readouterr().out
+    assert "Usage:   xcltk basefc <options>" in txt and "--minINCLUDE FLOAT|INT" in txt and "[0.900000]" in txt
+    with pytest.raises(SystemExit) as e:
+        main(["xcltk", "nonsense"])
+    assert e.value.code == 1
+    with pytest.raises(SystemExit) as e:
+        main(["xcltk", "baf"])
+    assert e.value.code == 0 and "--phasedSNP" in capsys.readouterr().out
+
+
+def test_snp_loaders_agree_with_oracle_loaders():
+    from xcltk_amd import fc_common as fcc
+    for ds in ("c1", "special"):
+        d = os.path.join(util.GOLDEN, "datasets", ds)
+        assert fcc.load_snp_from_tsv(d + "/snps.tsv") == O.load_snps(d + "/snps.tsv")
+        assert fcc.load_region_from_txt(d + "/regions.tsv") == O.load_regions(d + "/regions.tsv")
+    d = os.path.join(util.GOLDEN, "datasets", "c1")
+    assert fcc.load_snp_from_vcf(d + "/snps.vcf") == O.load_snps(d + "/snps.vcf") == fcc.load_snp_from_tsv(d + "/snps.tsv")
+
+
+def test_lpt_assign_balances():
+    from xcltk_amd.shard import contig_owner, lpt_assign
+    from xcltk_amd.synth.soa import HG38_LENGTHS
+    bins = lpt_assign(HG38_LENGTHS, 8)
+    assert sorted(sum(bins, [])) == list(range(24))
+    loads = [sum(HG38_LENGTHS[i] for i in b) for b in bins]
+    assert max(loads) / (sum(loads) / 8) < 1.08
+    assert set(contig_owner(["a"] * 24, HG38_LENGTHS, 8).tolist()) == set(range(8))
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from xcltk_amd.shard import gather_coo
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(5)
+row = np.sort(rng.integers(0, 1000, 500)).astype(np.int32); col = rng.integers(0, 50, 500).astype(np.int32)
+key = np.unique(row.astype(np.int64) * 100 + col); row = (key // 100).astype(np.int32); col = (key % 100).astype(np.int32)
+val = (row * 7 + col + 1).astype(np.int32)
+mine = (row % world) == rank                       # ranks own disjoint rows
+got = gather_coo((row[mine], col[mine], val[mine]), world)
+empty = gather_coo((row[:0], col[:0], val[:0]), world)
+ok = np.array_equal(got[0], row) and np.array_equal(got[1], col) and np.array_equal(got[2], val) and len(empty[0]) == 0
+print("RANK%d %s" % (rank, "OK" if ok else "BAD"))
+dist.destroy_process_group()
+'''
+
+
+def test_gather_coo_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script), ROOT],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout, r.stdout[-2000:]

@@ -287,6 +287,7 @@ int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size
     if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 4; }
     b->n_threads = n_threads;
     b->pool = new Pool(n_threads);
+    if (const char* cb = getenv("XCK_CHUNK_BYTES")) { long long v = atoll(cb); if (v >= 1024) b->chunk_target = (size_t)v; }   // tests: force many chunks
     *out = b;
     return XCK_OK;
 }
