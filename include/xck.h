@@ -142,13 +142,14 @@ typedef struct xck_result {
 typedef struct xck_stats {
     int64_t n_batches;
     int64_t n_reads;            /* records pushed (every decoded BAM record counts)          */
-    int64_t n_hits;             /* (read,region) or (read,SNP) pairs emitted by the join     */
-    int64_t n_hits_unique;      /* after de-duplication                                      */
+    int64_t n_hits;             /* (read,region) or (read,SNP) pairs accepted by the join    */
+    int64_t n_hits_unique;      /* keys that reached HBM after the in-LDS de-duplication     */
     double  ms_h2d;             /* host-measured, cumulative                                 */
     double  ms_device;          /* HIP-event time of all kernels, cumulative                 */
     double  ms_join;            /* HIP-event time of the join/pileup kernels only            */
     double  ms_sort;            /* HIP-event time of sort + reduce kernels                   */
     int64_t algo_bytes_join;    /* algorithmic bytes of the join kernels         */
+    int64_t n_join_launches;    /* fused join kernel launches (device-resident batches are fused) */
     int32_t key_bits;           /* 64 or 128                                                 */
     int32_t umi_bits;
 } xck_stats;

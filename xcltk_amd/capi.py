@@ -68,14 +68,15 @@ class Coo(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("row", C.POINTER(C.c_int32)),
                 ("col", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_int32))]
 
-    def to_numpy(self):
+    def to_numpy(self, copy=True):
+        """(row, col, val) int32 arrays; copy=False returns views of the engine-owned pinned
+        buffers (valid until the next finish / reset / destroy of that engine)."""
         n = int(self.nnz)
         if n == 0:
             z = np.zeros(0, dtype=np.int32)
             return z, z.copy(), z.copy()
-        return (np.ctypeslib.as_array(self.row, shape=(n,)).copy(),
-                np.ctypeslib.as_array(self.col, shape=(n,)).copy(),
-                np.ctypeslib.as_array(self.val, shape=(n,)).copy())
+        out = tuple(np.ctypeslib.as_array(p, shape=(n,)) for p in (self.row, self.col, self.val))
+        return tuple(a.copy() for a in out) if copy else out
 
 
 class Result(C.Structure):
@@ -86,7 +87,7 @@ class Stats(C.Structure):
     _fields_ = [("n_batches", C.c_int64), ("n_reads", C.c_int64), ("n_hits", C.c_int64),
                 ("n_hits_unique", C.c_int64), ("ms_h2d", C.c_double), ("ms_device", C.c_double),
                 ("ms_join", C.c_double), ("ms_sort", C.c_double),
-                ("algo_bytes_join", C.c_int64), ("key_bits", C.c_int32), ("umi_bits", C.c_int32)]
+                ("algo_bytes_join", C.c_int64), ("n_join_launches", C.c_int64), ("key_bits", C.c_int32), ("umi_bits", C.c_int32)]
 
 
 class IngestOpts(C.Structure):

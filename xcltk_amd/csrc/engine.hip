@@ -21,6 +21,7 @@
 #include <cstring>
 #include <limits>
 #include <chrono>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "xck_internal.h"
@@ -65,36 +66,105 @@ struct ReadFilter {                      // check_read(), rdr/fc/core.py:46-62
     int32_t min_inc_len;
 };
 
-template <class K> struct JoinArgs {
-    int32_t n;
+// One queued record batch (device pointers) inside a fused launch.
+struct BatchDesc {
+    int32_t n, tile0;                       // reads, first tile of this batch in the fused grid
     const int32_t* pos; const uint16_t* flag; const uint8_t* mapq; const int32_t* cell;
     const uint64_t* umi; const uint32_t* cig_off; const uint32_t* cigar;
     const uint32_t* seq_off; const uint8_t* seq;
     uint64_t ordinal_base;
-    ReadFilter f;
-    // region tables of this contig
-    const int32_t* reg_s0; const int32_t* reg_e0; const int32_t* reg_row;
-    const int32_t* win_off; const int32_t* win_list; int32_t n_win;
-    // SNP tables of this contig
-    const int32_t* snp_p0; const int32_t* snp_win; int32_t n_swin; int32_t snp_end;
-    KeyLayout<K> kl;
-    K* keys; uint64_t* vals; unsigned long long cap;
-    unsigned long long* ctl;             // [0] cursor, [1] overflow, [2] OR of emitted umi codes
+    const int32_t* win_off; int32_t n_win;                  // region window index of the batch's contig
+    const int32_t* snp_win; int32_t n_swin; int32_t snp_end; // SNP window table of the batch's contig
 };
+constexpr int MAX_FUSE = 64;              // batches per fused launch
+
+template <class K> struct JoinArgs {
+    int32_t n_batches;
+    const BatchDesc* desc;                // [n_batches] in device memory
+    ReadFilter f;
+    const int32_t* win_s0; const int32_t* win_e0; const int32_t* win_row;   // region of every window-list entry
+    const int32_t* snp_p0;
+    KeyLayout<K> kl;
+    K* keys; uint64_t* vals; unsigned long long cap;   // cap = capacity of ONE shard
+    unsigned long long* ctl;             // control block, see CTL_* below
+};
+
+// The append cursor is sharded: a returning atomicAdd on one word tops out near 88 ops/us on gfx950
+// (one L2 channel), which bounded the first two versions of this kernel.  Tiles use shard
+// blockIdx % NSHARD; every shard owns its own cursor word (128 B apart -> different channels) and
+// its own slice [shard*cap, (shard+1)*cap) of the hit buffer; finish() packs the slices.
+constexpr int NSHARD = 16;
+constexpr int CTL_OVERFLOW = 1, CTL_SCRATCH = 3, CTL_SHARD0 = 16, CTL_STRIDE = 16;
+constexpr int CTL_WORDS = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
+__host__ __device__ inline int ctl_cursor(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE; }
+__host__ __device__ inline int ctl_accepted(int shard) { return CTL_SHARD0 + (NSHARD + shard) * CTL_STRIDE; }
 
 struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint64_t umi; bool ok; };
 
+// ---- join kernel: one 256-thread block per tile of 2048 consecutive reads ---------------------
+// Reads are coordinate sorted, so a tile touches a handful of index windows, regions / SNPs and
+// one contiguous run of CIGAR words: all of that is staged in LDS once per tile (with a global
+// fallback for anything outside the staged range - the staging is a cache, never a correctness
+// assumption).  Accepted (read, region) keys go into an LDS hash set (64-bit keys), which removes
+// the PCR/UMI duplicates that sit next to each other in a sorted BAM before they ever reach HBM;
+// pileup hits and 128-bit keys go through an LDS queue.  The set / queue is flushed as one
+// contiguous COO fragment: ONE atomicAdd on the global cursor per flush (a cursor word saturates
+// at ~88 returning atomics/us on gfx950 - one per 256 reads was the bottleneck of the first
+// version), wave ballot + mbcnt prefix compaction, coalesced 8/16-byte stores.
+#ifndef XCK_TILE_ITEMS
+#define XCK_TILE_ITEMS 4
+#endif
+#ifndef XCK_HS_BYTES
+#define XCK_HS_BYTES 16384
+#endif
+#ifndef XCK_CG_CAP
+#define XCK_CG_CAP 1536
+#endif
+#ifndef XCK_ST_CAP
+#define XCK_ST_CAP 256
+#endif
+constexpr int TILE_ITEMS = XCK_TILE_ITEMS;
+constexpr int TILE = JOIN_BLOCK * TILE_ITEMS;
+constexpr int HS_BYTES = XCK_HS_BYTES;   // LDS set / queue storage per block
+constexpr int HS_SLOTS = HS_BYTES / 8;   // slots of the 64-bit key set
+constexpr int CG_CAP = XCK_CG_CAP;       // staged CIGAR words
+constexpr int ST_CAP = XCK_ST_CAP;       // staged regions / SNPs
+constexpr int ST_WIN = 64;               // staged index windows
+
+template <class K, int MODE> struct JoinSmem {
+    static constexpr bool USE_SET = (MODE == XCK_MODE_BASEFC) && sizeof(K) == 8;
+    static constexpr int  QCAP = HS_BYTES / (int)(sizeof(K) + (MODE == XCK_MODE_BAF ? 8 : 0));
+    alignas(16) unsigned char store[HS_BYTES];
+    uint32_t cig[CG_CAP];
+    int32_t  st_a[ST_CAP], st_b[ST_CAP], st_c[ST_CAP];
+    int32_t  st_w[ST_WIN + 1];
+    uint32_t cg_lo, cg_n;                // staged CIGAR range [cg_lo, cg_lo + cg_n)
+    int32_t  w0, nw;                     // staged windows [w0, w0 + nw)          (basefc)
+    int32_t  k0, nk;                     // staged SNPs    [k0, k0 + nk)          (pileup)
+    uint32_t count;                      // entries currently in the set / queue
+    uint32_t wcnt[JOIN_BLOCK / 64];
+    unsigned long long base;
+    __device__ K* keys() { return reinterpret_cast<K*>(store); }
+    __device__ uint64_t* vals() { return reinterpret_cast<uint64_t*>(store + (size_t)QCAP * sizeof(K)); }
+};
+
+template <class K, int MODE>
+__device__ __forceinline__ uint32_t cig_at(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, uint32_t c) {
+    uint32_t rel = c - sm.cg_lo;
+    return rel < sm.cg_n ? sm.cig[rel] : d.cigar[c];
+}
+
 // filter + CIGAR summary of read i (endpos = htslib bam_endpos, n_al = len(read.positions))
-template <class K>
-__device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, int i) {
+template <class K, int MODE>
+__device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int i) {
     ReadInfo r; r.ok = false; r.pos = 0; r.endpos = 0; r.n_al = 0; r.c0 = r.c1 = 0; r.cell = -1; r.umi = 0;
-    if (i >= a.n) return r;
-    uint32_t flag = a.flag[i];
-    int32_t mapq = a.mapq[i];
-    r.cell = a.cell[i];
-    r.umi = a.umi[i];
-    r.pos = a.pos[i];
-    r.c0 = a.cig_off[i]; r.c1 = a.cig_off[i + 1];
+    if (i >= d.n) return r;
+    uint32_t flag = d.flag[i];
+    int32_t mapq = d.mapq[i];
+    r.cell = d.cell[i];
+    r.umi = d.umi[i];
+    r.pos = d.pos[i];
+    r.c0 = d.cig_off[i]; r.c1 = d.cig_off[i + 1];
     bool ok = mapq >= a.f.min_mapq;
     ok = ok && !(a.f.excl_flag && (flag & a.f.excl_flag));
     ok = ok && !(a.f.incl_flag && !(flag & a.f.incl_flag));
@@ -103,7 +173,7 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, int i) {
     if (!ok) return r;
     int32_t rlen = 0, n_al = 0;
     for (uint32_t c = r.c0; c < r.c1; c++) {
-        uint32_t w = a.cigar[c]; uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
+        uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
         if (op_ref(op)) rlen += l;
         if (op_aligned(op)) n_al += l;
     }
@@ -116,12 +186,12 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, int i) {
 }
 
 // __get_include_len(): aligned bases with s0 <= p < e0
-template <class K>
-__device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const ReadInfo& r, int32_t s0, int32_t e0) {
+template <class K, int MODE>
+__device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const ReadInfo& r, int32_t s0, int32_t e0) {
     if (r.pos >= s0 && r.endpos <= e0) return r.n_al;
     int32_t p = r.pos, m = 0;
     for (uint32_t c = r.c0; c < r.c1; c++) {
-        uint32_t w = a.cigar[c]; uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
+        uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
         if (op_aligned(op)) {
             int32_t lo = max(p, s0), hi = min(p + l, e0);
             if (hi > lo) m += hi - lo;
@@ -131,44 +201,18 @@ __device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const Read
     return m;
 }
 
-template <class K, bool WRITE>
-__device__ __forceinline__ uint32_t enum_regions(const JoinArgs<K>& a, const ReadInfo& r, unsigned long long dst,
-                                                 uint64_t& umi_or) {
-    uint32_t cnt = 0;
-    int32_t w_lo = r.pos >> WS;
-    if (w_lo >= a.n_win) return 0;
-    int32_t w_hi = min((r.endpos - 1) >> WS, a.n_win - 1);
-    for (int32_t w = w_lo; w <= w_hi; w++) {
-        int32_t k0 = a.win_off[w], k1 = a.win_off[w + 1];
-        for (int32_t k = k0; k < k1; k++) {
-            int32_t g = a.win_list[k];
-            int32_t s0 = a.reg_s0[g], e0 = a.reg_e0[g];
-            if (w != max(w_lo, s0 >> WS)) continue;                 // report each pair once
-            if (!(r.pos < e0 && r.endpos > s0)) continue;           // htslib fetch overlap
-            int32_t m = included_len(a, r, s0, e0);
-            if (a.f.frac_mode) {
-                if (r.n_al <= 0) continue;
-                if ((double)m / (double)r.n_al < a.f.min_inc_frac) continue;   // IEEE double, as float(n)
-            } else if (m < a.f.min_inc_len) continue;
-            if (WRITE) { a.keys[dst + cnt] = a.kl.make((uint32_t)a.reg_row[g], (uint32_t)r.cell, r.umi); umi_or |= r.umi; }
-            cnt++;
-        }
-    }
-    return cnt;
-}
-
 // UCount.push_read + get_query_bases: BAM nibble of the query base at reference p0, or -1
-template <class K>
-__device__ __forceinline__ int allele_at(const JoinArgs<K>& a, const ReadInfo& r, int i, int32_t p0) {
+template <class K, int MODE>
+__device__ __forceinline__ int allele_at(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const ReadInfo& r, int i, int32_t p0) {
     int32_t rp = r.pos, q = 0;
     for (uint32_t c = r.c0; c < r.c1; c++) {
-        uint32_t w = a.cigar[c]; uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
+        uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
         if (op_aligned(op)) {
             if (p0 >= rp && p0 < rp + l) {
                 int32_t qi = q + (p0 - rp);
-                uint32_t s0 = a.seq_off[i], s1 = a.seq_off[i + 1];
+                uint32_t s0 = d.seq_off[i], s1 = d.seq_off[i + 1];
                 if ((uint32_t)(qi >> 1) >= s1 - s0) return -1;
-                uint32_t by = a.seq[s0 + (qi >> 1)];
+                uint32_t by = d.seq[s0 + (qi >> 1)];
                 return (qi & 1) ? int(by & 15u) : int(by >> 4);
             }
             rp += l; q += l;
@@ -178,26 +222,224 @@ __device__ __forceinline__ int allele_at(const JoinArgs<K>& a, const ReadInfo& r
     return -1;
 }
 
-template <class K, bool WRITE>
-__device__ __forceinline__ uint32_t enum_snps(const JoinArgs<K>& a, const ReadInfo& r, int i, unsigned long long dst,
-                                              uint64_t& umi_or) {
-    uint32_t cnt = 0;
-    int32_t w_lo = r.pos >> WS;
-    if (w_lo >= a.n_swin) return 0;
-    int32_t k = a.snp_win[w_lo];
-    while (k < a.snp_end && a.snp_p0[k] < r.pos) k++;
-    for (; k < a.snp_end; k++) {
-        int32_t p0 = a.snp_p0[k];
-        if (p0 >= r.endpos) break;
-        if (WRITE) {
-            int al = allele_at(a, r, i, p0);
-            a.keys[dst + cnt] = a.kl.make((uint32_t)k, (uint32_t)r.cell, r.umi);
-            a.vals[dst + cnt] = ((a.ordinal_base + (uint64_t)i) << ALLELE_BITS) | (uint64_t)(al + 1);
-            umi_or |= r.umi;
+// append straight to HBM (slow path: LDS set/queue saturated)
+template <class K, int MODE>
+__device__ __forceinline__ void emit_global(const JoinArgs<K>& a, K key, uint64_t val) {
+    const int shard = blockIdx.x & (NSHARD - 1);
+    unsigned long long idx = atomicAdd(&a.ctl[ctl_cursor(shard)], 1ull);
+    if (idx < a.cap) { idx += (unsigned long long)shard * a.cap; a.keys[idx] = key; if (MODE == XCK_MODE_BAF) a.vals[idx] = val; }
+    else atomicExch(&a.ctl[CTL_OVERFLOW], 1ull);
+}
+
+template <class K, int MODE>
+__device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, K key, uint64_t val) {
+    if constexpr (JoinSmem<K, MODE>::USE_SET) {
+        unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
+        const unsigned long long kk = (unsigned long long)key;
+        uint32_t slot = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (HS_SLOTS - 1);
+        for (int probe = 0; probe < 24; probe++) {
+            unsigned long long prev = atomicCAS(&set[slot], ~0ull, kk);
+            if (prev == ~0ull) { atomicAdd(&sm.count, 1u); return; }
+            if (prev == kk) return;                                  // duplicate (same region, cell, UMI)
+            slot = (slot + 1) & (HS_SLOTS - 1);
         }
-        cnt++;
+        emit_global<K, MODE>(a, key, val);
+    } else {
+        uint32_t idx = atomicAdd(&sm.count, 1u);
+        if (idx < (uint32_t)JoinSmem<K, MODE>::QCAP) { sm.keys()[idx] = key; if (MODE == XCK_MODE_BAF) sm.vals()[idx] = val; }
+        else emit_global<K, MODE>(a, key, val);
     }
-    return cnt;
+}
+
+// write the LDS set / queue to HBM as one contiguous fragment; block-wide call
+template <class K, int MODE>
+__device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (JoinSmem<K, MODE>::USE_SET) {
+        unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
+        constexpr int PER_WAVE = HS_SLOTS / (JOIN_BLOCK / 64);
+        uint32_t c = 0;
+        for (int s = wave * PER_WAVE + lane; s < (wave + 1) * PER_WAVE; s += 64) c += (set[s] != ~0ull) ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        if (lane == 0) sm.wcnt[wave] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
+            unsigned long long b = 0;
+            if (total) {
+                const int shard = blockIdx.x & (NSHARD - 1);
+                b = atomicAdd(&a.ctl[ctl_cursor(shard)], (unsigned long long)total);
+                if (b + total > a.cap) { atomicExch(&a.ctl[CTL_OVERFLOW], 1ull); b = ~0ull; }
+                else b += (unsigned long long)shard * a.cap;
+            }
+            sm.base = b; sm.count = 0;
+        }
+        __syncthreads();
+        unsigned long long dst = sm.base;
+        const bool fits = dst != ~0ull;
+        for (int w = 0; w < wave; w++) dst += sm.wcnt[w];
+        for (int s = wave * PER_WAVE + lane; s < (wave + 1) * PER_WAVE; s += 64) {
+            unsigned long long v = set[s];
+            bool valid = v != ~0ull;
+            unsigned long long m = __ballot(valid);
+            if (valid) {
+                uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (fits) a.keys[dst + pre] = (K)v;
+                set[s] = ~0ull;
+            }
+            dst += __popcll(m);
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        const uint32_t total = min(sm.count, (uint32_t)JoinSmem<K, MODE>::QCAP);
+        if (threadIdx.x == 0) {
+            unsigned long long b = 0;
+            if (total) {
+                const int shard = blockIdx.x & (NSHARD - 1);
+                b = atomicAdd(&a.ctl[ctl_cursor(shard)], (unsigned long long)total);
+                if (b + total > a.cap) { atomicExch(&a.ctl[CTL_OVERFLOW], 1ull); b = ~0ull; }
+                else b += (unsigned long long)shard * a.cap;
+            }
+            sm.base = b;
+        }
+        __syncthreads();
+        const unsigned long long dst = sm.base;
+        if (dst != ~0ull)
+            for (uint32_t t = threadIdx.x; t < total; t += JOIN_BLOCK) {
+                a.keys[dst + t] = sm.keys()[t];
+                if (MODE == XCK_MODE_BAF) a.vals[dst + t] = sm.vals()[t];
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) sm.count = 0;
+        __syncthreads();
+    }
+}
+
+template <class K, int MODE>
+__device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r) {
+    uint32_t n_acc = 0;
+    int32_t w_lo = r.pos >> WS;
+    if (w_lo >= d.n_win) return 0;
+    int32_t w_hi = min((r.endpos - 1) >> WS, d.n_win - 1);
+    for (int32_t w = w_lo; w <= w_hi; w++) {
+        const bool staged = (uint32_t)(w - sm.w0) < (uint32_t)sm.nw;
+        int32_t k0, k1;
+        if (staged) { k0 = sm.st_w[w - sm.w0]; k1 = sm.st_w[w - sm.w0 + 1]; }
+        else { k0 = d.win_off[w]; k1 = d.win_off[w + 1]; }
+        for (int32_t k = k0; k < k1; k++) {
+            int32_t s0, e0, row;
+            if (staged) { s0 = sm.st_a[k]; e0 = sm.st_b[k]; row = sm.st_c[k]; }
+            else { s0 = a.win_s0[k]; e0 = a.win_e0[k]; row = a.win_row[k]; }
+            if (w != max(w_lo, s0 >> WS)) continue;                 // report each (read, region) pair once
+            if (!(r.pos < e0 && r.endpos > s0)) continue;           // htslib fetch overlap
+            int32_t m = included_len(a, d, sm, r, s0, e0);
+            if (a.f.frac_mode) {
+                if (r.n_al <= 0) continue;
+                if ((double)m / (double)r.n_al < a.f.min_inc_frac) continue;   // IEEE double, as m / float(n)
+            } else if (m < a.f.min_inc_len) continue;
+            emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
+            n_acc++;
+        }
+    }
+    return n_acc;
+}
+
+template <class K, int MODE>
+__device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r, int i) {
+    uint32_t n_acc = 0;
+    int32_t w_lo = r.pos >> WS;
+    if (w_lo >= d.n_swin) return 0;
+    int32_t k = d.snp_win[w_lo];
+    auto p0_of = [&](int32_t kk) { uint32_t d = (uint32_t)(kk - sm.k0); return d < (uint32_t)sm.nk ? sm.st_a[d] : a.snp_p0[kk]; };
+    while (k < d.snp_end && p0_of(k) < r.pos) k++;
+    for (; k < d.snp_end; k++) {
+        int32_t p0 = p0_of(k);
+        if (p0 >= r.endpos) break;
+        int al = allele_at(a, d, sm, r, i, p0);
+        emit<K, MODE>(a, sm, a.kl.make((uint32_t)k, (uint32_t)r.cell, r.umi),
+                      ((d.ordinal_base + (uint64_t)i) << ALLELE_BITS) | (uint64_t)(al + 1));
+        n_acc++;
+    }
+    return n_acc;
+}
+
+template <class K, int MODE>
+__global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
+    __shared__ JoinSmem<K, MODE> sm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // ---- prologue: every round trip to memory is done by many lanes at once (no serial chains) ----
+    // (1) which batch of the fused launch owns this tile: one gather of the tile0 column + ballot
+    int b;
+    { int t0 = lane < a.n_batches ? a.desc[lane].tile0 : 0x7fffffff;
+      b = __builtin_amdgcn_readfirstlane(__popcll(__ballot(t0 <= (int)blockIdx.x)) - 1); }
+    const BatchDesc d = a.desc[b];                                   // uniform index -> scalar loads
+    const int tile0 = ((int)blockIdx.x - d.tile0) * TILE;
+    const int tile1 = min(tile0 + TILE, d.n);
+    if constexpr (JoinSmem<K, MODE>::USE_SET) {
+        unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
+        for (int s = tid; s < HS_SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
+    }
+    // (2) tile extent: four scalars fetched by four lanes, then broadcast (each wave on its own: no barrier)
+    uint32_t v4 = 0;
+    if (lane == 0) v4 = d.cig_off[tile0]; else if (lane == 1) v4 = d.cig_off[tile1];
+    else if (lane == 2) v4 = (uint32_t)max(d.pos[tile0], 0); else if (lane == 3) v4 = (uint32_t)max(d.pos[tile1 - 1], 0);
+    const uint32_t c_lo = __shfl(v4, 0, 64), c_hi = __shfl(v4, 1, 64);
+    const int32_t p_first = (int32_t)__shfl(v4, 2, 64), p_last = (int32_t)__shfl(v4, 3, 64);
+    const uint32_t cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
+    const int32_t w0 = p_first >> WS;
+    int32_t nw = 0, e0 = 0, k0 = 0, nk = 0;
+    if (MODE == XCK_MODE_BASEFC) {
+        // (3) window offsets w0 .. w0+64 in one load per lane; keep the longest prefix whose entries fit
+        if (w0 < d.n_win && p_last >= p_first) {
+            const int32_t nw_max = min(min((p_last >> WS) + 1, d.n_win - 1) - w0 + 1, ST_WIN);
+            const int32_t off_l = d.win_off[min(w0 + lane, d.n_win)];
+            const int32_t off_last = d.win_off[min(w0 + ST_WIN, d.n_win)];
+            e0 = __shfl(off_l, 0, 64);
+            const unsigned long long fit = __ballot(lane >= 1 && lane <= nw_max && off_l - e0 <= ST_CAP);
+            nw = __popcll(fit);                                   // monotone offsets -> prefix
+            if (nw == ST_WIN - 1 && nw_max == ST_WIN && off_last - e0 <= ST_CAP) nw = ST_WIN;
+            if (tid <= nw) sm.st_w[tid] = (tid < 64 ? off_l : off_last) - e0;
+        }
+    } else {
+        if (w0 < d.n_swin) { k0 = d.snp_win[w0]; nk = min(d.snp_end - k0, ST_CAP); }
+    }
+    if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; }
+    // (4) CIGAR run + table entries, coalesced
+    for (uint32_t c = tid; c < cg_n; c += JOIN_BLOCK) sm.cig[c] = d.cigar[c_lo + c];
+    if (MODE == XCK_MODE_BASEFC) {
+        if (nw > 0) {
+            const int32_t n_ent = d.win_off[w0 + nw] - e0;
+            for (int32_t t = tid; t < n_ent; t += JOIN_BLOCK) {
+                sm.st_a[t] = a.win_s0[e0 + t]; sm.st_b[t] = a.win_e0[e0 + t]; sm.st_c[t] = a.win_row[e0 + t];
+            }
+        }
+    } else {
+        for (int32_t t = tid; t < nk; t += JOIN_BLOCK) sm.st_a[t] = a.snp_p0[k0 + t];
+    }
+    __syncthreads();
+    // ---- 8 coalesced sweeps over the tile ----
+    uint32_t acc = 0;
+    constexpr uint32_t FLUSH_AT = JoinSmem<K, MODE>::USE_SET ? HS_SLOTS / 2 : (uint32_t)JoinSmem<K, MODE>::QCAP / 2;
+    for (int j = 0; j < TILE_ITEMS; j++) {
+        const int i = tile0 + j * JOIN_BLOCK + tid;
+        ReadInfo r = load_read<K, MODE>(a, d, sm, i);
+        if (r.ok) {
+            if (MODE == XCK_MODE_BASEFC) acc += join_regions<K, MODE>(a, d, sm, r);
+            else acc += join_snps<K, MODE>(a, d, sm, r, i);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS only: keeps global loads in flight
+        if (sm.count > FLUSH_AT) flush<K, MODE>(a, sm);            // block-uniform
+    }
+    flush<K, MODE>(a, sm);
+    // accepted (read, region|SNP) pairs before the LDS de-duplication: the algorithmic unit of the join
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd, 64);
+    if (lane == 0) sm.wcnt[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) { acc = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
+                    if (acc) atomicAdd(&a.ctl[ctl_accepted(blockIdx.x & (NSHARD - 1))], (unsigned long long)acc); }
 }
 
 // exclusive scan of one uint32 per thread over a 256-thread block; returns block total in `total`
@@ -213,41 +455,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
     for (int w = 0; w < JOIN_BLOCK / 64; w++) { uint32_t t = s_wave[w]; if (w < wave) base += t; total += t; }
     __syncthreads();
     return base + inc - v;
-}
-
-// One thread per read; per-block COO fragment allocated with ONE atomic on the global cursor.
-template <class K, int MODE>
-__global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
-    __shared__ uint32_t s_wave[JOIN_BLOCK / 64];
-    __shared__ unsigned long long s_base;
-    __shared__ unsigned long long s_or;
-    const int i = blockIdx.x * JOIN_BLOCK + threadIdx.x;
-    ReadInfo r = load_read(a, i);
-    uint64_t umi_or = 0;
-    uint32_t cnt = 0;
-    if (r.ok) cnt = (MODE == XCK_MODE_BASEFC) ? enum_regions<K, false>(a, r, 0, umi_or)
-                                              : enum_snps<K, false>(a, r, i, 0, umi_or);
-    uint32_t total;
-    uint32_t excl = block_excl_scan(cnt, s_wave, total);
-    if (total == 0) return;                                           // uniform per block
-    if (threadIdx.x == 0) {
-        unsigned long long b = atomicAdd(&a.ctl[0], (unsigned long long)total);
-        if (b + total > a.cap) { atomicExch(&a.ctl[1], 1ull); b = ~0ull; }
-        s_base = b; s_or = 0;
-    }
-    __syncthreads();
-    unsigned long long base = s_base;
-    if (base == ~0ull) return;                                        // fragment does not fit: host retries
-    if (cnt) {
-        if (MODE == XCK_MODE_BASEFC) enum_regions<K, true>(a, r, base + excl, umi_or);
-        else enum_snps<K, true>(a, r, i, base + excl, umi_or);
-    }
-    // OR of emitted umi codes (tells finish() how many key bits are really in use)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) umi_or |= __shfl_xor(umi_or, d, 64);
-    if ((threadIdx.x & 63) == 0 && umi_or) atomicOr(&s_or, (unsigned long long)umi_or);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_or) atomicOr(&a.ctl[2], s_or);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -447,11 +654,19 @@ struct BatchSlot {
     int32_t* pos = nullptr; uint16_t* flag = nullptr; uint8_t* mapq = nullptr; int32_t* cell = nullptr;
     uint64_t* umi = nullptr; uint32_t* cig_off = nullptr; uint32_t* cigar = nullptr; uint32_t* seq_off = nullptr; uint8_t* seq = nullptr;
     size_t cap_reads = 0, cap_cig = 0, cap_seq = 0;
-    hipEvent_t copied = nullptr, done = nullptr;
     bool busy = false;
 };
 
-struct PendingLaunch { bool valid = false; xck_batch dev; unsigned long long cursor_before = 0; int slot = -1; };
+// grow-only device workspace: finish() sub-allocates from it instead of hipMalloc/hipFree per call
+struct Arena {
+    char* base = nullptr; size_t cap = 0, off = 0;
+    template <class T> T* get(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += std::max<size_t>(n, 1) * sizeof(T);
+        return off <= cap ? p : nullptr;
+    }
+};
 
 struct EngineImpl {
     xck_engine* eng = nullptr;
@@ -463,25 +678,33 @@ struct EngineImpl {
     int n_cells = 0, n_regions = 0, n_snps_sorted = 0;
     std::vector<ContigTab> ctab;
     // device tables
-    int32_t *d_reg_s0 = nullptr, *d_reg_e0 = nullptr, *d_reg_row = nullptr, *d_win_off = nullptr, *d_win_list = nullptr;
+    int32_t *d_win_s0 = nullptr, *d_win_e0 = nullptr, *d_win_row = nullptr, *d_win_off = nullptr;
     int32_t *d_snp_p0 = nullptr, *d_snp_win = nullptr, *d_csr_off = nullptr, *d_csr_reg = nullptr;
     uint32_t *d_snp_info = nullptr, *d_tally = nullptr;
     hipStream_t s_copy = nullptr, s_comp = nullptr;
     BatchSlot slot[2];
     int next_slot = 0;
     int64_t max_batch_reads = 0;
-    // hit accumulators
+    // hit accumulators (ping-pong pair so that sort results can stay where they land)
     void* d_keys = nullptr; uint64_t* d_vals = nullptr; size_t hit_cap = 0;
-    unsigned long long* d_ctl = nullptr;       // [0] cursor [1] overflow [2] umi OR [3] scratch total
+    unsigned long long* d_ctl = nullptr;       // CTL_WORDS control words (overflow flag, scratch, sharded cursors)
     unsigned long long* h_ctl = nullptr;       // pinned mirror
-    unsigned long long cursor = 0;             // host view after the last completed launch
-    PendingLaunch pend;
+    unsigned long long cur[NSHARD] = {0};      // host view of the shard cursors after the last completed launch
+    unsigned long long cur_before[NSHARD] = {0}, acc_before[NSHARD] = {0};
+    unsigned long long cursor = 0;             // sum of cur[]; hit_cap is the capacity of ONE shard
+    // fused launch queue
+    std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
+    std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
+    int inflight_slot = -1;
+    int64_t queued_reads = 0, inflight_reads = 0;
+    BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> join_events;   // recycled
     xck_stats st{};
-    // results (host)
-    std::vector<int32_t> res[4][3];
+    int64_t n_join_launches = 0;
+    // workspace + results
+    Arena ws1, ws2;
+    int32_t* h_res[4] = {nullptr, nullptr, nullptr, nullptr}; size_t h_res_cap[4] = {0, 0, 0, 0}; size_t res_nnz[4] = {0, 0, 0, 0};
     bool finished = false;
 };
 
@@ -587,11 +810,14 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
         im->n_snps_sorted = (int)snp_p0.size();
     }
     int rc;
-    if ((rc = dev_upload(im, &im->d_reg_s0, reg_s0))) return rc;
-    if ((rc = dev_upload(im, &im->d_reg_e0, reg_e0))) return rc;
-    if ((rc = dev_upload(im, &im->d_reg_row, reg_row))) return rc;
+    {   // window-list entries carry their region inline (one load level less in the join)
+        std::vector<int32_t> ws0(win_list.size()), we0(win_list.size()), wrow(win_list.size());
+        for (size_t k = 0; k < win_list.size(); k++) { int32_t g = win_list[k]; ws0[k] = reg_s0[g]; we0[k] = reg_e0[g]; wrow[k] = reg_row[g]; }
+        if ((rc = dev_upload(im, &im->d_win_s0, ws0))) return rc;
+        if ((rc = dev_upload(im, &im->d_win_e0, we0))) return rc;
+        if ((rc = dev_upload(im, &im->d_win_row, wrow))) return rc;
+    }
     if ((rc = dev_upload(im, &im->d_win_off, win_off))) return rc;
-    if ((rc = dev_upload(im, &im->d_win_list, win_list))) return rc;
     if ((rc = dev_upload(im, &im->d_snp_p0, snp_p0))) return rc;
     if ((rc = dev_upload(im, &im->d_snp_win, snp_win))) return rc;
     if ((rc = dev_upload(im, &im->d_snp_info, snp_info))) return rc;
@@ -604,17 +830,41 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
     return 0;
 }
 
-static int ensure_hits(EngineImpl* im, size_t need) {
+static int arena_begin(EngineImpl* im, Arena& a, size_t need) {
+    a.off = 0;
+    if (need > a.cap) {
+        if (a.base) HIP_TRY(hipFree(a.base));
+        a.base = nullptr; a.cap = 0;
+        size_t c = need + need / 4 + (1 << 20);
+        HIP_TRY(hipMalloc((void**)&a.base, c));
+        a.cap = c;
+    }
+    return 0;
+}
+
+static int res_reserve(EngineImpl* im, int m, size_t nnz) {
+    if (nnz * 3 > im->h_res_cap[m]) {
+        if (im->h_res[m]) HIP_TRY(hipHostFree(im->h_res[m]));
+        im->h_res[m] = nullptr; im->h_res_cap[m] = 0;
+        size_t c = nnz * 3 + nnz / 2 + 1024;
+        HIP_TRY(hipHostMalloc((void**)&im->h_res[m], c * sizeof(int32_t), hipHostMallocDefault));
+        im->h_res_cap[m] = c;
+    }
+    return 0;
+}
+
+static int ensure_hits(EngineImpl* im, size_t need) {           // need = elements per shard
     if (need <= im->hit_cap) return 0;
     size_t ncap = std::max<size_t>(need, im->hit_cap * 2);
     void* nk = nullptr; uint64_t* nv = nullptr;
-    HIP_TRY(hipMalloc(&nk, ncap * key_bytes(im)));
-    if (im->mode == XCK_MODE_BAF) HIP_TRY(hipMalloc((void**)&nv, ncap * sizeof(uint64_t)));
-    if (im->cursor) {
-        HIP_TRY(hipMemcpyAsync(nk, im->d_keys, im->cursor * key_bytes(im), hipMemcpyDeviceToDevice, im->s_comp));
-        if (nv) HIP_TRY(hipMemcpyAsync(nv, im->d_vals, im->cursor * sizeof(uint64_t), hipMemcpyDeviceToDevice, im->s_comp));
-        HIP_TRY(hipStreamSynchronize(im->s_comp));
+    HIP_TRY(hipMalloc(&nk, ncap * NSHARD * key_bytes(im)));
+    if (im->mode == XCK_MODE_BAF) HIP_TRY(hipMalloc((void**)&nv, ncap * NSHARD * sizeof(uint64_t)));
+    for (int sh = 0; sh < NSHARD; sh++) if (im->cur[sh]) {
+        HIP_TRY(hipMemcpyAsync((char*)nk + (size_t)sh * ncap * key_bytes(im), (char*)im->d_keys + (size_t)sh * im->hit_cap * key_bytes(im),
+                               im->cur[sh] * key_bytes(im), hipMemcpyDeviceToDevice, im->s_comp));
+        if (nv) HIP_TRY(hipMemcpyAsync(nv + (size_t)sh * ncap, im->d_vals + (size_t)sh * im->hit_cap, im->cur[sh] * sizeof(uint64_t), hipMemcpyDeviceToDevice, im->s_comp));
     }
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
     if (im->d_keys) HIP_TRY(hipFree(im->d_keys));
     if (im->d_vals) HIP_TRY(hipFree(im->d_vals));
     im->d_keys = nk; im->d_vals = nv; im->hit_cap = ncap;
@@ -635,54 +885,68 @@ static int slot_reserve(EngineImpl* im, BatchSlot& s, size_t n_reads, size_t n_c
     return 0;
 }
 
+// launch ONE fused join kernel over every batch in im->inflight
 template <class K>
-static int launch_join_t(EngineImpl* im, const xck_batch& d, hipEvent_t e0, hipEvent_t e1) {
+static int launch_join_t(EngineImpl* im) {
+    const int nb = (int)im->inflight.size();
+    int32_t tiles = 0;
+    for (int i = 0; i < nb; i++) { im->inflight[i].tile0 = tiles; tiles += (im->inflight[i].n + TILE - 1) / TILE; im->h_desc[i] = im->inflight[i]; }
+    HIP_TRY(hipMemcpyAsync(im->d_desc, im->h_desc, nb * sizeof(BatchDesc), hipMemcpyHostToDevice, im->s_comp));
     JoinArgs<K> a;
-    a.n = d.n_reads; a.pos = d.pos; a.flag = d.flag; a.mapq = d.mapq; a.cell = d.cell; a.umi = d.umi;
-    a.cig_off = d.cig_off; a.cigar = d.cigar; a.seq_off = d.seq_off; a.seq = d.seq; a.ordinal_base = d.ordinal_base;
-    a.f = im->rf;
-    const ContigTab& t = im->ctab[d.contig];
-    a.reg_s0 = im->d_reg_s0; a.reg_e0 = im->d_reg_e0; a.reg_row = im->d_reg_row;
-    a.win_off = im->d_win_off + t.win_base; a.win_list = im->d_win_list; a.n_win = t.n_win;
-    a.snp_p0 = im->d_snp_p0; a.snp_win = im->d_snp_win + t.swin_base; a.n_swin = t.n_swin; a.snp_end = t.snp_base + t.n_snp;
+    a.n_batches = nb; a.desc = im->d_desc; a.f = im->rf;
+    a.win_s0 = im->d_win_s0; a.win_e0 = im->d_win_e0; a.win_row = im->d_win_row;
+    a.snp_p0 = im->d_snp_p0;
     a.kl.ubits = im->ubits; a.kl.cbits = im->cbits;
     a.keys = (K*)im->d_keys; a.vals = im->d_vals; a.cap = im->hit_cap; a.ctl = im->d_ctl;
-    dim3 grid((d.n_reads + JOIN_BLOCK - 1) / JOIN_BLOCK), block(JOIN_BLOCK);
-    HIP_TRY(hipEventRecord(e0, im->s_comp));
+    dim3 grid(tiles), block(JOIN_BLOCK);
+    HIP_TRY(hipEventRecord(im->ev0, im->s_comp));
     if (im->mode == XCK_MODE_BASEFC) hipLaunchKernelGGL((k_join<K, XCK_MODE_BASEFC>), grid, block, 0, im->s_comp, a);
     else hipLaunchKernelGGL((k_join<K, XCK_MODE_BAF>), grid, block, 0, im->s_comp, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, im->s_comp));
+    HIP_TRY(hipEventRecord(im->ev1, im->s_comp));
+    HIP_TRY(hipMemcpyAsync(im->h_ctl, im->d_ctl, CTL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, im->s_comp));
     return 0;
 }
+static int launch_join(EngineImpl* im) { return im->key_bits == 64 ? launch_join_t<uint64_t>(im) : launch_join_t<u128>(im); }
 
-static int launch_join(EngineImpl* im, const xck_batch& d) {
-    int rc = im->key_bits == 64 ? launch_join_t<uint64_t>(im, d, im->ev0, im->ev1) : launch_join_t<u128>(im, d, im->ev0, im->ev1);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(im->h_ctl, im->d_ctl, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, im->s_comp));
-    return 0;
-}
-
-// wait for the launch in flight, collect its cursor / timing, retry it if its fragment buffer overflowed
+// wait for the launch in flight, collect cursor / timing; if its fragments did not fit, grow, rewind and replay
 static int complete_pending(EngineImpl* im) {
-    while (im->pend.valid) {
+    while (!im->inflight.empty()) {
         HIP_TRY(hipStreamSynchronize(im->s_comp));
         float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, im->ev0, im->ev1));
-        im->st.ms_join += ms; im->st.ms_device += ms;
-        if (im->h_ctl[1]) {                                   // overflow: grow, rewind cursor, run again
-            size_t want = std::max<size_t>(im->h_ctl[0] + (size_t)im->pend.dev.n_reads * 4, im->hit_cap * 2);
-            int rc = ensure_hits(im, want); if (rc) return rc;
-            unsigned long long z[2] = { im->pend.cursor_before, 0 };
-            HIP_TRY(hipMemcpyAsync(im->d_ctl, z, sizeof z, hipMemcpyHostToDevice, im->s_comp));
+        im->st.ms_join += ms; im->st.ms_device += ms; im->n_join_launches++;
+        if (im->h_ctl[CTL_OVERFLOW]) {                       // some fragment did not fit: grow, rewind, replay
+            unsigned long long mx = 0;
+            for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, im->h_ctl[ctl_cursor(sh)]);
+            int rc = ensure_hits(im, std::max<size_t>(mx + mx / 4 + 65536, im->hit_cap * 2)); if (rc) return rc;
+            for (int sh = 0; sh < NSHARD; sh++) { im->h_ctl[ctl_cursor(sh)] = im->cur_before[sh]; im->h_ctl[ctl_accepted(sh)] = im->acc_before[sh]; }
+            im->h_ctl[CTL_OVERFLOW] = 0;
+            HIP_TRY(hipMemcpyAsync(im->d_ctl, im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipMemcpyHostToDevice, im->s_comp));
             HIP_TRY(hipStreamSynchronize(im->s_comp));
-            rc = launch_join(im, im->pend.dev); if (rc) return rc;
+            rc = launch_join(im); if (rc) return rc;
             continue;
         }
-        im->cursor = im->h_ctl[0];
-        if (im->pend.slot >= 0) im->slot[im->pend.slot].busy = false;
-        im->pend.valid = false;
+        im->cursor = 0;
+        for (int sh = 0; sh < NSHARD; sh++) { im->cur[sh] = im->h_ctl[ctl_cursor(sh)]; im->cursor += im->cur[sh]; }
+        if (im->inflight_slot >= 0) im->slot[im->inflight_slot].busy = false;
+        im->inflight.clear(); im->inflight_slot = -1; im->inflight_reads = 0;
     }
     return 0;
+}
+
+// launch whatever is queued (after the previous launch has been confirmed)
+static int launch_queue(EngineImpl* im, int slot_idx) {
+    if (im->queue.empty()) return 0;
+    int rc = complete_pending(im); if (rc) return rc;
+    { unsigned long long mx = 0;
+      for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, im->cur[sh]);
+      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / NSHARD + 65536); if (rc) return rc; }
+    im->inflight.swap(im->queue); im->queue.clear();
+    im->inflight_reads = im->queued_reads; im->queued_reads = 0;
+    im->inflight_slot = slot_idx;
+    for (int sh = 0; sh < NSHARD; sh++) { im->cur_before[sh] = im->cur[sh]; im->acc_before[sh] = im->h_ctl[ctl_accepted(sh)]; }
+    if (slot_idx >= 0) im->slot[slot_idx].busy = true;
+    return launch_join(im);
 }
 
 int engine_push(xck_engine* e, const xck_batch* b, bool device_resident) {
@@ -698,51 +962,55 @@ int engine_push(xck_engine* e, const xck_batch* b, bool device_resident) {
     const ContigTab& t = im->ctab[b->contig];
     bool has_targets = im->mode == XCK_MODE_BASEFC ? t.n_reg > 0 : t.n_snp > 0;
     if (!has_targets) return 0;
-    xck_batch dev = *b;
-    int slot_idx = -1;
-    if (!device_resident) {
-        size_t n = (size_t)b->n_reads;
-        // offsets need not start at 0 (a batch may be a window into a larger decode buffer)
-        const uint32_t c_lo = b->cig_off[0], s_lo = im->mode == XCK_MODE_BAF ? b->seq_off[0] : 0;
-        if (b->cig_off[n] < c_lo || (im->mode == XCK_MODE_BAF && b->seq_off[n] < s_lo)) { e->err = "batch offsets are not monotonic"; return XCK_E_ARG; }
-        uint32_t n_cig = b->cig_off[n] - c_lo, n_seq = im->mode == XCK_MODE_BAF ? b->seq_off[n] - s_lo : 0;
-        // the slot we are about to overwrite may still feed the launch in flight
-        slot_idx = im->next_slot; im->next_slot ^= 1;
-        BatchSlot& s = im->slot[slot_idx];
-        if (s.busy) { int rc = complete_pending(im); if (rc) return rc; }
-        int rc = slot_reserve(im, s, n, std::max<uint32_t>(n_cig, 1), std::max<uint32_t>(n_seq, 1)); if (rc) return rc;
-        auto t0 = std::chrono::steady_clock::now();
-        HIP_TRY(hipMemcpyAsync(s.pos, b->pos, n * 4, hipMemcpyHostToDevice, im->s_copy));
-        HIP_TRY(hipMemcpyAsync(s.flag, b->flag, n * 2, hipMemcpyHostToDevice, im->s_copy));
-        HIP_TRY(hipMemcpyAsync(s.mapq, b->mapq, n, hipMemcpyHostToDevice, im->s_copy));
-        HIP_TRY(hipMemcpyAsync(s.cell, b->cell, n * 4, hipMemcpyHostToDevice, im->s_copy));
-        HIP_TRY(hipMemcpyAsync(s.umi, b->umi, n * 8, hipMemcpyHostToDevice, im->s_copy));
-        HIP_TRY(hipMemcpyAsync(s.cig_off, b->cig_off, (n + 1) * 4, hipMemcpyHostToDevice, im->s_copy));
-        if (n_cig) HIP_TRY(hipMemcpyAsync(s.cigar, b->cigar + c_lo, (size_t)n_cig * 4, hipMemcpyHostToDevice, im->s_copy));
-        if (im->mode == XCK_MODE_BAF) {
-            HIP_TRY(hipMemcpyAsync(s.seq_off, b->seq_off, (n + 1) * 4, hipMemcpyHostToDevice, im->s_copy));
-            if (n_seq) HIP_TRY(hipMemcpyAsync(s.seq, b->seq + s_lo, n_seq, hipMemcpyHostToDevice, im->s_copy));
-        }
-        HIP_TRY(hipStreamSynchronize(im->s_copy));             // caller may reuse its arrays now
-        im->st.ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        dev.pos = s.pos; dev.flag = s.flag; dev.mapq = s.mapq; dev.cell = s.cell; dev.umi = s.umi;
-        dev.cig_off = s.cig_off; dev.cigar = s.cigar - c_lo; dev.seq_off = s.seq_off; dev.seq = s.seq - s_lo;   // rebased, never read below *_lo
-        im->st.algo_bytes_join += (int64_t)n * 20 + (int64_t)n_cig * 4 + (int64_t)(n_seq / 2);
+    BatchDesc d;
+    memset(&d, 0, sizeof d);
+    d.n = b->n_reads; d.ordinal_base = b->ordinal_base;
+    d.win_off = im->d_win_off + t.win_base; d.n_win = t.n_win;
+    d.snp_win = im->d_snp_win + t.swin_base; d.n_swin = t.n_swin; d.snp_end = t.snp_base + t.n_snp;
+    if (device_resident) {
+        // deferred: consecutive device-resident batches are fused into one launch (>> 256 workgroups)
+        d.pos = b->pos; d.flag = b->flag; d.mapq = b->mapq; d.cell = b->cell; d.umi = b->umi;
+        d.cig_off = b->cig_off; d.cigar = b->cigar; d.seq_off = b->seq_off; d.seq = b->seq;
+        im->queue.push_back(d); im->queued_reads += b->n_reads;
+        if ((int)im->queue.size() >= MAX_FUSE) return launch_queue(im, -1);
+        return 0;
     }
-    // previous launch must have finished before the next one may append (cursor / overflow protocol)
-    int rc = complete_pending(im); if (rc) return rc;
-    rc = ensure_hits(im, im->cursor + (size_t)b->n_reads * 6 + 4096); if (rc) return rc;
-    im->pend.valid = true; im->pend.dev = dev; im->pend.cursor_before = im->cursor; im->pend.slot = slot_idx;
-    if (slot_idx >= 0) im->slot[slot_idx].busy = true;
-    rc = launch_join(im, dev); if (rc) return rc;
-    // algorithmic bytes of this launch: SoA record + CIGAR words (+ 2-bit bases for pileup)
-    return 0;
+    int rc = launch_queue(im, -1); if (rc) return rc;          // keep launch order == push order
+    size_t n = (size_t)b->n_reads;
+    // offsets need not start at 0 (a batch may be a window into a larger decode buffer)
+    const uint32_t c_lo = b->cig_off[0], s_lo = im->mode == XCK_MODE_BAF ? b->seq_off[0] : 0;
+    if (b->cig_off[n] < c_lo || (im->mode == XCK_MODE_BAF && b->seq_off[n] < s_lo)) { e->err = "batch offsets are not monotonic"; return XCK_E_ARG; }
+    uint32_t n_cig = b->cig_off[n] - c_lo, n_seq = im->mode == XCK_MODE_BAF ? b->seq_off[n] - s_lo : 0;
+    int slot_idx = im->next_slot; im->next_slot ^= 1;
+    BatchSlot& s = im->slot[slot_idx];
+    if (s.busy) { rc = complete_pending(im); if (rc) return rc; }   // slot still feeds the launch in flight
+    rc = slot_reserve(im, s, n, std::max<uint32_t>(n_cig, 1), std::max<uint32_t>(n_seq, 1)); if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemcpyAsync(s.pos, b->pos, n * 4, hipMemcpyHostToDevice, im->s_copy));
+    HIP_TRY(hipMemcpyAsync(s.flag, b->flag, n * 2, hipMemcpyHostToDevice, im->s_copy));
+    HIP_TRY(hipMemcpyAsync(s.mapq, b->mapq, n, hipMemcpyHostToDevice, im->s_copy));
+    HIP_TRY(hipMemcpyAsync(s.cell, b->cell, n * 4, hipMemcpyHostToDevice, im->s_copy));
+    HIP_TRY(hipMemcpyAsync(s.umi, b->umi, n * 8, hipMemcpyHostToDevice, im->s_copy));
+    HIP_TRY(hipMemcpyAsync(s.cig_off, b->cig_off, (n + 1) * 4, hipMemcpyHostToDevice, im->s_copy));
+    if (n_cig) HIP_TRY(hipMemcpyAsync(s.cigar, b->cigar + c_lo, (size_t)n_cig * 4, hipMemcpyHostToDevice, im->s_copy));
+    if (im->mode == XCK_MODE_BAF) {
+        HIP_TRY(hipMemcpyAsync(s.seq_off, b->seq_off, (n + 1) * 4, hipMemcpyHostToDevice, im->s_copy));
+        if (n_seq) HIP_TRY(hipMemcpyAsync(s.seq, b->seq + s_lo, n_seq, hipMemcpyHostToDevice, im->s_copy));
+    }
+    HIP_TRY(hipStreamSynchronize(im->s_copy));                 // caller may reuse its arrays now
+    im->st.ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    im->st.algo_bytes_join += (int64_t)n * 20 + (int64_t)n_cig * 4 + (int64_t)(n_seq / 2);
+    d.pos = s.pos; d.flag = s.flag; d.mapq = s.mapq; d.cell = s.cell; d.umi = s.umi;
+    d.cig_off = s.cig_off; d.cigar = s.cigar - c_lo; d.seq_off = s.seq_off; d.seq = s.seq - s_lo;   // rebased, never read below *_lo
+    im->queue.push_back(d); im->queued_reads += b->n_reads;
+    return launch_queue(im, slot_idx);                         // the kernel overlaps the caller's next decode + copy
 }
 
 int engine_flush(xck_engine* e) {
     EngineImpl* im = (EngineImpl*)e->impl;
-    if (!im) return XCK_E_STATE;
+    if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     HIP_TRY(hipSetDevice(im->device));
+    int rc = launch_queue(im, -1); if (rc) return rc;
     return complete_pending(im);
 }
 
@@ -753,139 +1021,139 @@ struct Timer {
     int stop(double* acc) { HIP_TRY(hipEventRecord(b, im->s_comp)); HIP_TRY(hipEventSynchronize(b)); float ms; HIP_TRY(hipEventElapsedTime(&ms, a, b)); *acc += ms; im->st.ms_device += ms; return 0; }
 };
 
-template <class K>
-static int sort_keys(EngineImpl* im, K** keys, K** alt, size_t n, int lo0, int hi0, int lo1, int hi1,
-                     uint64_t** vals64 = nullptr, uint64_t** valt64 = nullptr, uint8_t** vals8 = nullptr, uint8_t** valt8 = nullptr) {
-    // One radix sort over key bits [lo0, hi1).  (rocPRIM's mid-size merge path is not stable, so the
-    // classic "sort low range, then high range" trick to skip the all-zero bits between the used UMI
-    // bits and the cell field is NOT safe with it - measured on gfx950, tools/scratch/sorttest.hip.)
-    (void)hi0; (void)lo1;
-    for (int pass = 0; pass < 1; pass++) {
-        int lo = lo0, hi = hi1;
-        if (hi <= lo) continue;
-        size_t tmp_bytes = 0; void* tmp = nullptr;
-        for (int phase = 0; phase < 2; phase++) {
-            hipError_t er;
-            if (vals64) er = rocprim::radix_sort_pairs(tmp, tmp_bytes, *keys, *alt, *vals64, *valt64, n, (unsigned)lo, (unsigned)hi, im->s_comp);
-            else if (vals8) er = rocprim::radix_sort_pairs(tmp, tmp_bytes, *keys, *alt, *vals8, *valt8, n, (unsigned)lo, (unsigned)hi, im->s_comp);
-            else er = rocprim::radix_sort_keys(tmp, tmp_bytes, *keys, *alt, n, (unsigned)lo, (unsigned)hi, im->s_comp);
-            HIP_TRY(er);
-            if (phase == 0) HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-        }
-        HIP_TRY(hipStreamSynchronize(im->s_comp));
-        HIP_TRY(hipFree(tmp));
-        std::swap(*keys, *alt);
-        if (vals64) std::swap(*vals64, *valt64);
-        if (vals8) std::swap(*vals8, *valt8);
-    }
+// One radix sort over key bits [0, top).  (rocPRIM's mid-size merge path is not stable, so the classic
+// "sort the low range, then the high range" trick to skip the all-zero bits between the used UMI bits and
+// the cell field is NOT safe with it - measured on gfx950, tools/scratch/sorttest.hip.)
+template <class K, class V>
+static size_t sort_tmp_bytes(size_t n, int top) {
+    size_t tb = 0; K* k = nullptr; V* v = nullptr;
+    if constexpr (std::is_same<V, rocprim::empty_type>::value) (void)rocprim::radix_sort_keys(nullptr, tb, k, k, n, 0u, (unsigned)top, (hipStream_t)0);
+    else (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, n, 0u, (unsigned)top, (hipStream_t)0);
+    return tb + 256;
+}
+template <class K, class V>
+static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout, V* vin, V* vout, size_t n, int top) {
+    hipError_t er;
+    if constexpr (std::is_same<V, rocprim::empty_type>::value) er = rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, 0u, (unsigned)top, im->s_comp);
+    else er = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, (unsigned)top, im->s_comp);
+    HIP_TRY(er);
     return 0;
 }
 
-static int used_bits(unsigned long long v) { int b = 0; while (v) { b++; v >>= 1; } return std::max(b, 1); }
-
+// ordered compaction of dense[i] > 0 into pinned host COO arrays of matrix m
 template <class K>
-static int compact_coo(EngineImpl* im, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, std::vector<int32_t> out[3]) {
+static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m) {
     size_t nb = (n + CP_TILE - 1) / CP_TILE;
-    uint32_t* d_blk = nullptr; unsigned long long* d_off = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_blk, nb * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&d_off, nb * sizeof(unsigned long long)));
+    uint32_t* d_blk = ws.get<uint32_t>(nb); unsigned long long* d_off = ws.get<unsigned long long>(nb);
+    if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (compaction)"; return XCK_E_NOMEM; }
     hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
-    hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, im->d_ctl + 3);
+    hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, im->d_ctl + CTL_SCRATCH);
     HIP_TRY(hipGetLastError());
-    unsigned long long total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, im->d_ctl + 3, sizeof total, hipMemcpyDeviceToHost, im->s_comp));
+    HIP_TRY(hipMemcpyAsync(im->h_ctl + CTL_SCRATCH, im->d_ctl + CTL_SCRATCH, sizeof(unsigned long long), hipMemcpyDeviceToHost, im->s_comp));
     HIP_TRY(hipStreamSynchronize(im->s_comp));
-    for (int j = 0; j < 3; j++) out[j].assign(total, 0);
-    if (total) {
-        int32_t* d_o = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_o, total * 3 * sizeof(int32_t)));
-        hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off,
-                           d_o, d_o + total, d_o + 2 * total);
-        HIP_TRY(hipGetLastError());
-        for (int j = 0; j < 3; j++) HIP_TRY(hipMemcpyAsync(out[j].data(), d_o + j * total, total * sizeof(int32_t), hipMemcpyDeviceToHost, im->s_comp));
-        HIP_TRY(hipStreamSynchronize(im->s_comp));
-        HIP_TRY(hipFree(d_o));
+    size_t total = im->h_ctl[CTL_SCRATCH];
+    im->res_nnz[m] = total;
+    if (!total) return 0;
+    int rc = res_reserve(im, m, total); if (rc) return rc;
+    int32_t* d_o = ws.get<int32_t>(total * 3);
+    if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
+    hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off,
+                       d_o, d_o + total, d_o + 2 * total);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(im->h_res[m], d_o, total * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, im->s_comp));
+    return 0;
+}
+
+// copy the used prefix of every shard slice into one contiguous array (sort input)
+template <class K>
+static int pack_shards(EngineImpl* im, K* dst_keys, uint64_t* dst_vals) {
+    size_t off = 0;
+    for (int sh = 0; sh < NSHARD; sh++) {
+        const size_t c = im->cur[sh];
+        if (!c) continue;
+        HIP_TRY(hipMemcpyAsync(dst_keys + off, (K*)im->d_keys + (size_t)sh * im->hit_cap, c * sizeof(K), hipMemcpyDeviceToDevice, im->s_comp));
+        if (dst_vals) HIP_TRY(hipMemcpyAsync(dst_vals + off, im->d_vals + (size_t)sh * im->hit_cap, c * sizeof(uint64_t), hipMemcpyDeviceToDevice, im->s_comp));
+        off += c;
     }
-    HIP_TRY(hipFree(d_blk)); HIP_TRY(hipFree(d_off));
     return 0;
 }
 
 template <class K>
 static int finish_t(EngineImpl* im) {
     KeyLayout<K> kl; kl.ubits = im->ubits; kl.cbits = im->cbits;
-    size_t n = im->cursor;
-    for (int m = 0; m < 4; m++) for (int j = 0; j < 3; j++) im->res[m][j].clear();
-    im->st.n_hits = (int64_t)n;
+    const size_t n = im->cursor;
+    for (int m = 0; m < 4; m++) im->res_nnz[m] = 0;
+    { int64_t acc = 0; for (int sh = 0; sh < NSHARD; sh++) acc += (int64_t)im->h_ctl[ctl_accepted(sh)];
+      im->st.n_hits = acc; }                          // accepted pairs (before the LDS de-duplication)
+    im->st.n_hits_unique = (int64_t)n;                // keys that reached HBM
     if (n == 0) return 0;
     if (n >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 hits in one finish() is not supported yet"; return XCK_E_CAPACITY; }
     Timer tm{im, im->ev0, im->ev1};
     int rc;
-    const int ub_used = std::min(used_bits(im->h_ctl[2]), im->ubits);
     const int top = im->ubits + im->cbits + im->rbits;
     const unsigned gs = (unsigned)((n + 255) / 256);
-    K* keys = (K*)im->d_keys; K* alt = nullptr;
-    HIP_TRY(hipMalloc((void**)&alt, n * sizeof(K)));
+    const size_t nb = (n + CP_TILE - 1) / CP_TILE;
+    K* keys = (K*)im->d_keys;
     if (im->mode == XCK_MODE_BASEFC) {
+        const size_t tmpb = sort_tmp_bytes<K, rocprim::empty_type>(n, top);
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 4 + tmpb + nb * 12 + n * 12 + (1 << 16)))) return rc;
+        K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb); int32_t* dense = im->ws1.get<int32_t>(n);
         if ((rc = tm.start())) return rc;
-        if ((rc = sort_keys<K>(im, &keys, &alt, n, 0, ub_used, im->ubits, top))) return rc;
-        int32_t* dense = nullptr;
-        HIP_TRY(hipMalloc((void**)&dense, n * sizeof(int32_t)));
+        if ((rc = pack_shards(im, alt, (uint64_t*)nullptr))) return rc;             // shard slices -> contiguous
+        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top))) return rc;
         hipLaunchKernelGGL((k_count_distinct<K>), dim3(gs), dim3(256), 0, im->s_comp, keys, (long long)n, kl, dense);
         HIP_TRY(hipGetLastError());
-        if ((rc = compact_coo<K>(im, dense, keys, n, kl, im->res[0]))) return rc;
+        if ((rc = compact_coo<K>(im, im->ws1, dense, keys, n, kl, 0))) return rc;
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
-        HIP_TRY(hipFree(dense));
     } else {
-        uint64_t* vals = im->d_vals; uint64_t* valt = nullptr;
-        HIP_TRY(hipMalloc((void**)&valt, n * sizeof(uint64_t)));
+        const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + (1 << 16)))) return rc;
+        K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
-        if ((rc = sort_keys<K>(im, &keys, &alt, n, 0, ub_used, im->ubits, top, &vals, &valt))) return rc;
-        uint8_t* al = nullptr;
-        HIP_TRY(hipMalloc((void**)&al, n));
+        if ((rc = pack_shards(im, alt, valt))) return rc;
+        if ((rc = sort_run<K, uint64_t>(im, tmp, tmpb, alt, keys, valt, im->d_vals, n, top))) return rc;
+        std::swap(alt, keys); { uint64_t* t_ = valt; valt = im->d_vals; (void)t_; }   // sorted data now lives in d_keys / d_vals
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
-        hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, keys, vals, (long long)n, kl, al, im->d_tally);
+        hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, im->d_tally);
         HIP_TRY(hipGetLastError());
-        // fan-out count
-        unsigned long long zero = 0, n2 = 0;
-        HIP_TRY(hipMemcpyAsync(im->d_ctl + 3, &zero, sizeof zero, hipMemcpyHostToDevice, im->s_comp));
-        hipLaunchKernelGGL((k_expand<K, false>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, keys, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (uint8_t*)nullptr, im->d_ctl + 3);
+        unsigned long long zero = 0;
+        HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_SCRATCH, 0, sizeof zero, im->s_comp));
+        hipLaunchKernelGGL((k_expand<K, false>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
+                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (uint8_t*)nullptr, im->d_ctl + CTL_SCRATCH);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&n2, im->d_ctl + 3, sizeof n2, hipMemcpyDeviceToHost, im->s_comp));
+        HIP_TRY(hipMemcpyAsync(im->h_ctl + CTL_SCRATCH, im->d_ctl + CTL_SCRATCH, sizeof zero, hipMemcpyDeviceToHost, im->s_comp));
         HIP_TRY(hipStreamSynchronize(im->s_comp));
-        im->st.n_hits_unique = (int64_t)n2;
+        const size_t n2 = im->h_ctl[CTL_SCRATCH];
         if (n2 >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 region hits"; return XCK_E_CAPACITY; }
         if (n2) {
-            K *k2 = nullptr, *k2b = nullptr; uint8_t *v2 = nullptr, *v2b = nullptr;
-            HIP_TRY(hipMalloc((void**)&k2, n2 * sizeof(K))); HIP_TRY(hipMalloc((void**)&k2b, n2 * sizeof(K)));
-            HIP_TRY(hipMalloc((void**)&v2, n2)); HIP_TRY(hipMalloc((void**)&v2b, n2));
-            HIP_TRY(hipMemcpyAsync(im->d_ctl + 3, &zero, sizeof zero, hipMemcpyHostToDevice, im->s_comp));
-            hipLaunchKernelGGL((k_expand<K, true>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, keys, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                               im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl + 3);
+            const size_t tmpb2 = sort_tmp_bytes<K, uint8_t>(n2, top);
+            const size_t nb2 = (n2 + CP_TILE - 1) / CP_TILE;
+            if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + (1 << 16)))) return rc;
+            K* k2 = im->ws2.get<K>(n2); K* k2b = im->ws2.get<K>(n2); uint8_t* v2 = im->ws2.get<uint8_t>(n2); uint8_t* v2b = im->ws2.get<uint8_t>(n2);
+            void* tmp2 = im->ws2.get<char>(tmpb2); int32_t* dense = im->ws2.get<int32_t>(3 * n2);
+            HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_SCRATCH, 0, sizeof zero, im->s_comp));
+            hipLaunchKernelGGL((k_expand<K, true>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
+                               im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl + CTL_SCRATCH);
             HIP_TRY(hipGetLastError());
-            if ((rc = sort_keys<K>(im, &k2, &k2b, n2, 0, ub_used, im->ubits, top, nullptr, nullptr, &v2, &v2b))) return rc;
-            int32_t* dense = nullptr;
-            HIP_TRY(hipMalloc((void**)&dense, n2 * 3 * sizeof(int32_t)));
+            if ((rc = sort_run<K, uint8_t>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
             const unsigned gs2 = (unsigned)((n2 + 255) / 256);
-            hipLaunchKernelGGL((k_hap_counts<K>), dim3(gs2), dim3(256), 0, im->s_comp, k2, v2, (long long)n2, kl, im->no_dup_hap,
+            hipLaunchKernelGGL((k_hap_counts<K>), dim3(gs2), dim3(256), 0, im->s_comp, k2b, v2b, (long long)n2, kl, im->no_dup_hap,
                                dense, dense + n2, dense + 2 * n2);
             HIP_TRY(hipGetLastError());
-            for (int m = 0; m < 3; m++) if ((rc = compact_coo<K>(im, dense + m * n2, k2, n2, kl, im->res[1 + m]))) return rc;
-            HIP_TRY(hipFree(dense)); HIP_TRY(hipFree(k2)); HIP_TRY(hipFree(k2b)); HIP_TRY(hipFree(v2)); HIP_TRY(hipFree(v2b));
+            for (int m = 0; m < 3; m++) if ((rc = compact_coo<K>(im, im->ws2, dense + m * n2, k2b, n2, kl, 1 + m))) return rc;
         }
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
-        HIP_TRY(hipFree(al));
-        im->d_vals = vals; HIP_TRY(hipFree(valt));
     }
-    im->d_keys = keys; HIP_TRY(hipFree(alt));
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
     return 0;
 }
 
 int engine_finish(xck_engine* e, xck_result* out) {
     EngineImpl* im = (EngineImpl*)e->impl;
-    if (!im) return XCK_E_STATE;
+    if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     HIP_TRY(hipSetDevice(im->device));
-    int rc = complete_pending(im); if (rc) return rc;
+    int rc = launch_queue(im, -1); if (rc) return rc;
+    rc = complete_pending(im); if (rc) return rc;
     if (!im->finished) {
         rc = im->key_bits == 64 ? finish_t<uint64_t>(im) : finish_t<u128>(im);
         if (rc) return rc;
@@ -894,24 +1162,27 @@ int engine_finish(xck_engine* e, xck_result* out) {
     memset(out, 0, sizeof *out);
     xck_coo* dst[4] = { &out->count, &out->ad, &out->dp, &out->oth };
     for (int m = 0; m < 4; m++) {
-        dst[m]->nnz = (int64_t)im->res[m][0].size();
-        dst[m]->row = im->res[m][0].data(); dst[m]->col = im->res[m][1].data(); dst[m]->val = im->res[m][2].data();
+        const size_t z = im->res_nnz[m];
+        dst[m]->nnz = (int64_t)z;
+        dst[m]->row = im->h_res[m]; dst[m]->col = im->h_res[m] ? im->h_res[m] + z : nullptr; dst[m]->val = im->h_res[m] ? im->h_res[m] + 2 * z : nullptr;
     }
-    if (im->mode == XCK_MODE_BASEFC) im->st.n_hits_unique = 0;
     return 0;
 }
 
 int engine_reset(xck_engine* e) {
     EngineImpl* im = (EngineImpl*)e->impl;
-    if (!im) return XCK_E_STATE;
+    if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     HIP_TRY(hipSetDevice(im->device));
-    int rc = complete_pending(im); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(im->d_ctl, 0, 4 * sizeof(unsigned long long), im->s_comp));
+    int rc = launch_queue(im, -1); if (rc) return rc;
+    rc = complete_pending(im); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long), im->s_comp));
     HIP_TRY(hipStreamSynchronize(im->s_comp));
-    im->cursor = 0; im->finished = false; im->h_ctl[0] = im->h_ctl[1] = im->h_ctl[2] = 0;
+    im->cursor = 0; im->finished = false;
+    for (int i = 0; i < CTL_WORDS; i++) im->h_ctl[i] = 0;
+    for (int sh = 0; sh < NSHARD; sh++) im->cur[sh] = 0;
     int kb = im->key_bits, ub = im->ubits;
     memset(&im->st, 0, sizeof im->st);
-    im->st.key_bits = kb; im->st.umi_bits = ub;
+    im->st.key_bits = kb; im->st.umi_bits = ub; im->n_join_launches = 0;
     return 0;
 }
 
@@ -919,6 +1190,7 @@ int engine_stats(const xck_engine* e, xck_stats* out) {
     const EngineImpl* im = (const EngineImpl*)e->impl;
     if (!im) return XCK_E_STATE;
     *out = im->st; out->key_bits = im->key_bits; out->umi_bits = im->ubits;
+    out->n_join_launches = im->n_join_launches;
     return 0;
 }
 
@@ -950,11 +1222,13 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     HIP_TRY(hipStreamCreateWithFlags(&im->s_copy, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&im->s_comp, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&im->ev0)); HIP_TRY(hipEventCreate(&im->ev1));
-    HIP_TRY(hipMalloc((void**)&im->d_ctl, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(im->d_ctl, 0, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc((void**)&im->h_ctl, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-    memset(im->h_ctl, 0, 4 * sizeof(unsigned long long));
-    rc = ensure_hits(im, (size_t)1 << 24); if (rc) return rc;
+    HIP_TRY(hipMalloc((void**)&im->d_ctl, CTL_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    memset(im->h_ctl, 0, CTL_WORDS * sizeof(unsigned long long));
+    HIP_TRY(hipMalloc((void**)&im->d_desc, MAX_FUSE * sizeof(BatchDesc)));
+    HIP_TRY(hipHostMalloc((void**)&im->h_desc, MAX_FUSE * sizeof(BatchDesc), hipHostMallocDefault));
+    rc = ensure_hits(im, (size_t)1 << 20); if (rc) return rc;
     return 0;
 }
 
@@ -963,11 +1237,14 @@ void engine_destroy(xck_engine* e) {
     if (!im) return;
     hipSetDevice(im->device);
     if (im->s_comp) hipStreamSynchronize(im->s_comp);
-    void* ptrs[] = { im->d_reg_s0, im->d_reg_e0, im->d_reg_row, im->d_win_off, im->d_win_list, im->d_snp_p0, im->d_snp_win,
-                     im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_ctl };
+    void* ptrs[] = { im->d_win_s0, im->d_win_e0, im->d_win_row, im->d_win_off, im->d_snp_p0, im->d_snp_win,
+                     im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_ctl, im->d_desc,
+                     im->ws1.base, im->ws2.base };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& s : im->slot) { void* q[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.cigar, s.seq_off, s.seq }; for (void* p : q) if (p) hipFree(p); }
+    for (int m = 0; m < 4; m++) if (im->h_res[m]) hipHostFree(im->h_res[m]);
     if (im->h_ctl) hipHostFree(im->h_ctl);
+    if (im->h_desc) hipHostFree(im->h_desc);
     if (im->ev0) hipEventDestroy(im->ev0);
     if (im->ev1) hipEventDestroy(im->ev1);
     if (im->s_copy) hipStreamDestroy(im->s_copy);

@@ -194,15 +194,16 @@ class Engine(object):
         finally:
             self.lib.xck_bam_close(b)
 
-    def finish(self):
+    def finish(self, copy=True):
         """-> {"count": (row, col, val)} or {"ad": .., "dp": .., "oth": ..}; rows are 0-based
-        region indices (input order), cols 0-based cell indices, sorted by (row, col)."""
+        region indices (input order), cols 0-based cell indices, sorted by (row, col).
+        copy=False returns views of the engine's pinned result buffers."""
         res = capi.Result()
         self._check(self.lib.xck_finish(self.h, C.byref(res)), "xck_finish")
         self._result = res
         if self.mode == XCK_MODE_BASEFC:
-            return {"count": res.count.to_numpy()}
-        return {"ad": res.ad.to_numpy(), "dp": res.dp.to_numpy(), "oth": res.oth.to_numpy()}
+            return {"count": res.count.to_numpy(copy)}
+        return {"ad": res.ad.to_numpy(copy), "dp": res.dp.to_numpy(copy), "oth": res.oth.to_numpy(copy)}
 
     def write_mtx(self, path, name, row_map, n_rows_out):
         """Write matrix `name` of the last finish() in the reference's exact text format."""
