@@ -37,6 +37,7 @@ extern "C" {
 /* counting modes */
 #define XCK_MODE_BASEFC   1   /* feature x cell counts        (xcltk basefc)        */
 #define XCK_MODE_BAF      2   /* feature x cell AD / DP / OTH (xcltk baf, step 3)   */
+#define XCK_MODE_BOTH     3   /* both from ONE decode of the BAM */
 
 /* UMI / read-name key code meaning "no usable key" (tag missing or empty string;
  * reference: check_read() -12, rdr/fc/mcount.py:41, baf/fc/mcount.py:116-117) */
@@ -65,7 +66,7 @@ typedef struct xck_snp {
  * path reads (rdr/fc/config.py:5-41, baf/fc/config.py:8-60). */
 typedef struct xck_config {
     uint32_t struct_size;       /* sizeof(xck_config), for ABI checking                      */
-    int32_t  mode;              /* XCK_MODE_*                                                */
+    int32_t  mode;              /* XCK_MODE_* (BOTH: every pushed batch feeds both pipelines) */
     int32_t  device;            /* HIP device ordinal                                        */
     /* read filter = check_read(), rdr/fc/core.py:46-62 == baf/fc/core.py:18-34 */
     double   min_mapq;          /* drop if mapq < min_mapq                                   */

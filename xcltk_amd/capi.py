@@ -12,6 +12,7 @@ import numpy as np
 
 XCK_MODE_BASEFC = 1
 XCK_MODE_BAF = 2
+XCK_MODE_BOTH = 3
 XCK_UMI_NONE = 0xFFFFFFFFFFFFFFFF
 XCK_F_FORCE_KEY128 = 1
 XCK_F_VERIFY_CRC = 2

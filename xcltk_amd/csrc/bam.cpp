@@ -177,14 +177,22 @@ struct HostSoA {
     size_t cap_reads = 0, cap_cig = 0, cap_seq = 0; bool pinned = false;
 };
 
+struct RecRef { const uint8_t* p; uint32_t len; int32_t tid; uint32_t l_seq; uint16_t n_cig; };
+
+// Records found by one inflate task in its own byte range, walked right after inflating (data
+// still hot in that core's cache) under the SPECULATION that a record starts at the first byte of
+// the range - true for BGZF writers that flush a block before a record that would not fit (htslib,
+// samtools, this repo's writers).  The serial stitch keeps a part only if the previous part ended
+// exactly at its start; otherwise that range is re-walked serially from the true offset.
+struct WalkPart { size_t u_begin = 0, u_end = 0, spec_start = 0, stop = 0; std::vector<RecRef> recs; };
+
 struct Chunk {
     std::vector<BlockRef> blocks;
     std::vector<uint8_t> ubuf; size_t usize = 0;
+    std::vector<WalkPart> parts;
     TaskGroup tg; std::atomic<bool> failed{false}; std::string err; std::mutex emu;
     bool valid = false;
 };
-
-struct RecRef { const uint8_t* p; uint32_t len; };
 
 struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
 
@@ -193,6 +201,7 @@ struct xck_bam {
     std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
     uint64_t next_coff = 0;            // next BGZF block to schedule
     uint32_t first_skip = 0;           // bytes of the first scheduled block that precede the first record
+    uint32_t stitch_skip = 0;          // same value, consumed by the first stitch
     bool eof_sched = false;
     Pool* pool = nullptr; int n_threads = 1;
     Chunk ch[2]; int cur = 0; bool primed = false;
@@ -325,10 +334,16 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc) {
     if (c.ubuf.size() < usz + 8) c.ubuf.resize(usz + 8);
     const size_t nb = c.blocks.size();
     const size_t per = std::max<size_t>(1, (nb + (size_t)b->n_threads * 4 - 1) / ((size_t)b->n_threads * 4));
-    for (size_t i0 = 0; i0 < nb; i0 += per) {
-        size_t i1 = std::min(nb, i0 + per);
-        Chunk* cp = &c; const uint8_t* map = b->map;
-        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc] {
+    const size_t n_parts = (nb + per - 1) / per;
+    c.parts.resize(n_parts);
+    const size_t skip0 = b->first_skip;            // bytes before the first record (first chunk of the file only)
+    for (size_t pi = 0; pi < n_parts; pi++) {
+        size_t i0 = pi * per, i1 = std::min(nb, i0 + per);
+        WalkPart& wp = c.parts[pi];
+        wp.u_begin = c.blocks[i0].uoff; wp.u_end = c.blocks[i1 - 1].uoff + c.blocks[i1 - 1].isize;
+        wp.spec_start = wp.u_begin + (pi == 0 ? skip0 : 0); wp.stop = wp.spec_start; wp.recs.clear();
+        Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp;
+        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp] {
             if (!t_zs.ok) { cp->failed = true; return; }
             for (size_t i = i0; i < i1; i++) {
                 std::string e;
@@ -336,6 +351,17 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc) {
                     std::lock_guard<std::mutex> lk(cp->emu); cp->failed = true; cp->err = e; return;
                 }
             }
+            // speculative record walk over this range
+            const uint8_t* u = cp->ubuf.data(); size_t o = wpp->spec_start; const size_t end = wpp->u_end;
+            if (o > end) { wpp->stop = o; return; }
+            while (o + 4 <= end) {
+                uint32_t bs = le32(u + o);
+                if (bs < 32 || o + 4 + (size_t)bs > end) break;
+                const uint8_t* r = u + o + 4;
+                wpp->recs.push_back({r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)});
+                o += 4 + (size_t)bs;
+            }
+            wpp->stop = o;
         });
     }
 }
@@ -413,7 +439,7 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
-    if (!b->primed) { schedule_chunk(b, b->ch[0], crc); b->cur = 0; b->primed = true; }
+    if (!b->primed) { schedule_chunk(b, b->ch[0], crc); b->stitch_skip = b->first_skip; b->first_skip = 0; b->cur = 0; b->primed = true; }
     Chunk& c = b->ch[b->cur];
     if (!c.valid && !c.failed) {
         if (!b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
@@ -424,10 +450,10 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     // start inflating the following chunk while this one is walked and parsed
     Chunk& nx = b->ch[b->cur ^ 1];
     schedule_chunk(b, nx, crc);
-    // ---- record walk (serial) ----
+    // ---- stitch the per-task record lists (serial, cheap); re-walk only where the speculation failed ----
     b->recs.clear(); b->rec_contig.clear();
     const uint8_t* u = c.ubuf.data(); size_t usz = c.usize; size_t off = 0;
-    if (b->first_skip) { off = b->first_skip; b->first_skip = 0; if (off > usz) { b->err = "corrupt BAM header offset"; return XCK_E_IO; } }
+    if (b->stitch_skip) { off = b->stitch_skip; b->stitch_skip = 0; if (off > usz) { b->err = "corrupt BAM header offset"; return XCK_E_IO; } }
     b->stitch.clear();
     if (!b->carry.empty()) {
         b->stitch = b->carry; b->carry.clear();
@@ -440,29 +466,43 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         } else { b->carry.swap(b->stitch); }
     }
     const int n_refs = (int)b->ref_names.size();
-    auto add_rec = [&](const uint8_t* p, uint32_t len) -> bool {
-        if (len < 32) return false;
-        int32_t tid = (int32_t)le32(p);
-        int32_t ctg = (tid >= 0 && tid < n_refs && o->tid_to_contig) ? o->tid_to_contig[tid] : -1;
-        b->recs.push_back({p, len}); b->rec_contig.push_back(ctg);
-        return true;
-    };
-    if (!b->stitch.empty()) { if (!add_rec(b->stitch.data() + 4, (uint32_t)b->stitch.size() - 4)) { b->err = "corrupt BAM record"; return XCK_E_IO; } }
-    while (off + 4 <= usz) {
-        uint32_t bs = le32(u + off);
-        if (off + 4 + (size_t)bs > usz) break;
-        if (!add_rec(u + off + 4, bs)) { b->err = "corrupt BAM record (block_size < 32)"; return XCK_E_IO; }
-        off += 4 + (size_t)bs;
+    auto contig_of = [&](int32_t tid) { return (tid >= 0 && tid < n_refs && o->tid_to_contig) ? o->tid_to_contig[tid] : -1; };
+    if (!b->stitch.empty()) {
+        if (b->stitch.size() < 36) { b->err = "corrupt BAM record"; return XCK_E_IO; }
+        const uint8_t* r = b->stitch.data() + 4;
+        b->recs.push_back({r, (uint32_t)b->stitch.size() - 4, (int32_t)le32(r), le32(r + 16), le16(r + 12)});
     }
+    { size_t pi = 0; bool incomplete = false;
+      while (!incomplete) {
+          while (pi < c.parts.size() && c.parts[pi].u_end <= off) pi++;
+          if (pi == c.parts.size()) break;
+          WalkPart& wp = c.parts[pi];
+          if (off == wp.spec_start) {                                   // speculation held: take the task's list
+              b->recs.insert(b->recs.end(), wp.recs.begin(), wp.recs.end());
+              off = wp.stop;
+              if (off == wp.u_end) { pi++; continue; }
+          }
+          while (off < wp.u_end) {                                      // serial walk (record straddles ranges / mis-speculation)
+              if (off + 4 > usz) { incomplete = true; break; }
+              uint32_t bs = le32(u + off);
+              if (off + 4 + (size_t)bs > usz) { incomplete = true; break; }
+              if (bs < 32) { b->err = "corrupt BAM record (block_size < 32)"; return XCK_E_IO; }
+              const uint8_t* r = u + off + 4;
+              b->recs.push_back({r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)});
+              off += 4 + (size_t)bs;
+          }
+          pi++;
+      } }
     if (off < usz) b->carry.insert(b->carry.end(), u + off, u + usz);
+    b->rec_contig.resize(b->recs.size());
+    for (size_t r = 0; r < b->recs.size(); r++) b->rec_contig[r] = contig_of(b->recs[r].tid);
     // ---- output layout: prefix sums + batch segmentation ----
     const int64_t nrec = (int64_t)b->recs.size();
     int64_t limit = nrec;
     if (o->max_records > 0 && b->n_records + nrec > o->max_records) { limit = std::max<int64_t>(0, o->max_records - b->n_records); }
     b->rec_out.assign(nrec, -1);
     size_t n_out = 0, n_cig = 0, n_seq = 0;
-    for (int64_t r = 0; r < limit; r++) if (b->rec_contig[r] >= 0) {
-        const uint8_t* p = b->recs[r].p; n_out++; n_cig += le16(p + 12); n_seq += (le32(p + 16) + 1) / 2; }
+    for (int64_t r = 0; r < limit; r++) if (b->rec_contig[r] >= 0) { n_out++; n_cig += b->recs[r].n_cig; n_seq += (b->recs[r].l_seq + 1) / 2; }
     if (n_cig >= (size_t(1) << 32) || n_seq >= (size_t(1) << 32)) { b->err = "chunk too large"; return XCK_E_IO; }
     if (!soa_reserve(b->soa, n_out + 1, n_cig + 1, e->dec.want_seq ? n_seq + 1 : 1)) { b->err = "out of host memory"; return XCK_E_NOMEM; }
     HostSoA& s = b->soa;
@@ -477,9 +517,8 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
               cur_c = ctg; seg0 = (int64_t)oi; seg_r = r;
           }
           if (ctg < 0) continue;
-          const uint8_t* p = b->recs[r].p;
           b->rec_out[r] = (int64_t)oi;
-          co += le16(p + 12); so += e->dec.want_seq ? (le32(p + 16) + 1) / 2 : 0; oi++;
+          co += b->recs[r].n_cig; so += e->dec.want_seq ? (b->recs[r].l_seq + 1) / 2 : 0; oi++;
           s.cig_off[oi] = co; s.seq_off[oi] = so;
       }
       if (cur_c >= 0 && (int64_t)oi > seg0) b->pending.push_back({cur_c, seg0, (int64_t)oi, ord_hi | (uint64_t)(b->n_records + seg_r)});
@@ -523,7 +562,7 @@ int xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t*
     xck_batch bt;
     int rc;
     while ((rc = xck_bam_next_batch(e, b, o, &bt)) == 1) {
-        int prc = engine_push(e, &bt, false);
+        int prc = xck_push_batch(e, &bt);                     // fused handles feed both pipelines
         if (prc) return prc;
     }
     if (n_records) *n_records = b->n_records;

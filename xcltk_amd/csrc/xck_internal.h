@@ -56,6 +56,7 @@ uint64_t hash_bytes(const char* s, size_t n);
 // 2-bit / interned key code, see include/xck.h xck_umi_bits()
 uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, bool* overflow);
 
+constexpr int XCK_F_LAYOUT_BOTH = 1 << 16;   // internal: size the row field for regions AND SNPs (fused handle)
 // key layout rule shared by engine and decoder: 64-bit keys (row | cell | umi) when the UMI code
 // gets >= 26 bits, otherwise 128-bit keys with a 64-bit UMI code.
 struct KeyBits { int key_bits, ubits, cbits, rbits; };
@@ -64,7 +65,7 @@ inline KeyBits key_layout(const xck_config* cfg) {
     KeyBits k;
     k.cbits = bits_for_count(cfg->n_cells > 2 ? cfg->n_cells : 2);
     k.rbits = bits_for_count(cfg->n_regions > 2 ? cfg->n_regions : 2);
-    if (cfg->mode == XCK_MODE_BAF) { int sb = bits_for_count(cfg->n_snps > 2 ? cfg->n_snps : 2); if (sb > k.rbits) k.rbits = sb; }
+    if ((cfg->mode & XCK_MODE_BAF) || (cfg->flags & XCK_F_LAYOUT_BOTH)) { int sb = bits_for_count(cfg->n_snps > 2 ? cfg->n_snps : 2); if (sb > k.rbits) k.rbits = sb; }
     int ub = 64 - k.rbits - k.cbits;
     if ((cfg->flags & XCK_F_FORCE_KEY128) || ub < 26) { k.key_bits = 128; k.ubits = 64; }
     else { k.key_bits = 64; k.ubits = ub; }
@@ -81,7 +82,10 @@ struct xck_engine {
     std::string err;
     xck::DecodeCfg dec;
     xck::InternTable intern;
-    void* impl = nullptr;                // xck::EngineImpl (engine.hip); null for decode-only handles
+    void* impl = nullptr;                // xck::EngineImpl being addressed (engine.hip); null for decode-only handles
+    void* impls[2] = {nullptr, nullptr}; // fused handle (XCK_MODE_BOTH): [0] basefc pipeline, [1] pileup pipeline
+    int n_impl = 0;
+    int mode = 0;
     int umi_bits = 64;
     // host pinned batch staging used by xck_ingest_bam lives in the xck_bam
 };

@@ -201,9 +201,12 @@ class Engine(object):
         res = capi.Result()
         self._check(self.lib.xck_finish(self.h, C.byref(res)), "xck_finish")
         self._result = res
-        if self.mode == XCK_MODE_BASEFC:
-            return {"count": res.count.to_numpy(copy)}
-        return {"ad": res.ad.to_numpy(copy), "dp": res.dp.to_numpy(copy), "oth": res.oth.to_numpy(copy)}
+        out = {}
+        if self.mode & XCK_MODE_BASEFC:
+            out["count"] = res.count.to_numpy(copy)
+        if self.mode & XCK_MODE_BAF:
+            out.update(ad=res.ad.to_numpy(copy), dp=res.dp.to_numpy(copy), oth=res.oth.to_numpy(copy))
+        return out
 
     def write_mtx(self, path, name, row_map, n_rows_out):
         """Write matrix `name` of the last finish() in the reference's exact text format."""
