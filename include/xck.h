@@ -190,13 +190,17 @@ void xck_bam_close(xck_bam* b);
 int  xck_bam_n_refs(const xck_bam* b);
 const char* xck_bam_ref_name(const xck_bam* b, int tid);
 int64_t     xck_bam_ref_len(const xck_bam* b, int tid);
+/* records per reference from the .bai next to the file (XCK_E_IO if there is no usable index);
+ * used to balance contigs over GPUs */
+int  xck_bam_ref_records(xck_bam* b, int tid, int64_t* n_mapped, int64_t* n_unmapped);
 
 typedef struct xck_ingest_opts {
     uint32_t struct_size;
     int32_t  sample;            /* index of this BAM in the BAM list (ordinal high bits; column
                                    index in well mode)                                       */
     const int32_t* tid_to_contig; /* [n_refs] engine contig id per BAM tid, -1 = not used    */
-    int32_t  use_index;         /* 1: seek with the .bai to the first/last wanted tid        */
+    int32_t  use_index;         /* 1: decode only the virtual-offset ranges of the wanted tids
+                                   (needs PATH.bai; silently decodes everything if absent)   */
     int64_t  max_records;       /* stop after this many records (0 = all)                    */
 } xck_ingest_opts;
 

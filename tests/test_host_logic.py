@@ -254,3 +254,33 @@ def test_gather_coo_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29617", str(script), ROOT],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("ds,mask", [("multibam", [True, False]), ("multibam", [False, True]), ("special", [False, True, False])])
+def test_indexed_contig_subset_decode(ds, mask):
+    """use_index + contig_mask (multi-GPU sharding) must yield exactly the records of the owned
+    contigs, in file order, with the same ordinals' relative order."""
+    import json
+    ddir = os.path.join(util.GOLDEN, "datasets", ds)
+    regions, snps = util.load_tables(ddir)
+    names = O.contig_table(regions, snps)
+    info = json.load(open(os.path.join(ddir, "dataset.json")))
+    samples = sorted(x.strip() for x in open(os.path.join(ddir, "barcodes.tsv")))
+    mask = (mask + [False] * len(names))[:len(names)]
+    eng = Engine(capi.XCK_MODE_BAF, names, regions, len(samples), snps=snps, barcodes=samples, cell_tag="CB", umi_tag="UB",
+                 decode_only=True, n_threads=2)
+    fn = os.path.join(ddir, info["bams"][0])
+    counts = eng.contig_record_counts(fn)
+    full = list(eng.decode_bam(fn))
+    sub = list(eng.decode_bam(fn, contig_mask=mask, use_index=True))
+    sub_noidx = list(eng.decode_bam(fn, contig_mask=mask, use_index=False))
+    eng.close()
+    assert counts is not None
+    want = [b for b in full if mask[b["contig"]]]
+    for got in (sub, sub_noidx):
+        assert [b["contig"] for b in got] == [b["contig"] for b in want]
+        for g, w in zip(got, want):
+            for k in ("pos", "flag", "mapq", "cell", "umi"):
+                assert np.array_equal(g[k], w[k]), k
+    assert sum(b["n_reads"] for b in full if b["contig"] >= 0) <= int(counts.sum())
+    assert sum(b["n_reads"] for b in want) == int(counts[np.array(mask)].sum())

@@ -115,17 +115,17 @@ def afc_core(conf):
     info("#regions: total=%d; with_snps=%d." % (len(regions), sum(has_snp)))
     eng = fcc.make_engine(conf, XCK_MODE_BAF, regions, snps)
     try:
-        fcc.stream_bams(eng, conf)
-        coo = eng.finish()
-        if conf.output_all_reg:
-            rm = fcc.row_map_all(len(regions))
-        else:          # only regions that wrote a DP or OTH line keep a row (baf/fc/core.py:101-113)
-            rm = fcc.row_map_from_rows(len(regions), coo["dp"][0], coo["oth"][0])
-        n_rows = int(rm.max()) if len(rm) else 0
-        fcc.write_region_tsv(conf.out_region_fn, regions, rm)
-        eng.write_mtx(conf.out_ad_fn, "ad", rm, n_rows)
-        eng.write_mtx(conf.out_dp_fn, "dp", rm, n_rows)
-        eng.write_mtx(conf.out_oth_fn, "oth", rm, n_rows)
+        coo, dist = fcc.count_all(eng, conf)
+        if coo is not None:                               # rank 0 (or the only process) writes
+            if conf.output_all_reg:
+                rm = fcc.row_map_all(len(regions))
+            else:      # only regions that wrote a DP or OTH line keep a row (baf/fc/core.py:101-113)
+                rm = fcc.row_map_from_rows(len(regions), coo["dp"][0], coo["oth"][0])
+            n_rows = int(rm.max()) if len(rm) else 0
+            fcc.write_region_tsv(conf.out_region_fn, regions, rm)
+            eng.write_mtx_arrays(conf.out_ad_fn, coo["ad"], rm, n_rows)
+            eng.write_mtx_arrays(conf.out_dp_fn, coo["dp"], rm, n_rows)
+            eng.write_mtx_arrays(conf.out_oth_fn, coo["oth"], rm, n_rows)
         if conf.debug > 0:
             info("engine stats: %s" % eng.stats())
     finally:

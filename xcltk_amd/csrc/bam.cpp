@@ -200,6 +200,11 @@ struct xck_bam {
     std::string path; int fd = -1; const uint8_t* map = nullptr; uint64_t fsize = 0;
     std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
     uint64_t next_coff = 0;            // next BGZF block to schedule
+    uint64_t stop_coff = ~0ull;        // last block (file offset) of the virtual-offset range being decoded
+    // .bai: per reference [beg, end) virtual offsets + record counts (samtools pseudo-bin 37450 or bin chunks)
+    bool idx_loaded = false, idx_ok = false;
+    std::vector<uint64_t> idx_beg, idx_end; std::vector<int64_t> idx_mapped, idx_unmapped;
+    std::vector<std::pair<uint64_t, uint64_t>> ranges; size_t range_i = 0; bool use_ranges = false, ranges_set = false;
     uint32_t first_skip = 0;           // bytes of the first scheduled block that precede the first record
     uint32_t stitch_skip = 0;          // same value, consumed by the first stitch
     bool eof_sched = false;
@@ -317,12 +322,71 @@ int64_t xck_bam_ref_len(const xck_bam* b, int tid) { return (b && tid >= 0 && ti
 
 }  // extern "C"
 
+// ---- .bai (SAMv1 section 5.2): only what contig sharding needs: where each reference starts / ends ----
+static void load_index(xck_bam* b) {
+    if (b->idx_loaded) return;
+    b->idx_loaded = true;
+    std::string cand[2] = { b->path + ".bai", b->path.size() > 4 ? b->path.substr(0, b->path.size() - 4) + ".bai" : std::string() };
+    std::vector<uint8_t> d;
+    for (auto& fn : cand) { if (fn.empty()) continue; FILE* fp = fopen(fn.c_str(), "rb"); if (!fp) continue;
+        fseek(fp, 0, SEEK_END); long n = ftell(fp); fseek(fp, 0, SEEK_SET); d.resize(n > 0 ? (size_t)n : 0);
+        size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), fp); fclose(fp); if (got == d.size() && got >= 8) break; d.clear(); }
+    if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return;
+    size_t o = 4; auto need = [&](size_t k) { return o + k <= d.size(); };
+    uint32_t n_ref = le32(d.data() + o); o += 4;
+    if (n_ref != b->ref_names.size()) return;
+    b->idx_beg.assign(n_ref, ~0ull); b->idx_end.assign(n_ref, 0); b->idx_mapped.assign(n_ref, 0); b->idx_unmapped.assign(n_ref, 0);
+    auto le64 = [&](size_t at) { return (uint64_t)le32(d.data() + at) | ((uint64_t)le32(d.data() + at + 4) << 32); };
+    for (uint32_t r = 0; r < n_ref; r++) {
+        if (!need(4)) return;
+        uint32_t n_bin = le32(d.data() + o); o += 4;
+        for (uint32_t k = 0; k < n_bin; k++) {
+            if (!need(8)) return;
+            uint32_t bin = le32(d.data() + o), n_chunk = le32(d.data() + o + 4); o += 8;
+            if (!need((size_t)n_chunk * 16)) return;
+            if (bin == 37450 && n_chunk == 2) { b->idx_mapped[r] = (int64_t)le64(o + 16); b->idx_unmapped[r] = (int64_t)le64(o + 24); }
+            else for (uint32_t c = 0; c < n_chunk; c++) { uint64_t cb = le64(o + c * 16), ce = le64(o + c * 16 + 8);
+                if (cb < b->idx_beg[r]) b->idx_beg[r] = cb; if (ce > b->idx_end[r]) b->idx_end[r] = ce; }
+            o += (size_t)n_chunk * 16;
+        }
+        if (!need(4)) return;
+        uint32_t n_intv = le32(d.data() + o); o += 4;
+        if (!need((size_t)n_intv * 8)) return;
+        o += (size_t)n_intv * 8;
+    }
+    b->idx_ok = true;
+}
+
+// restrict decoding to the references wanted by tid_to_contig (virtual-offset ranges from the index)
+static void set_ranges(xck_bam* b, const xck_ingest_opts* o) {
+    b->ranges_set = true; b->use_ranges = false;
+    if (!o->use_index || !o->tid_to_contig) return;
+    load_index(b);
+    if (!b->idx_ok) return;                                            // no usable index: decode everything
+    std::vector<std::pair<uint64_t, uint64_t>> rg;
+    for (size_t t = 0; t < b->ref_names.size(); t++)
+        if (o->tid_to_contig[t] >= 0 && b->idx_beg[t] != ~0ull && b->idx_end[t] > b->idx_beg[t]) rg.push_back({b->idx_beg[t], b->idx_end[t]});
+    std::sort(rg.begin(), rg.end());
+    for (auto& x : rg) { if (!b->ranges.empty() && (x.first >> 16) <= (b->ranges.back().second >> 16) + 1) b->ranges.back().second = std::max(b->ranges.back().second, x.second); else b->ranges.push_back(x); }
+    b->use_ranges = true; b->range_i = 0;
+}
+
+// position the chunk pipeline at the start of the next range; false when no range is left
+static bool begin_range(xck_bam* b) {
+    if (b->range_i >= b->ranges.size()) return false;
+    auto rg = b->ranges[b->range_i++];
+    b->next_coff = rg.first >> 16; b->first_skip = (uint32_t)(rg.first & 0xffff); b->stop_coff = rg.second >> 16;
+    b->eof_sched = false; b->primed = false; b->carry.clear();
+    return true;
+}
+
 // schedule the inflate of the next chunk into c (asynchronous)
 static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc) {
     c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear();
     if (b->eof_sched) return;
     uint64_t coff = b->next_coff; size_t usz = 0;
     while (usz < b->chunk_target) {
+        if (coff > b->stop_coff) { b->eof_sched = true; break; }          // end of the indexed range
         BlockRef br; std::string e;
         if (!bgzf_peek(b->map, b->fsize, coff, &br, &e)) { b->eof_sched = true; if (!e.empty()) { c.failed = true; c.err = e; } break; }
         br.uoff = usz; usz += br.isize; coff += br.clen;
@@ -439,9 +503,15 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
+    if (!b->ranges_set) { set_ranges(b, o); if (b->use_ranges && !begin_range(b)) return 0; }
     if (!b->primed) { schedule_chunk(b, b->ch[0], crc); b->stitch_skip = b->first_skip; b->first_skip = 0; b->cur = 0; b->primed = true; }
     Chunk& c = b->ch[b->cur];
     if (!c.valid && !c.failed) {
+        if (b->use_ranges) {                                           // this range is exhausted: move to the next one
+            b->ch[b->cur ^ 1].tg.wait();
+            if (!begin_range(b)) return 0;
+            return decode_next_chunk(e, b, o);
+        }
         if (!b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
         return 0;
     }
@@ -538,6 +608,15 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
 }
 
 extern "C" {
+
+int xck_bam_ref_records(xck_bam* b, int tid, int64_t* n_mapped, int64_t* n_unmapped) {
+    if (!b || tid < 0 || tid >= (int)b->ref_names.size()) return XCK_E_ARG;
+    load_index(b);
+    if (!b->idx_ok) return XCK_E_IO;
+    if (n_mapped) *n_mapped = b->idx_mapped[tid];
+    if (n_unmapped) *n_unmapped = b->idx_unmapped[tid];
+    return XCK_OK;
+}
 
 int xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) {
     if (!e || !b || !o || !out) return XCK_E_ARG;

@@ -147,31 +147,54 @@ class Engine(object):
         refs = [self.lib.xck_bam_ref_name(b, i).decode() for i in range(self.lib.xck_bam_n_refs(b))]
         return b, refs
 
-    def _opts(self, refs, sample, max_records=0):
+    def _opts(self, refs, sample, max_records=0, contig_mask=None, use_index=False):
         t2c = resolve_contigs(refs, self.contig_names)
+        if contig_mask is not None:                     # multi-GPU: this rank only owns some contigs
+            keep = np.asarray(contig_mask, dtype=bool)
+            t2c = np.where((t2c >= 0) & keep[np.maximum(t2c, 0)], t2c, -1).astype(np.int32)
         o = capi.IngestOpts()
         o.struct_size = C.sizeof(capi.IngestOpts)
         o.sample = sample
         o.tid_to_contig = t2c.ctypes.data_as(C.POINTER(C.c_int32))
         o.max_records = max_records
+        o.use_index = 1 if use_index else 0
         return o, t2c
 
-    def ingest_bam(self, path, sample=0, n_threads=0, max_records=0):
-        """Decode one BAM file and run the join kernels on every batch. Returns #records."""
+    def contig_record_counts(self, path):
+        """Records per engine contig from the BAM's .bai (None if there is no usable index)."""
+        b, refs = self._open(path, 1)
+        try:
+            t2c = resolve_contigs(refs, self.contig_names)
+            out = np.zeros(len(self.contig_names), dtype=np.int64)
+            m, u = C.c_int64(0), C.c_int64(0)
+            for tid, c in enumerate(t2c.tolist()):
+                if c < 0:
+                    continue
+                if self.lib.xck_bam_ref_records(b, tid, C.byref(m), C.byref(u)) != 0:
+                    return None
+                out[c] += m.value + u.value
+            return out
+        finally:
+            self.lib.xck_bam_close(b)
+
+    def ingest_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False):
+        """Decode one BAM file and run the join kernels on every batch. Returns #records decoded.
+        contig_mask (bool per engine contig) restricts the pass to the contigs this rank owns;
+        with use_index the .bai is used to inflate only their byte ranges."""
         b, refs = self._open(path, n_threads or self.cfg.n_threads)
         try:
-            o, keep = self._opts(refs, sample, max_records)
+            o, keep = self._opts(refs, sample, max_records, contig_mask, use_index)
             n = C.c_int64(0)
             self._check(self.lib.xck_ingest_bam(self.h, b, C.byref(o), C.byref(n)), "xck_ingest_bam")
             return int(n.value)
         finally:
             self.lib.xck_bam_close(b)
 
-    def decode_bam(self, path, sample=0, n_threads=0, max_records=0):
+    def decode_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False):
         """Pull-style decode (tests / inspection): yields dicts of numpy copies per batch."""
         b, refs = self._open(path, n_threads or self.cfg.n_threads)
         try:
-            o, keep = self._opts(refs, sample, max_records)
+            o, keep = self._opts(refs, sample, max_records, contig_mask, use_index)
             bt = capi.Batch()
             while True:
                 rc = self.lib.xck_bam_next_batch(self.h, b, C.byref(o), C.byref(bt))
@@ -215,6 +238,19 @@ class Engine(object):
         coo = getattr(self._result, name)
         rm = np.ascontiguousarray(row_map, dtype=np.int32)
         rc = self.lib.xck_write_mtx(path.encode(), C.byref(coo), rm.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    int(n_rows_out), self.n_cells)
+        if rc != 0:
+            raise XckError("xck_write_mtx failed (%d)" % rc)
+
+    def write_mtx_arrays(self, path, coo, row_map, n_rows_out):
+        """Same writer for (row, col, val) arrays that did not come from this engine's last
+        finish() - e.g. the blocks gathered from all ranks."""
+        row, col, val = (np.ascontiguousarray(a, dtype=np.int32) for a in coo)
+        c = capi.Coo()
+        c.nnz = len(row)
+        c.row, c.col, c.val = (capi.np_ptr(a, C.c_int32) for a in (row, col, val))
+        rm = np.ascontiguousarray(row_map, dtype=np.int32)
+        rc = self.lib.xck_write_mtx(path.encode(), C.byref(c), rm.ctypes.data_as(C.POINTER(C.c_int32)),
                                     int(n_rows_out), self.n_cells)
         if rc != 0:
             raise XckError("xck_write_mtx failed (%d)" % rc)

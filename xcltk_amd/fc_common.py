@@ -253,15 +253,76 @@ def make_engine(conf, mode, regions, snps=(), device=None, **extra):
                   cell_tag=conf.cell_tag, umi_tag=conf.umi_tag, device=device, **kw)
 
 
-def stream_bams(eng, conf, log_prefix="[engine]"):
+class Dist(object):
+    """Multi-GPU context (one process per GPU).  With WORLD_SIZE > 1 every
+    rank builds the full tables, streams only the contigs it owns (LPT on .bai record counts,
+    contig lengths as fallback) and the per-rank sparse blocks are concatenated on rank 0 by one
+    all-gatherv (RCCL over xGMI with the nccl backend; gloo when XCK_DIST_BACKEND=gloo)."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = None
+        self.device = "cpu"
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.backend = os.environ.get("XCK_DIST_BACKEND", "nccl")
+            if not dist.is_initialized():
+                if self.backend == "nccl":
+                    torch.cuda.set_device(self.local_rank)
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                else:
+                    dist.init_process_group(self.backend)
+            if self.backend == "nccl":
+                self.device = "cuda:%d" % self.local_rank
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def contig_mask(self, eng, conf):
+        """bool per engine contig: True where this rank owns the contig."""
+        from .shard import contig_owner
+        n = len(eng.contig_names)
+        weights = np.zeros(n, dtype=np.float64)
+        for fn in conf.sam_fn_list:
+            c = eng.contig_record_counts(fn)
+            if c is None:                           # no index: every contig weighs the same
+                weights[:] = 1.0
+                break
+            weights += c
+        return contig_owner(eng.contig_names, weights + 1e-9, self.world) == self.rank
+
+    def gather(self, coo):
+        from .shard import gather_coo
+        return {k: gather_coo(v, self.world, self.device) for k, v in coo.items()}
+
+
+def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None):
     """One streaming pass over every BAM, in list order (= the reference's fetch order)."""
     t0 = time.time()
     n_tot = 0
     for i, fn in enumerate(conf.sam_fn_list):
-        n = eng.ingest_bam(fn, sample=i)
+        n = eng.ingest_bam(fn, sample=i, contig_mask=contig_mask, use_index=contig_mask is not None)
         n_tot += n
         if conf.debug > 0:
             info("%s %s: %d records" % (log_prefix, fn, n))
     dt = max(time.time() - t0, 1e-9)
     info("%s %d BAM record(s) decoded and joined in %.2fs (%.0f reads/s)" % (log_prefix, n_tot, dt, n_tot / dt))
     return n_tot
+
+
+def count_all(eng, conf, log_prefix="[engine]"):
+    """Stream every BAM (this rank's contigs when running multi-GPU), fold, gather.
+    Returns (coo dict or None on non-zero ranks, Dist)."""
+    dist = Dist()
+    mask = dist.contig_mask(eng, conf) if dist.active else None
+    stream_bams(eng, conf, log_prefix, mask)
+    coo = eng.finish(copy=False)
+    if dist.active:
+        coo = dist.gather(coo)
+        if dist.rank != 0:
+            coo = None
+    return coo, dist

@@ -55,18 +55,19 @@ def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_lis
                  no_orphan=no_orphan, min_include=min_include, min_count=min_count, min_maf=min_maf,
                  no_dup_hap=no_dup_hap, n_threads=max(0, int(ncores)))
     try:
-        fcc.stream_bams(eng, conf, log_prefix="[fused]")
-        coo = eng.finish(copy=False)
+        coo, dist = fcc.count_all(eng, conf, log_prefix="[fused]")
+        if coo is None:
+            return 0
         n = len(regions)
         rm = fcc.row_map_all(n) if rdr_output_all_reg else fcc.row_map_from_rows(n, coo["count"][0])
         fcc.write_region_tsv(os.path.join(fc_dir, "features.tsv"), regions, rm)
-        eng.write_mtx(os.path.join(fc_dir, "matrix.mtx"), "count", rm, int(rm.max()) if n else 0)
+        eng.write_mtx_arrays(os.path.join(fc_dir, "matrix.mtx"), coo["count"], rm, int(rm.max()) if n else 0)
         rm = fcc.row_map_all(n) if baf_output_all_reg else fcc.row_map_from_rows(n, coo["dp"][0], coo["oth"][0])
         nr = int(rm.max()) if n else 0
         fcc.write_region_tsv(conf.out_region_fn, regions, rm)
-        eng.write_mtx(conf.out_ad_fn, "ad", rm, nr)
-        eng.write_mtx(conf.out_dp_fn, "dp", rm, nr)
-        eng.write_mtx(conf.out_oth_fn, "oth", rm, nr)
+        eng.write_mtx_arrays(conf.out_ad_fn, coo["ad"], rm, nr)
+        eng.write_mtx_arrays(conf.out_dp_fn, coo["dp"], rm, nr)
+        eng.write_mtx_arrays(conf.out_oth_fn, coo["oth"], rm, nr)
     finally:
         eng.close()
     info("fused basefc + baf done in %.2fs" % (time.time() - t0))

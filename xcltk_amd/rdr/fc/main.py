@@ -163,15 +163,14 @@ def fc_core(conf):
     regions = conf.reg_list
     eng = fcc.make_engine(conf, XCK_MODE_BASEFC, regions)
     try:
-        fcc.stream_bams(eng, conf)
-        coo = eng.finish()
-        rows = coo["count"][0]
-        if conf.output_all_reg:
-            rm = fcc.row_map_all(len(regions))            # row = input line number
-        else:
-            rm = fcc.row_map_from_rows(len(regions), rows)
-        fcc.write_region_tsv(conf.out_region_fn, regions, rm)
-        eng.write_mtx(conf.out_mtx_fn, "count", rm, int(rm.max()) if len(rm) else 0)
+        coo, dist = fcc.count_all(eng, conf)
+        if coo is not None:                               # rank 0 (or the only process) writes
+            if conf.output_all_reg:
+                rm = fcc.row_map_all(len(regions))        # row = input line number
+            else:
+                rm = fcc.row_map_from_rows(len(regions), coo["count"][0])
+            fcc.write_region_tsv(conf.out_region_fn, regions, rm)
+            eng.write_mtx_arrays(conf.out_mtx_fn, coo["count"], rm, int(rm.max()) if len(rm) else 0)
         if conf.debug > 0:
             info("engine stats: %s" % eng.stats())
     finally:
