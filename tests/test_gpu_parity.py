@@ -87,3 +87,25 @@ def test_frac_divide_matches_host():
         want = sum(1 for m, n in zip(mm, nn) if not lib.xo_frac_drop(int(m), int(n), v))
         assert int(exp["count"][2].sum()) == want
         util.assert_coo_equal(got, exp, ["count"])
+
+
+@pytest.fixture(scope="module")
+def large():
+    from xcltk_amd.synth import soa as _soa
+    regions, snps, names = _soa.make_tables(4000, 60000, _soa.HG38_LENGTHS[:4], seed=21, max_len=300000)
+    bs = _soa.gen_reads(regions, names, 3000000, 1500, seed=22, max_batch=700000)
+    return regions, snps, names, [util.batch_from_dict(b) for b in bs]
+
+
+@pytest.mark.parametrize("mode,mats", [(capi.XCK_MODE_BASEFC, ["count"]), (capi.XCK_MODE_BAF, ["ad", "dp", "oth"])])
+def test_large_scale_parity(large, mode, mats):
+    """3 M reads / thousands of tiles: catches races and tile-boundary bugs that tiny inputs cannot
+    (every LDS flush / spill path and the sharded cursors are exercised)."""
+    regions, snps, names, batches = large
+    got, exp, st = util.engine_vs_oracle(mode, names, regions, snps, 1500, batches)
+    assert st["n_hits"] > 100000
+    util.assert_coo_equal(got, exp, mats)
+    # determinism: a second run gives the identical result and the identical accepted-pair count
+    got2, _, st2 = util.engine_vs_oracle(mode, names, regions, snps, 1500, batches)
+    util.assert_coo_equal(got2, exp, mats)
+    assert st2["n_hits"] == st["n_hits"]

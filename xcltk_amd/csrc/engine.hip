@@ -66,6 +66,9 @@ struct ReadFilter {                      // check_read(), rdr/fc/core.py:46-62
     int32_t min_inc_len;
 };
 
+#define XCK_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ const XCK_GLOBAL T* as_global(const T* p) { return (const XCK_GLOBAL T*)p; }
+
 // One queued record batch (device pointers) inside a fused launch.
 struct BatchDesc {
     int32_t n, tile0;                       // reads, first tile of this batch in the fused grid
@@ -111,6 +114,12 @@ struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint
 // contiguous COO fragment: ONE atomicAdd on the global cursor per flush (a cursor word saturates
 // at ~88 returning atomics/us on gfx950 - one per 256 reads was the bottleneck of the first
 // version), wave ballot + mbcnt prefix compaction, coalesced 8/16-byte stores.
+#ifndef XCK_UNROLL_PROBE
+#define XCK_UNROLL_PROBE 1
+#endif
+#ifndef XCK_UNROLL_TILE
+#define XCK_UNROLL_TILE 1
+#endif
 #ifndef XCK_TILE_ITEMS
 #define XCK_TILE_ITEMS 4
 #endif
@@ -151,20 +160,29 @@ template <class K, int MODE> struct JoinSmem {
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t cig_at(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, uint32_t c) {
     uint32_t rel = c - sm.cg_lo;
-    return rel < sm.cg_n ? sm.cig[rel] : d.cigar[c];
+    return rel < sm.cg_n ? sm.cig[rel] : as_global(d.cigar)[c];
 }
 
-// filter + CIGAR summary of read i (endpos = htslib bam_endpos, n_al = len(read.positions))
+// the seven SoA fields of one read, fetched one sweep ahead of their use (software prefetch)
+struct RawRead { int32_t pos, cell; uint64_t umi; uint32_t c0, c1; uint32_t flag; int32_t mapq; bool valid; };
+__device__ __forceinline__ RawRead fetch_read(const BatchDesc& d, int i) {
+    RawRead w; w.valid = i < d.n; w.pos = 0; w.cell = -1; w.umi = 0; w.c0 = w.c1 = 0; w.flag = 0; w.mapq = 0;
+    if (w.valid) { w.flag = as_global(d.flag)[i]; w.mapq = as_global(d.mapq)[i]; w.cell = as_global(d.cell)[i]; w.umi = as_global(d.umi)[i];
+                   w.pos = as_global(d.pos)[i]; w.c0 = as_global(d.cig_off)[i]; w.c1 = as_global(d.cig_off)[i + 1]; }
+    return w;
+}
+
+// filter + CIGAR summary of a read (endpos = htslib bam_endpos, n_al = len(read.positions))
 template <class K, int MODE>
-__device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int i) {
+__device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const RawRead& w) {
     ReadInfo r; r.ok = false; r.pos = 0; r.endpos = 0; r.n_al = 0; r.c0 = r.c1 = 0; r.cell = -1; r.umi = 0;
-    if (i >= d.n) return r;
-    uint32_t flag = d.flag[i];
-    int32_t mapq = d.mapq[i];
-    r.cell = d.cell[i];
-    r.umi = d.umi[i];
-    r.pos = d.pos[i];
-    r.c0 = d.cig_off[i]; r.c1 = d.cig_off[i + 1];
+    if (!w.valid) return r;
+    uint32_t flag = w.flag;
+    int32_t mapq = w.mapq;
+    r.cell = w.cell;
+    r.umi = w.umi;
+    r.pos = w.pos;
+    r.c0 = w.c0; r.c1 = w.c1;
     bool ok = mapq >= a.f.min_mapq;
     ok = ok && !(a.f.excl_flag && (flag & a.f.excl_flag));
     ok = ok && !(a.f.incl_flag && !(flag & a.f.incl_flag));
@@ -210,9 +228,9 @@ __device__ __forceinline__ int allele_at(const JoinArgs<K>& a, const BatchDesc& 
         if (op_aligned(op)) {
             if (p0 >= rp && p0 < rp + l) {
                 int32_t qi = q + (p0 - rp);
-                uint32_t s0 = d.seq_off[i], s1 = d.seq_off[i + 1];
+                uint32_t s0 = as_global(d.seq_off)[i], s1 = as_global(d.seq_off)[i + 1];
                 if ((uint32_t)(qi >> 1) >= s1 - s0) return -1;
-                uint32_t by = d.seq[s0 + (qi >> 1)];
+                uint32_t by = as_global(d.seq)[s0 + (qi >> 1)];
                 return (qi & 1) ? int(by & 15u) : int(by >> 4);
             }
             rp += l; q += l;
@@ -237,6 +255,9 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
         unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
         const unsigned long long kk = (unsigned long long)key;
         uint32_t slot = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (HS_SLOTS - 1);
+#if !XCK_UNROLL_PROBE
+#pragma unroll 1
+#endif
         for (int probe = 0; probe < 24; probe++) {
             unsigned long long prev = atomicCAS(&set[slot], ~0ull, kk);
             if (prev == ~0ull) { atomicAdd(&sm.count, 1u); return; }
@@ -327,17 +348,18 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
         const bool staged = (uint32_t)(w - sm.w0) < (uint32_t)sm.nw;
         int32_t k0, k1;
         if (staged) { k0 = sm.st_w[w - sm.w0]; k1 = sm.st_w[w - sm.w0 + 1]; }
-        else { k0 = d.win_off[w]; k1 = d.win_off[w + 1]; }
+        else { k0 = as_global(d.win_off)[w]; k1 = as_global(d.win_off)[w + 1]; }
         for (int32_t k = k0; k < k1; k++) {
             int32_t s0, e0, row;
             if (staged) { s0 = sm.st_a[k]; e0 = sm.st_b[k]; row = sm.st_c[k]; }
-            else { s0 = a.win_s0[k]; e0 = a.win_e0[k]; row = a.win_row[k]; }
+            else { s0 = as_global(a.win_s0)[k]; e0 = as_global(a.win_e0)[k]; row = as_global(a.win_row)[k]; }
             if (w != max(w_lo, s0 >> WS)) continue;                 // report each (read, region) pair once
             if (!(r.pos < e0 && r.endpos > s0)) continue;           // htslib fetch overlap
             int32_t m = included_len(a, d, sm, r, s0, e0);
             if (a.f.frac_mode) {
                 if (r.n_al <= 0) continue;
-                if ((double)m / (double)r.n_al < a.f.min_inc_frac) continue;   // IEEE double, as m / float(n)
+                // m == n gives exactly 1.0, never below a threshold in (0,1): skip the fp64 divide
+                if (m != r.n_al && (double)m / (double)r.n_al < a.f.min_inc_frac) continue;   // IEEE double, as m / float(n)
             } else if (m < a.f.min_inc_len) continue;
             emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
             n_acc++;
@@ -351,8 +373,8 @@ __device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchD
     uint32_t n_acc = 0;
     int32_t w_lo = r.pos >> WS;
     if (w_lo >= d.n_swin) return 0;
-    int32_t k = d.snp_win[w_lo];
-    auto p0_of = [&](int32_t kk) { uint32_t d = (uint32_t)(kk - sm.k0); return d < (uint32_t)sm.nk ? sm.st_a[d] : a.snp_p0[kk]; };
+    int32_t k = as_global(d.snp_win)[w_lo];
+    auto p0_of = [&](int32_t kk) { uint32_t d = (uint32_t)(kk - sm.k0); return d < (uint32_t)sm.nk ? sm.st_a[d] : as_global(a.snp_p0)[kk]; };
     while (k < d.snp_end && p0_of(k) < r.pos) k++;
     for (; k < d.snp_end; k++) {
         int32_t p0 = p0_of(k);
@@ -383,8 +405,8 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     }
     // (2) tile extent: four scalars fetched by four lanes, then broadcast (each wave on its own: no barrier)
     uint32_t v4 = 0;
-    if (lane == 0) v4 = d.cig_off[tile0]; else if (lane == 1) v4 = d.cig_off[tile1];
-    else if (lane == 2) v4 = (uint32_t)max(d.pos[tile0], 0); else if (lane == 3) v4 = (uint32_t)max(d.pos[tile1 - 1], 0);
+    if (lane == 0) v4 = as_global(d.cig_off)[tile0]; else if (lane == 1) v4 = as_global(d.cig_off)[tile1];
+    else if (lane == 2) v4 = (uint32_t)max(as_global(d.pos)[tile0], 0); else if (lane == 3) v4 = (uint32_t)max(as_global(d.pos)[tile1 - 1], 0);
     const uint32_t c_lo = __shfl(v4, 0, 64), c_hi = __shfl(v4, 1, 64);
     const int32_t p_first = (int32_t)__shfl(v4, 2, 64), p_last = (int32_t)__shfl(v4, 3, 64);
     const uint32_t cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
@@ -394,8 +416,8 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         // (3) window offsets w0 .. w0+64 in one load per lane; keep the longest prefix whose entries fit
         if (w0 < d.n_win && p_last >= p_first) {
             const int32_t nw_max = min(min((p_last >> WS) + 1, d.n_win - 1) - w0 + 1, ST_WIN);
-            const int32_t off_l = d.win_off[min(w0 + lane, d.n_win)];
-            const int32_t off_last = d.win_off[min(w0 + ST_WIN, d.n_win)];
+            const int32_t off_l = as_global(d.win_off)[min(w0 + lane, d.n_win)];
+            const int32_t off_last = as_global(d.win_off)[min(w0 + ST_WIN, d.n_win)];
             e0 = __shfl(off_l, 0, 64);
             const unsigned long long fit = __ballot(lane >= 1 && lane <= nw_max && off_l - e0 <= ST_CAP);
             nw = __popcll(fit);                                   // monotone offsets -> prefix
@@ -403,36 +425,51 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             if (tid <= nw) sm.st_w[tid] = (tid < 64 ? off_l : off_last) - e0;
         }
     } else {
-        if (w0 < d.n_swin) { k0 = d.snp_win[w0]; nk = min(d.snp_end - k0, ST_CAP); }
+        if (w0 < d.n_swin) { k0 = as_global(d.snp_win)[w0]; nk = min(d.snp_end - k0, ST_CAP); }
     }
     if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; }
     // (4) CIGAR run + table entries, coalesced
-    for (uint32_t c = tid; c < cg_n; c += JOIN_BLOCK) sm.cig[c] = d.cigar[c_lo + c];
+    for (uint32_t c = tid; c < cg_n; c += JOIN_BLOCK) sm.cig[c] = as_global(d.cigar)[c_lo + c];
     if (MODE == XCK_MODE_BASEFC) {
         if (nw > 0) {
-            const int32_t n_ent = d.win_off[w0 + nw] - e0;
+            const int32_t n_ent = as_global(d.win_off)[w0 + nw] - e0;
             for (int32_t t = tid; t < n_ent; t += JOIN_BLOCK) {
-                sm.st_a[t] = a.win_s0[e0 + t]; sm.st_b[t] = a.win_e0[e0 + t]; sm.st_c[t] = a.win_row[e0 + t];
+                sm.st_a[t] = as_global(a.win_s0)[e0 + t]; sm.st_b[t] = as_global(a.win_e0)[e0 + t]; sm.st_c[t] = as_global(a.win_row)[e0 + t];
             }
         }
     } else {
-        for (int32_t t = tid; t < nk; t += JOIN_BLOCK) sm.st_a[t] = a.snp_p0[k0 + t];
+        for (int32_t t = tid; t < nk; t += JOIN_BLOCK) sm.st_a[t] = as_global(a.snp_p0)[k0 + t];
     }
     __syncthreads();
     // ---- 8 coalesced sweeps over the tile ----
     uint32_t acc = 0;
-    constexpr uint32_t FLUSH_AT = JoinSmem<K, MODE>::USE_SET ? HS_SLOTS / 2 : (uint32_t)JoinSmem<K, MODE>::QCAP / 2;
+    // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
+    constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? HS_SLOTS : JoinSmem<K, MODE>::QCAP;
+    constexpr int FLUSH_EVERY = (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2));
+    RawRead nxt = fetch_read(d, tile0 + tid);
+#if XCK_UNROLL_TILE
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
     for (int j = 0; j < TILE_ITEMS; j++) {
         const int i = tile0 + j * JOIN_BLOCK + tid;
-        ReadInfo r = load_read<K, MODE>(a, d, sm, i);
+        const RawRead cur = nxt;
+        if (j + 1 < TILE_ITEMS) nxt = fetch_read(d, i + JOIN_BLOCK);      // next sweep's loads fly during this sweep's work
+        ReadInfo r = load_read<K, MODE>(a, d, sm, cur);
         if (r.ok) {
             if (MODE == XCK_MODE_BASEFC) acc += join_regions<K, MODE>(a, d, sm, r);
             else acc += join_snps<K, MODE>(a, d, sm, r, i);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS only: keeps global loads in flight
-        if (sm.count > FLUSH_AT) flush<K, MODE>(a, sm);            // block-uniform
+        // Flush points are fixed at compile time, never decided from sm.count: a count-based decision read
+        // after the barrier races with the next sweep's inserts (threads could disagree and split at the
+        // barriers inside flush()).  A set / queue that saturates between two flush points spills through
+        // emit_global(), which is always correct.
+        if ((j + 1) % FLUSH_EVERY == 0 || j + 1 == TILE_ITEMS) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: global prefetches stay in flight
+            flush<K, MODE>(a, sm);
+        }
     }
-    flush<K, MODE>(a, sm);
     // accepted (read, region|SNP) pairs before the LDS de-duplication: the algorithmic unit of the join
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd, 64);
