@@ -69,6 +69,8 @@ def main():
                                                 device=device, contig_subset=shard if world > 1 else None)
     torch.cuda.synchronize()
     n_reads = arrays["n_reads"]
+    data_checksum = [int(arrays["pos"].to(torch.int64).sum().item()), int((arrays["umi"] & 0xFFFFFF).sum().item()),
+                     int(arrays["cell"].to(torch.int64).sum().item())]
     filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
     eng_fc = Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=local, min_include=0.9, **filt)
     eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=local,
@@ -172,28 +174,40 @@ def main():
         import oracle as O
         import util
         take, tot = [], 0
-        for c, s, e in batches:
+        for c, s, e in batches:                        # whole contigs only, so that their matrix rows are complete
             if tot >= args.cpu_sample:
                 break
-            e2 = min(e, s + args.cpu_sample - tot)
-            take.append((c, s, e2)); tot += e2 - s
+            take.append((c, s, e)); tot += e - s
         hb = [util.batch_from_dict(soa_torch.host_batch_dict(arrays, c, s, e, True)) for c, s, e in take]
         tc = 0.0
-        for mode, sn in ((capi.XCK_MODE_BASEFC, []), (capi.XCK_MODE_BAF, snps)):
+        sample_contigs = {names[c] for c, _, _ in take}
+        row_in_sample = np.array([r[0] in sample_contigs for r in regions])
+        parity = "ok"
+        n_cmp = 0
+        for mode, sn, mats in ((capi.XCK_MODE_BASEFC, [], ["count"]), (capi.XCK_MODE_BAF, snps, ["ad", "dp", "oth"])):
             cfg, keep = O.make_config(mode, names, regions, sn, args.cells)
             t1 = time.perf_counter()
-            O.run_oracle(cfg, [b for b, _ in hb])
+            exp = O.run_oracle(cfg, [b for b, _ in hb])
             tc += time.perf_counter() - t1
+            for m in mats:                              # the GPU result of the last timed step, restricted to those rows
+                g = res[m]
+                sel = row_in_sample[g[0]]
+                ok = all(np.array_equal(g[j][sel], exp[m][j]) for j in range(3))
+                n_cmp += int(sel.sum())
+                if not ok:
+                    parity = "MISMATCH in %s" % m
         cpu = dict(value=round(tot / tc, 1), unit="reads/s", cores=1, kind="port",
-                   sample="first %d reads (contig-ordered prefix) of the same workload, basefc + pileup, oracle/xck_oracle.c" % tot,
-                   seconds=round(tc, 2))
+                   sample="the %d reads of contig(s) %s of the same workload, basefc + pileup, oracle/xck_oracle.c" % (tot, ",".join(sorted(sample_contigs))),
+                   seconds=round(tc, 2), gpu_rows_vs_oracle="%s (%d non-zeros compared bit for bit)" % (parity, n_cmp))
+        if parity != "ok":
+            sys.exit("bench.py: GPU result differs from the oracle on the sampled contigs: " + parity)
 
     line = dict(metric="reads/sec into AD/DP+basefc matrices", value=round(value, 1), unit="reads/s",
                 n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3),
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64", data="synthetic",
                 config=dict(workload="BASELINE.json configs[1]: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
                                      "basefc + pileup per step, SoA resident in HBM" % (n_reads, args.cells, len(snps), len(regions)),
-                            reads_per_gpu=n_reads, parallelism="contig-shard x%d" % world,
+                            reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world,
                             nnz={kk: int(len(v[0])) for kk, v in res.items()},
                             hits=dict(basefc=int(hits_fc), pileup=int(hits_baf),
                                       basefc_after_lds_dedup=int(sfc["n_hits_unique"]))),

@@ -79,11 +79,24 @@ struct BatchDesc {
     const int32_t* win_off; int32_t n_win;                  // region window index of the batch's contig
     const int32_t* snp_win; int32_t n_swin; int32_t snp_end; // SNP window table of the batch's contig
 };
-constexpr int MAX_FUSE = 64;              // batches per fused launch
+constexpr int MAX_FUSE = 24;              // batches per fused launch (the table travels in the kernel arguments)
+
+// Batch table, passed BY VALUE: it lives in the kernarg segment and is read with scalar loads
+// through the constant cache instead of costing a dependent round trip to HBM per tile.
+struct BatchTable { int32_t n_batches; int32_t n_tiles; BatchDesc desc[MAX_FUSE]; };
+
+// Per-tile facts computed once by k_tile_meta (one thread per tile, all tiles in parallel) so that
+// the join kernel's prologue is ONE load of this record plus ONE round of independent staging loads.
+struct TileMeta {
+    uint32_t c_lo, cg_n;                  // CIGAR words of the tile: [c_lo, c_lo + cg_n) are staged
+    int32_t  w0, nw, e0, n_ent;           // basefc: staged windows [w0, w0+nw), their entries [e0, e0+n_ent)
+    int32_t  k0, nk;                      // pileup: staged SNPs [k0, k0+nk)
+    int32_t  b, r0, r1, pad;              // batch index, first / one-past-last read of the tile
+};
 
 template <class K> struct JoinArgs {
-    int32_t n_batches;
-    const BatchDesc* desc;                // [n_batches] in device memory
+    BatchTable bt;
+    const TileMeta* meta;                 // [n_tiles]
     ReadFilter f;
     const int32_t* win_s0; const int32_t* win_e0; const int32_t* win_row;   // region of every window-list entry
     const int32_t* snp_p0;
@@ -91,6 +104,8 @@ template <class K> struct JoinArgs {
     K* keys; uint64_t* vals; unsigned long long cap;   // cap = capacity of ONE shard
     unsigned long long* ctl;             // control block, see CTL_* below
 };
+
+static_assert(sizeof(JoinArgs<unsigned __int128>) <= 4000, "kernel arguments must stay under the 4 KiB kernarg limit");
 
 // The append cursor is sharded: a returning atomicAdd on one word tops out near 88 ops/us on gfx950
 // (one L2 channel), which bounded the first two versions of this kernel.  Tiles use shard
@@ -114,6 +129,9 @@ struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint
 // contiguous COO fragment: ONE atomicAdd on the global cursor per flush (a cursor word saturates
 // at ~88 returning atomics/us on gfx950 - one per 256 reads was the bottleneck of the first
 // version), wave ballot + mbcnt prefix compaction, coalesced 8/16-byte stores.
+#ifndef XCK_STAMPS
+#define XCK_STAMPS 0
+#endif
 #ifndef XCK_UNROLL_PROBE
 #define XCK_UNROLL_PROBE 1
 #endif
@@ -387,52 +405,62 @@ __device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchD
     return n_acc;
 }
 
+// one thread per tile: locate the batch, read the tile's extent, size the LDS staging
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= bt.n_tiles) return;
+    int lo = 0, hi = bt.n_batches - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (bt.desc[mid].tile0 <= t) lo = mid; else hi = mid - 1; }
+    const BatchDesc& d = bt.desc[lo];
+    TileMeta m;
+    m.b = lo; m.r0 = (t - d.tile0) * TILE; m.r1 = min(m.r0 + TILE, d.n); m.pad = 0;
+    const uint32_t c_lo = as_global(d.cig_off)[m.r0], c_hi = as_global(d.cig_off)[m.r1];
+    const int32_t p_first = max(as_global(d.pos)[m.r0], 0), p_last = max(as_global(d.pos)[m.r1 - 1], 0);
+    m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
+    m.w0 = p_first >> WS; m.nw = 0; m.e0 = 0; m.n_ent = 0; m.k0 = 0; m.nk = 0;
+    if (MODE == XCK_MODE_BASEFC) {
+        if (m.w0 < d.n_win && p_last >= p_first) {
+            int nw_max = min(min((p_last >> WS) + 1, d.n_win - 1) - m.w0 + 1, ST_WIN);
+            const int32_t e0 = as_global(d.win_off)[m.w0];
+            int a_ = 0, z_ = nw_max;                              // largest nw with entries <= ST_CAP (offsets are monotone)
+            while (a_ < z_) { int mid = (a_ + z_ + 1) >> 1; if (as_global(d.win_off)[m.w0 + mid] - e0 <= ST_CAP) a_ = mid; else z_ = mid - 1; }
+            m.nw = a_; m.e0 = e0; m.n_ent = as_global(d.win_off)[m.w0 + a_] - e0;
+        }
+    } else {
+        if (m.w0 < d.n_swin) { m.k0 = as_global(d.snp_win)[m.w0]; m.nk = min(d.snp_end - m.k0, ST_CAP); }
+    }
+    out[t] = m;
+}
+
 template <class K, int MODE>
 __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     __shared__ JoinSmem<K, MODE> sm;
     const int tid = threadIdx.x, lane = tid & 63;
-    // ---- prologue: every round trip to memory is done by many lanes at once (no serial chains) ----
-    // (1) which batch of the fused launch owns this tile: one gather of the tile0 column + ballot
-    int b;
-    { int t0 = lane < a.n_batches ? a.desc[lane].tile0 : 0x7fffffff;
-      b = __builtin_amdgcn_readfirstlane(__popcll(__ballot(t0 <= (int)blockIdx.x)) - 1); }
-    const BatchDesc d = a.desc[b];                                   // uniform index -> scalar loads
-    const int tile0 = ((int)blockIdx.x - d.tile0) * TILE;
-    const int tile1 = min(tile0 + TILE, d.n);
+#if XCK_STAMPS
+    long long t_s0 = clock64();
+#define STAMP(slot) do { long long t_ = clock64(); if (tid == 0) atomicAdd(&a.ctl[4 + (slot)], (unsigned long long)(t_ - t_s0)); t_s0 = t_; } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+    // ---- prologue: one record from k_tile_meta, then ONE round of independent loads ----
+    const XCK_GLOBAL TileMeta* mp = as_global(a.meta) + blockIdx.x;
+    const uint32_t c_lo = mp->c_lo, cg_n = mp->cg_n;
+    const int32_t w0 = mp->w0, nw = mp->nw, e0 = mp->e0, n_ent = mp->n_ent, k0 = mp->k0, nk = mp->nk;
+    const int b = __builtin_amdgcn_readfirstlane(mp->b);
+    const int tile0 = __builtin_amdgcn_readfirstlane(mp->r0);
+    const BatchDesc& d = a.bt.desc[b];                                // kernarg: scalar loads through the constant cache
+    STAMP(0);
+    RawRead nxt = fetch_read(d, tile0 + tid);                         // first sweep's loads overlap the staging
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
         for (int s = tid; s < HS_SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    // (2) tile extent: four scalars fetched by four lanes, then broadcast (each wave on its own: no barrier)
-    uint32_t v4 = 0;
-    if (lane == 0) v4 = as_global(d.cig_off)[tile0]; else if (lane == 1) v4 = as_global(d.cig_off)[tile1];
-    else if (lane == 2) v4 = (uint32_t)max(as_global(d.pos)[tile0], 0); else if (lane == 3) v4 = (uint32_t)max(as_global(d.pos)[tile1 - 1], 0);
-    const uint32_t c_lo = __shfl(v4, 0, 64), c_hi = __shfl(v4, 1, 64);
-    const int32_t p_first = (int32_t)__shfl(v4, 2, 64), p_last = (int32_t)__shfl(v4, 3, 64);
-    const uint32_t cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
-    const int32_t w0 = p_first >> WS;
-    int32_t nw = 0, e0 = 0, k0 = 0, nk = 0;
-    if (MODE == XCK_MODE_BASEFC) {
-        // (3) window offsets w0 .. w0+64 in one load per lane; keep the longest prefix whose entries fit
-        if (w0 < d.n_win && p_last >= p_first) {
-            const int32_t nw_max = min(min((p_last >> WS) + 1, d.n_win - 1) - w0 + 1, ST_WIN);
-            const int32_t off_l = as_global(d.win_off)[min(w0 + lane, d.n_win)];
-            const int32_t off_last = as_global(d.win_off)[min(w0 + ST_WIN, d.n_win)];
-            e0 = __shfl(off_l, 0, 64);
-            const unsigned long long fit = __ballot(lane >= 1 && lane <= nw_max && off_l - e0 <= ST_CAP);
-            nw = __popcll(fit);                                   // monotone offsets -> prefix
-            if (nw == ST_WIN - 1 && nw_max == ST_WIN && off_last - e0 <= ST_CAP) nw = ST_WIN;
-            if (tid <= nw) sm.st_w[tid] = (tid < 64 ? off_l : off_last) - e0;
-        }
-    } else {
-        if (w0 < d.n_swin) { k0 = as_global(d.snp_win)[w0]; nk = min(d.snp_end - k0, ST_CAP); }
-    }
     if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; }
-    // (4) CIGAR run + table entries, coalesced
     for (uint32_t c = tid; c < cg_n; c += JOIN_BLOCK) sm.cig[c] = as_global(d.cigar)[c_lo + c];
     if (MODE == XCK_MODE_BASEFC) {
         if (nw > 0) {
-            const int32_t n_ent = as_global(d.win_off)[w0 + nw] - e0;
+            for (int32_t t = tid; t <= nw; t += JOIN_BLOCK) sm.st_w[t] = as_global(d.win_off)[w0 + t] - e0;
             for (int32_t t = tid; t < n_ent; t += JOIN_BLOCK) {
                 sm.st_a[t] = as_global(a.win_s0)[e0 + t]; sm.st_b[t] = as_global(a.win_e0)[e0 + t]; sm.st_c[t] = as_global(a.win_row)[e0 + t];
             }
@@ -440,13 +468,14 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     } else {
         for (int32_t t = tid; t < nk; t += JOIN_BLOCK) sm.st_a[t] = as_global(a.snp_p0)[k0 + t];
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
     // ---- 8 coalesced sweeps over the tile ----
     uint32_t acc = 0;
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
     constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? HS_SLOTS : JoinSmem<K, MODE>::QCAP;
     constexpr int FLUSH_EVERY = (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2));
-    RawRead nxt = fetch_read(d, tile0 + tid);
 #if XCK_UNROLL_TILE
 #pragma unroll
 #else
@@ -466,8 +495,11 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         // barriers inside flush()).  A set / queue that saturates between two flush points spills through
         // emit_global(), which is always correct.
         if ((j + 1) % FLUSH_EVERY == 0 || j + 1 == TILE_ITEMS) {
+            STAMP(3);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: global prefetches stay in flight
+            STAMP(4);
             flush<K, MODE>(a, sm);
+            STAMP(5);
         }
     }
     // accepted (read, region|SNP) pairs before the LDS de-duplication: the algorithmic unit of the join
@@ -477,6 +509,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     __syncthreads();
     if (tid == 0) { acc = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
                     if (acc) atomicAdd(&a.ctl[ctl_accepted(blockIdx.x & (NSHARD - 1))], (unsigned long long)acc); }
+    STAMP(6);
 }
 
 // exclusive scan of one uint32 per thread over a 256-thread block; returns block total in `total`
@@ -734,7 +767,7 @@ struct EngineImpl {
     std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
     int inflight_slot = -1;
     int64_t queued_reads = 0, inflight_reads = 0;
-    BatchDesc* d_desc = nullptr; BatchDesc* h_desc = nullptr;
+    TileMeta* d_meta = nullptr; size_t meta_cap = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     xck_stats st{};
@@ -926,19 +959,32 @@ static int slot_reserve(EngineImpl* im, BatchSlot& s, size_t n_reads, size_t n_c
 template <class K>
 static int launch_join_t(EngineImpl* im) {
     const int nb = (int)im->inflight.size();
-    int32_t tiles = 0;
-    for (int i = 0; i < nb; i++) { im->inflight[i].tile0 = tiles; tiles += (im->inflight[i].n + TILE - 1) / TILE; im->h_desc[i] = im->inflight[i]; }
-    HIP_TRY(hipMemcpyAsync(im->d_desc, im->h_desc, nb * sizeof(BatchDesc), hipMemcpyHostToDevice, im->s_comp));
     JoinArgs<K> a;
-    a.n_batches = nb; a.desc = im->d_desc; a.f = im->rf;
+    int32_t tiles = 0;
+    for (int i = 0; i < nb; i++) { im->inflight[i].tile0 = tiles; tiles += (im->inflight[i].n + TILE - 1) / TILE; a.bt.desc[i] = im->inflight[i]; }
+    a.bt.n_batches = nb; a.bt.n_tiles = tiles;
+    if ((size_t)tiles > im->meta_cap) {
+        if (im->d_meta) HIP_TRY(hipFree(im->d_meta));
+        im->d_meta = nullptr; im->meta_cap = 0;
+        size_t c = (size_t)tiles + tiles / 2 + 1024;
+        HIP_TRY(hipMalloc((void**)&im->d_meta, c * sizeof(TileMeta)));
+        im->meta_cap = c;
+    }
+    a.meta = im->d_meta; a.f = im->rf;
     a.win_s0 = im->d_win_s0; a.win_e0 = im->d_win_e0; a.win_row = im->d_win_row;
     a.snp_p0 = im->d_snp_p0;
     a.kl.ubits = im->ubits; a.kl.cbits = im->cbits;
     a.keys = (K*)im->d_keys; a.vals = im->d_vals; a.cap = im->hit_cap; a.ctl = im->d_ctl;
     dim3 grid(tiles), block(JOIN_BLOCK);
     HIP_TRY(hipEventRecord(im->ev0, im->s_comp));
-    if (im->mode == XCK_MODE_BASEFC) hipLaunchKernelGGL((k_join<K, XCK_MODE_BASEFC>), grid, block, 0, im->s_comp, a);
-    else hipLaunchKernelGGL((k_join<K, XCK_MODE_BAF>), grid, block, 0, im->s_comp, a);
+    const dim3 mgrid((tiles + 255) / 256), mblock(256);
+    if (im->mode == XCK_MODE_BASEFC) {
+        hipLaunchKernelGGL((k_tile_meta<XCK_MODE_BASEFC>), mgrid, mblock, 0, im->s_comp, a.bt, im->d_meta);
+        hipLaunchKernelGGL((k_join<K, XCK_MODE_BASEFC>), grid, block, 0, im->s_comp, a);
+    } else {
+        hipLaunchKernelGGL((k_tile_meta<XCK_MODE_BAF>), mgrid, mblock, 0, im->s_comp, a.bt, im->d_meta);
+        hipLaunchKernelGGL((k_join<K, XCK_MODE_BAF>), grid, block, 0, im->s_comp, a);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(im->ev1, im->s_comp));
     HIP_TRY(hipMemcpyAsync(im->h_ctl, im->d_ctl, CTL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, im->s_comp));
@@ -1123,6 +1169,10 @@ static int finish_t(EngineImpl* im) {
     { int64_t acc = 0; for (int sh = 0; sh < NSHARD; sh++) acc += (int64_t)im->h_ctl[ctl_accepted(sh)];
       im->st.n_hits = acc; }                          // accepted pairs (before the LDS de-duplication)
     im->st.n_hits_unique = (int64_t)n;                // keys that reached HBM
+#if XCK_STAMPS
+    fprintf(stderr, "[stamps mode=%d] desc=%llu extent=%llu stage=%llu sweeps=%llu barrier=%llu flush=%llu tail=%llu (cycles summed over blocks)\n", im->mode,
+            im->h_ctl[4], im->h_ctl[5], im->h_ctl[6], im->h_ctl[7], im->h_ctl[8], im->h_ctl[9], im->h_ctl[10]);
+#endif
     if (n == 0) return 0;
     if (n >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 hits in one finish() is not supported yet"; return XCK_E_CAPACITY; }
     Timer tm{im, im->ev0, im->ev1};
@@ -1263,8 +1313,6 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     HIP_TRY(hipMemset(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc((void**)&im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     memset(im->h_ctl, 0, CTL_WORDS * sizeof(unsigned long long));
-    HIP_TRY(hipMalloc((void**)&im->d_desc, MAX_FUSE * sizeof(BatchDesc)));
-    HIP_TRY(hipHostMalloc((void**)&im->h_desc, MAX_FUSE * sizeof(BatchDesc), hipHostMallocDefault));
     rc = ensure_hits(im, (size_t)1 << 20); if (rc) return rc;
     return 0;
 }
@@ -1275,13 +1323,12 @@ void engine_destroy(xck_engine* e) {
     hipSetDevice(im->device);
     if (im->s_comp) hipStreamSynchronize(im->s_comp);
     void* ptrs[] = { im->d_win_s0, im->d_win_e0, im->d_win_row, im->d_win_off, im->d_snp_p0, im->d_snp_win,
-                     im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_ctl, im->d_desc,
+                     im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_ctl, im->d_meta,
                      im->ws1.base, im->ws2.base };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& s : im->slot) { void* q[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.cigar, s.seq_off, s.seq }; for (void* p : q) if (p) hipFree(p); }
     for (int m = 0; m < 4; m++) if (im->h_res[m]) hipHostFree(im->h_res[m]);
     if (im->h_ctl) hipHostFree(im->h_ctl);
-    if (im->h_desc) hipHostFree(im->h_desc);
     if (im->ev0) hipEventDestroy(im->ev0);
     if (im->ev1) hipEventDestroy(im->ev1);
     if (im->s_copy) hipStreamDestroy(im->s_copy);

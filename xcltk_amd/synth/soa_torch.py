@@ -151,11 +151,11 @@ def host_batch_dict(arrays, contig, s, e, with_seq):
         d[k] = arrays[k][s:e].cpu().numpy()
     d["flag"] = arrays["flag"][s:e].cpu().numpy().view(np.uint16)
     d["umi"] = arrays["umi"][s:e].cpu().numpy().view(np.uint64)
-    co = arrays["cig_off"][s:e + 1].cpu().numpy().astype(np.int64)
+    co = arrays["cig_off"][s:e + 1].cpu().numpy().view(np.uint32).astype(np.int64)
     d["cigar"] = arrays["cigar"][int(co[0]):int(co[-1])].cpu().numpy().view(np.uint32)
     d["cig_off"] = (co - co[0]).astype(np.uint32)
     if with_seq:
-        so = arrays["seq_off"][s:e + 1].cpu().numpy().astype(np.int64)
+        so = arrays["seq_off"][s:e + 1].cpu().numpy().view(np.uint32).astype(np.int64)   # offsets are uint32 bit patterns
         d["seq"] = arrays["seq"][int(so[0]):int(so[-1])].cpu().numpy()
         d["seq_off"] = (so - so[0]).astype(np.uint32)
     return d
