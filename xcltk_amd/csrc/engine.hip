@@ -29,7 +29,10 @@
 namespace xck {
 
 typedef unsigned __int128 u128;
-constexpr int WS = 13;                 // window shift of the interval index (8 KiB windows)
+#ifndef XCK_WS
+#define XCK_WS 15
+#endif
+constexpr int WS = XCK_WS;             // window shift of the interval index (2^WS bp windows)
 constexpr int JOIN_BLOCK = 256;
 
 #define HIP_TRY(expr)                                                                      \
@@ -160,8 +163,10 @@ constexpr int ST_WIN = 64;               // staged index windows
 
 template <class K, int MODE> struct JoinSmem {
     static constexpr bool USE_SET = (MODE == XCK_MODE_BASEFC) && sizeof(K) == 8;
-    static constexpr int  QCAP = HS_BYTES / (int)(sizeof(K) + (MODE == XCK_MODE_BAF ? 8 : 0));
-    alignas(16) unsigned char store[HS_BYTES];
+    // pileup emits ~0.1 hits per read: a small queue is enough and buys occupancy (LDS is the limiter)
+    static constexpr int  STORE_BYTES = MODE == XCK_MODE_BAF ? 6144 : HS_BYTES;
+    static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (MODE == XCK_MODE_BAF ? 8 : 0));
+    alignas(16) unsigned char store[STORE_BYTES];
     uint32_t cig[CG_CAP];
     int32_t  st_a[ST_CAP], st_b[ST_CAP], st_c[ST_CAP];
     int32_t  st_w[ST_WIN + 1];
@@ -278,7 +283,7 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
 #endif
         for (int probe = 0; probe < 24; probe++) {
             unsigned long long prev = atomicCAS(&set[slot], ~0ull, kk);
-            if (prev == ~0ull) { atomicAdd(&sm.count, 1u); return; }
+            if (prev == ~0ull) return;                               // new key (no shared counter: flush points are static)
             if (prev == kk) return;                                  // duplicate (same region, cell, UMI)
             slot = (slot + 1) & (HS_SLOTS - 1);
         }
@@ -391,7 +396,7 @@ __device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchD
     uint32_t n_acc = 0;
     int32_t w_lo = r.pos >> WS;
     if (w_lo >= d.n_swin) return 0;
-    int32_t k = as_global(d.snp_win)[w_lo];
+    int32_t k = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
     auto p0_of = [&](int32_t kk) { uint32_t d = (uint32_t)(kk - sm.k0); return d < (uint32_t)sm.nk ? sm.st_a[d] : as_global(a.snp_p0)[kk]; };
     while (k < d.snp_end && p0_of(k) < r.pos) k++;
     for (; k < d.snp_end; k++) {
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
             m.nw = a_; m.e0 = e0; m.n_ent = as_global(d.win_off)[m.w0 + a_] - e0;
         }
     } else {
-        if (m.w0 < d.n_swin) { m.k0 = as_global(d.snp_win)[m.w0]; m.nk = min(d.snp_end - m.k0, ST_CAP); }
+        if (m.w0 < d.n_swin) { m.k0 = as_global(d.snp_win)[m.w0]; m.nk = min(d.snp_end - m.k0, ST_CAP); m.nw = min(d.n_swin - m.w0, ST_WIN); }
     }
     out[t] = m;
 }
@@ -467,6 +472,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         }
     } else {
         for (int32_t t = tid; t < nk; t += JOIN_BLOCK) sm.st_a[t] = as_global(a.snp_p0)[k0 + t];
+        for (int32_t t = tid; t < nw; t += JOIN_BLOCK) sm.st_w[t] = as_global(d.snp_win)[w0 + t];     // first SNP of each window
     }
     STAMP(1);
     __syncthreads();
