@@ -74,7 +74,7 @@ def main():
     filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
     eng_fc = Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=local, min_include=0.9, **filt)
     eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=local,
-                     min_count=1, min_maf=0, no_dup_hap=True, **filt)
+                     min_count=1, min_maf=0, no_dup_hap=True, flags=0 if args.serial else capi.XCK_F_LOW_PRIORITY, **filt)
     b_fc = [soa_torch.device_batch(capi, arrays, c, s, e, False) for c, s, e in batches]
     b_baf = [soa_torch.device_batch(capi, arrays, c, s, e, True) for c, s, e in batches]
 

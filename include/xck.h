@@ -101,6 +101,8 @@ typedef struct xck_config {
 
 #define XCK_F_FORCE_KEY128   1  /* always use 128-bit sort keys (testing)                    */
 #define XCK_F_VERIFY_CRC     2  /* verify BGZF CRC32 while decoding                          */
+#define XCK_F_LOW_PRIORITY   8  /* run this engine's kernels on a low-priority HIP stream: lets a second
+                                   engine fill the GPU while the first one copies results out */
 #define XCK_F_DECODE_ONLY    4  /* handle drives the BAM decoder only: no GPU is touched, and
                                    xck_push_batch / xck_finish fail (used to run the host
                                    ingest on machines without a device; NOT a compute path)  */

@@ -17,6 +17,7 @@ XCK_UMI_NONE = 0xFFFFFFFFFFFFFFFF
 XCK_F_FORCE_KEY128 = 1
 XCK_F_VERIFY_CRC = 2
 XCK_F_DECODE_ONLY = 4
+XCK_F_LOW_PRIORITY = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libxck.so")

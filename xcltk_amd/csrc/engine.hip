@@ -1313,7 +1313,9 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     im->max_batch_reads = cfg->max_batch_reads > 0 ? cfg->max_batch_reads : (int64_t)1 << 21;
     int rc = build_tables(im, cfg); if (rc) return rc;
     HIP_TRY(hipStreamCreateWithFlags(&im->s_copy, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&im->s_comp, hipStreamNonBlocking));
+    { int lo = 0, hi = 0;                                   // numerically lowest value = highest priority
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_TRY(hipStreamCreateWithPriority(&im->s_comp, hipStreamNonBlocking, (cfg->flags & XCK_F_LOW_PRIORITY) ? lo : hi)); }
     HIP_TRY(hipEventCreate(&im->ev0)); HIP_TRY(hipEventCreate(&im->ev1));
     HIP_TRY(hipMalloc((void**)&im->d_ctl, CTL_WORDS * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long)));
