@@ -27,7 +27,7 @@ import torch
 
 from xcltk_amd import capi
 from xcltk_amd.engine import Engine
-from xcltk_amd.shard import gather_coo, lpt_assign
+from xcltk_amd.shard import gather_device_blocks, linear_partition
 from xcltk_amd.synth import soa, soa_torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
@@ -55,16 +55,25 @@ def main():
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback of the hot path)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # One rank per GPU (RCCL).  Test mode only: if fewer GPUs than ranks are visible (a 1-GPU box
+    # rehearsing the N>1 code path) the ranks share device 0 and the exchange runs over gloo.
+    shared_gpu = torch.cuda.device_count() < world
+    dev_idx = 0 if shared_gpu else local
+    torch.cuda.set_device(dev_idx)
+    device = torch.device("cuda", dev_idx)
+    gather_device = "cpu" if shared_gpu else device
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     # ---- tables (identical on every rank) and this rank's shard of contigs --------------------
     regions, snps, names = soa.make_tables(args.genes, args.snps, soa.HG38_LENGTHS, seed=2)
-    shard = lpt_assign(soa.HG38_LENGTHS, world)[rank]
+    # contiguous contig ranges per rank: rank-order concatenation of the blocks is already (row, col) order
+    shard = linear_partition(soa.HG38_LENGTHS, world)[rank]
     arrays, batches = soa_torch.gen_reads_device(regions, names, args.reads, args.cells, seed=100 + rank,
                                                 device=device, contig_subset=shard if world > 1 else None)
     torch.cuda.synchronize()
@@ -72,13 +81,11 @@ def main():
     data_checksum = [int(arrays["pos"].to(torch.int64).sum().item()), int((arrays["umi"] & 0xFFFFFF).sum().item()),
                      int(arrays["cell"].to(torch.int64).sum().item())]
     filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
-    eng_fc = Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=local, min_include=0.9, **filt)
-    eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=local,
-                     min_count=1, min_maf=0, no_dup_hap=True, flags=0 if args.serial else capi.XCK_F_LOW_PRIORITY, **filt)
+    eng_fc = Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=dev_idx, min_include=0.9, **filt)
+    eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=dev_idx,
+                     min_count=1, min_maf=0, no_dup_hap=True, **filt)
     b_fc = [soa_torch.device_batch(capi, arrays, c, s, e, False) for c, s, e in batches]
     b_baf = [soa_torch.device_batch(capi, arrays, c, s, e, True) for c, s, e in batches]
-
-    import threading
 
     def push_all(eng, bs):
         eng.reset()
@@ -87,27 +94,29 @@ def main():
         eng.flush()                                        # join kernel done (timed on its own stream)
 
     def step():
-        # basefc and pileup are independent engines (own streams, own accumulators).  The basefc join runs
-        # first and alone (so its HIP-event time is clean); then the pileup engine is driven from a second
-        # host thread so that its kernels overlap the basefc sort and, above all, the 170 MB copy-out of
-        # the basefc matrix over PCIe (ctypes drops the GIL during the C calls).
-        out, out2 = {}, {}
+        # basefc and pileup are independent engines (own streams, own accumulators).  The basefc fold ends
+        # with a 170 MB copy-out of the count matrix over PCIe: it is only ENQUEUED (xck_finish_async), the
+        # whole pileup pass then runs on the CUs while the copy engine drains it, and xck_finish collects it.
+        out = {}
         push_all(eng_fc, b_fc)
-
-        def baf():
-            push_all(eng_baf, b_baf)
-            out2.update(eng_baf.finish(copy=False))
         if args.serial:
             out.update(eng_fc.finish(copy=False))          # views of the pinned result buffers
-            baf()
+            push_all(eng_baf, b_baf)
+            out.update(eng_baf.finish(copy=False))
         else:
-            th = threading.Thread(target=baf)
-            th.start()
+            eng_fc.finish_async()
+            push_all(eng_baf, b_baf)
+            out.update(eng_baf.finish(copy=False))
             out.update(eng_fc.finish(copy=False))
-            th.join()
-        out.update(out2)
         if world > 1:
-            out = {k: gather_coo(v, world, device) for k, v in out.items()}   # RCCL all-gatherv
+            # all-gatherv of the per-contig sparse blocks to the writer rank, GPU to GPU over xGMI (RCCL):
+            # sizes first, then the padded [row|col|val] blocks that are still resident in HBM.  Every rank
+            # has also delivered its own row range to pinned host memory (out), in parallel over its own PCIe link.
+            dev_blocks = dict(eng_fc.result_device()); dev_blocks.update(eng_baf.result_device())
+            gathered = {}
+            for k in ("count", "ad", "dp", "oth"):
+                gathered[k] = gather_device_blocks(dev_blocks[k], world, rank, device, backend_is_nccl=not shared_gpu)
+            out["_gathered_sizes"] = {k: v[1] for k, v in gathered.items()}
         return out
 
     def sync():
@@ -119,16 +128,16 @@ def main():
     for _ in range(args.warmup):
         res = step()
     sync()
-    acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0)
+    acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0, ms_d2h_fc=0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
         sfc, sbaf = eng_fc.stats(), eng_baf.stats()     # HIP-event times of this step (reset() clears them)
-        acc["ms_join_fc"] += sfc["ms_join"]; acc["ms_fin_fc"] += sfc["ms_sort"]
+        acc["ms_join_fc"] += sfc["ms_join"]; acc["ms_fin_fc"] += sfc["ms_sort"]; acc["ms_d2h_fc"] += sfc["ms_d2h"]
         acc["ms_join_baf"] += sbaf["ms_join"]; acc["ms_fin_baf"] += sbaf["ms_sort"]
     sync()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device=gather_device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -208,7 +217,7 @@ def main():
                 config=dict(workload="BASELINE.json configs[1]: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
                                      "basefc + pileup per step, SoA resident in HBM" % (n_reads, args.cells, len(snps), len(regions)),
                             reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world,
-                            nnz={kk: int(len(v[0])) for kk, v in res.items()},
+                            nnz={kk: (int(sum(res["_gathered_sizes"][kk])) if world > 1 else int(len(v[0]))) for kk, v in res.items() if not kk.startswith("_")},
                             hits=dict(basefc=int(hits_fc), pileup=int(hits_baf),
                                       basefc_after_lds_dedup=int(sfc["n_hits_unique"]))),
                 roofline=roofline, cpu_baseline=cpu)

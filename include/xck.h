@@ -151,6 +151,7 @@ typedef struct xck_stats {
     double  ms_device;          /* HIP-event time of all kernels, cumulative                 */
     double  ms_join;            /* HIP-event time of the join/pileup kernels only            */
     double  ms_sort;            /* HIP-event time of sort + reduce kernels                   */
+    double  ms_d2h;             /* HIP-event time of the result copy-out (copy stream)       */
     int64_t algo_bytes_join;    /* algorithmic bytes of the join kernels         */
     int64_t n_join_launches;    /* fused join kernel launches (device-resident batches are fused) */
     int32_t key_bits;           /* 64 or 128                                                 */
@@ -180,8 +181,17 @@ int  xck_push_batch(xck_engine* e, const xck_batch* b);
  * that decode on the GPU side); no copy is made and they must stay valid until xck_flush(). */
 int  xck_push_batch_device(xck_engine* e, const xck_batch* b);
 int  xck_flush(xck_engine* e);                    /* wait for all queued device work */
-/* Fold all hits into the final sparse matrices (radix sort + segmented reduce on the GPU). */
+/* Fold all hits into the final sparse matrices (radix sort + segmented reduce on the GPU) and copy
+ * them to engine-owned pinned host memory. */
 int  xck_finish(xck_engine* e, xck_result* out);
+/* Same fold, but returns as soon as the copy-out of the matrices has been ENQUEUED on the engine's copy
+ * stream; a following xck_finish() waits for it and hands out the pointers.  Lets the caller run other
+ * GPU work (e.g. a second engine) while the matrix crosses PCIe. */
+int  xck_finish_async(xck_engine* e);
+/* Same matrices as the last xck_finish(), but the pointers are DEVICE addresses ([row|col|val] in the
+ * engine's workspace, valid until the next xck_finish / xck_reset): lets a multi-GPU driver exchange the
+ * per-contig sparse blocks GPU-to-GPU (RCCL over xGMI) without a host round trip. */
+int  xck_get_result_device(xck_engine* e, xck_result* out);
 /* Forget all pushed reads, keep tables and buffers (lets one engine be re-used per step). */
 int  xck_reset(xck_engine* e);
 int  xck_get_stats(const xck_engine* e, xck_stats* out);

@@ -88,7 +88,7 @@ class Result(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_batches", C.c_int64), ("n_reads", C.c_int64), ("n_hits", C.c_int64),
                 ("n_hits_unique", C.c_int64), ("ms_h2d", C.c_double), ("ms_device", C.c_double),
-                ("ms_join", C.c_double), ("ms_sort", C.c_double),
+                ("ms_join", C.c_double), ("ms_sort", C.c_double), ("ms_d2h", C.c_double),
                 ("algo_bytes_join", C.c_int64), ("n_join_launches", C.c_int64), ("key_bits", C.c_int32), ("umi_bits", C.c_int32)]
 
 
@@ -112,6 +112,8 @@ SYMBOLS = [
     ("xck_push_batch_device", C.c_int, [C.c_void_p, _P(Batch)]),
     ("xck_flush", C.c_int, [C.c_void_p]),
     ("xck_finish", C.c_int, [C.c_void_p, _P(Result)]),
+    ("xck_finish_async", C.c_int, [C.c_void_p]),
+    ("xck_get_result_device", C.c_int, [C.c_void_p, _P(Result)]),
     ("xck_reset", C.c_int, [C.c_void_p]),
     ("xck_get_stats", C.c_int, [C.c_void_p, _P(Stats)]),
     ("xck_bam_open", C.c_int, [C.c_char_p, C.c_int, _P(C.c_void_p), C.c_char_p, C.c_size_t]),

@@ -75,6 +75,8 @@ int xck_push_batch_device(xck_engine* e, const xck_batch* b) { if (!e || !b) ret
 int xck_flush(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_flush(e)); return XCK_OK; }
 int xck_reset(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_reset(e)); return XCK_OK; }
 
+int xck_finish_async(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_finish_async(e)); return XCK_OK; }
+
 int xck_finish(xck_engine* e, xck_result* out) {
     if (!e || !out) return XCK_E_ARG;
     memset(out, 0, sizeof *out);
@@ -83,6 +85,22 @@ int xck_finish(xck_engine* e, xck_result* out) {
         xck_result r;
         e->impl = e->impls[k];
         int rc = engine_finish(e, &r);
+        if (rc) { e->impl = e->impls[0]; return rc; }
+        if (e->mode == XCK_MODE_BOTH) { if (k == 0) out->count = r.count; else { out->ad = r.ad; out->dp = r.dp; out->oth = r.oth; } }
+        else *out = r;
+    }
+    e->impl = e->impls[0];
+    return XCK_OK;
+}
+
+int xck_get_result_device(xck_engine* e, xck_result* out) {
+    if (!e || !out) return XCK_E_ARG;
+    memset(out, 0, sizeof *out);
+    if (e->n_impl == 0) { e->impl = nullptr; return engine_result_device(e, out); }
+    for (int k = 0; k < e->n_impl; k++) {
+        xck_result r;
+        e->impl = e->impls[k];
+        int rc = engine_result_device(e, &r);
         if (rc) { e->impl = e->impls[0]; return rc; }
         if (e->mode == XCK_MODE_BOTH) { if (k == 0) out->count = r.count; else { out->ad = r.ad; out->dp = r.dp; out->oth = r.oth; } }
         else *out = r;
@@ -102,7 +120,7 @@ int xck_get_stats(const xck_engine* ce, xck_stats* out) {
         if (rc) { e->impl = e->impls[0]; return rc; }
         if (k == 0) *out = s;
         else { out->n_hits += s.n_hits; out->n_hits_unique += s.n_hits_unique; out->ms_h2d += s.ms_h2d; out->ms_device += s.ms_device;
-               out->ms_join += s.ms_join; out->ms_sort += s.ms_sort; out->algo_bytes_join += s.algo_bytes_join; out->n_join_launches += s.n_join_launches; }
+               out->ms_join += s.ms_join; out->ms_sort += s.ms_sort; out->ms_d2h += s.ms_d2h; out->algo_bytes_join += s.algo_bytes_join; out->n_join_launches += s.n_join_launches; }
     }
     e->impl = e->impls[0];
     return XCK_OK;

@@ -658,6 +658,16 @@ __global__ void k_hap_counts(const K* __restrict__ k, const uint8_t* __restrict_
     ad[i] = alt > 0 ? alt : 0; dp[i] = d > 0 ? d : 0; oth[i] = ot > 0 ? ot : 0;
 }
 
+// Control words go to the host through MAPPED pinned memory written by a tiny kernel, never through the
+// DMA engines: a 4 KB hipMemcpy D2H would queue behind a 170 MB result copy-out of another engine.
+__global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ host_alias, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) host_alias[i] = src[i];
+}
+
+__global__ void k_copy_words(const int32_t* __restrict__ src, int32_t* __restrict__ host_alias, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) host_alias[i] = src[i];
+}
+
 // ordered compaction of the non-zero entries of a dense int32 array into COO --------------------
 constexpr int CP_BLOCK = 256, CP_ITEMS = 8, CP_TILE = CP_BLOCK * CP_ITEMS;
 
@@ -764,7 +774,8 @@ struct EngineImpl {
     // hit accumulators (ping-pong pair so that sort results can stay where they land)
     void* d_keys = nullptr; uint64_t* d_vals = nullptr; size_t hit_cap = 0;
     unsigned long long* d_ctl = nullptr;       // CTL_WORDS control words (overflow flag, scratch, sharded cursors)
-    unsigned long long* h_ctl = nullptr;       // pinned mirror
+    unsigned long long* h_ctl = nullptr;       // pinned + mapped mirror
+    unsigned long long* d_hctl = nullptr;      // device alias of h_ctl (written by k_publish)
     unsigned long long cur[NSHARD] = {0};      // host view of the shard cursors after the last completed launch
     unsigned long long cur_before[NSHARD] = {0}, acc_before[NSHARD] = {0};
     unsigned long long cursor = 0;             // sum of cur[]; hit_cap is the capacity of ONE shard
@@ -775,12 +786,14 @@ struct EngineImpl {
     int64_t queued_reads = 0, inflight_reads = 0;
     TileMeta* d_meta = nullptr; size_t meta_cap = 0;
     // timing
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_res = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    bool copy_timed = false, copy_pending = false;
     xck_stats st{};
     int64_t n_join_launches = 0;
     // workspace + results
     Arena ws1, ws2;
     int32_t* h_res[4] = {nullptr, nullptr, nullptr, nullptr}; size_t h_res_cap[4] = {0, 0, 0, 0}; size_t res_nnz[4] = {0, 0, 0, 0};
+    int32_t* d_res[4] = {nullptr, nullptr, nullptr, nullptr};   // device copies [row | col | val] inside the workspace, valid until the next finish / reset
     bool finished = false;
 };
 
@@ -923,7 +936,7 @@ static int res_reserve(EngineImpl* im, int m, size_t nnz) {
         if (im->h_res[m]) HIP_TRY(hipHostFree(im->h_res[m]));
         im->h_res[m] = nullptr; im->h_res_cap[m] = 0;
         size_t c = nnz * 3 + nnz / 2 + 1024;
-        HIP_TRY(hipHostMalloc((void**)&im->h_res[m], c * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&im->h_res[m], c * sizeof(int32_t), hipHostMallocMapped));
         im->h_res_cap[m] = c;
     }
     return 0;
@@ -993,7 +1006,8 @@ static int launch_join_t(EngineImpl* im) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(im->ev1, im->s_comp));
-    HIP_TRY(hipMemcpyAsync(im->h_ctl, im->d_ctl, CTL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, im->s_comp));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, im->s_comp, (const unsigned long long*)im->d_ctl, im->d_hctl, CTL_WORDS);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 static int launch_join(EngineImpl* im) { return im->key_bits == 64 ? launch_join_t<uint64_t>(im) : launch_join_t<u128>(im); }
@@ -1138,10 +1152,11 @@ static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K*
     hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
     hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, im->d_ctl + CTL_SCRATCH);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(im->h_ctl + CTL_SCRATCH, im->d_ctl + CTL_SCRATCH, sizeof(unsigned long long), hipMemcpyDeviceToHost, im->s_comp));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->d_hctl + CTL_SCRATCH, 1);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     size_t total = im->h_ctl[CTL_SCRATCH];
-    im->res_nnz[m] = total;
+    im->res_nnz[m] = total; im->d_res[m] = nullptr;
     if (!total) return 0;
     int rc = res_reserve(im, m, total); if (rc) return rc;
     int32_t* d_o = ws.get<int32_t>(total * 3);
@@ -1149,7 +1164,22 @@ static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K*
     hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off,
                        d_o, d_o + total, d_o + 2 * total);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(im->h_res[m], d_o, total * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, im->s_comp));
+    im->d_res[m] = d_o;
+    // copy-out on the copy stream, ordered behind the scatter: the compute stream (and other engines) keep
+    // the CUs busy while the matrix crosses PCIe; xck_finish() waits for it, xck_finish_async() does not
+    if (total * 3 * sizeof(int32_t) >= (size_t(8) << 20)) {
+        HIP_TRY(hipEventRecord(im->ev_res, im->s_comp));
+        HIP_TRY(hipStreamWaitEvent(im->s_copy, im->ev_res, 0));
+        if (!im->copy_timed) { HIP_TRY(hipEventRecord(im->ev_c0, im->s_copy)); im->copy_timed = true; }
+        HIP_TRY(hipMemcpyAsync(im->h_res[m], d_o, total * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, im->s_copy));
+        HIP_TRY(hipEventRecord(im->ev_c1, im->s_copy));
+    } else {                                                  // small matrix: CUs store it straight into mapped pinned memory
+        int32_t* alias = nullptr;                             // (no DMA queue shared with another engine's bulk copy)
+        HIP_TRY(hipHostGetDevicePointer((void**)&alias, im->h_res[m], 0));
+        const unsigned g = (unsigned)std::min<size_t>((total * 3 + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_copy_words, dim3(g), dim3(256), 0, im->s_comp, (const int32_t*)d_o, alias, total * 3);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1171,7 +1201,7 @@ template <class K>
 static int finish_t(EngineImpl* im) {
     KeyLayout<K> kl; kl.ubits = im->ubits; kl.cbits = im->cbits;
     const size_t n = im->cursor;
-    for (int m = 0; m < 4; m++) im->res_nnz[m] = 0;
+    for (int m = 0; m < 4; m++) { im->res_nnz[m] = 0; im->d_res[m] = nullptr; }
     { int64_t acc = 0; for (int sh = 0; sh < NSHARD; sh++) acc += (int64_t)im->h_ctl[ctl_accepted(sh)];
       im->st.n_hits = acc; }                          // accepted pairs (before the LDS de-duplication)
     im->st.n_hits_unique = (int64_t)n;                // keys that reached HBM
@@ -1214,7 +1244,8 @@ static int finish_t(EngineImpl* im) {
         hipLaunchKernelGGL((k_expand<K, false>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
                            im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (uint8_t*)nullptr, im->d_ctl + CTL_SCRATCH);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(im->h_ctl + CTL_SCRATCH, im->d_ctl + CTL_SCRATCH, sizeof zero, hipMemcpyDeviceToHost, im->s_comp));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->d_hctl + CTL_SCRATCH, 1);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(im->s_comp));
         const size_t n2 = im->h_ctl[CTL_SCRATCH];
         if (n2 >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 region hits"; return XCK_E_CAPACITY; }
@@ -1241,16 +1272,30 @@ static int finish_t(EngineImpl* im) {
     return 0;
 }
 
-int engine_finish(xck_engine* e, xck_result* out) {
+// fold everything on the GPU and ENQUEUE the copy-out of the matrices; does not wait for the copy
+int engine_finish_async(xck_engine* e) {
     EngineImpl* im = (EngineImpl*)e->impl;
     if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     HIP_TRY(hipSetDevice(im->device));
     int rc = launch_queue(im, -1); if (rc) return rc;
     rc = complete_pending(im); if (rc) return rc;
     if (!im->finished) {
+        im->copy_timed = false;
         rc = im->key_bits == 64 ? finish_t<uint64_t>(im) : finish_t<u128>(im);
         if (rc) return rc;
-        im->finished = true;
+        im->finished = true; im->copy_pending = true;
+    }
+    return 0;
+}
+
+int engine_finish(xck_engine* e, xck_result* out) {
+    EngineImpl* im = (EngineImpl*)e->impl;
+    if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
+    int rc = engine_finish_async(e); if (rc) return rc;
+    if (im->copy_pending) {
+        HIP_TRY(hipStreamSynchronize(im->s_copy));
+        if (im->copy_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, im->ev_c0, im->ev_c1)); im->st.ms_d2h += ms; }
+        im->copy_pending = false;
     }
     memset(out, 0, sizeof *out);
     xck_coo* dst[4] = { &out->count, &out->ad, &out->dp, &out->oth };
@@ -1262,12 +1307,28 @@ int engine_finish(xck_engine* e, xck_result* out) {
     return 0;
 }
 
+// device-resident copy of the last finish() result (for device-to-device exchanges such as the RCCL gather)
+int engine_result_device(xck_engine* e, xck_result* out) {
+    EngineImpl* im = (EngineImpl*)e->impl;
+    if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
+    if (!im->finished) { e->err = "xck_get_result_device before xck_finish"; return XCK_E_STATE; }
+    memset(out, 0, sizeof *out);
+    xck_coo* dst[4] = { &out->count, &out->ad, &out->dp, &out->oth };
+    for (int m = 0; m < 4; m++) {
+        const size_t z = im->res_nnz[m];
+        dst[m]->nnz = (int64_t)z;
+        if (z && im->d_res[m]) { dst[m]->row = im->d_res[m]; dst[m]->col = im->d_res[m] + z; dst[m]->val = im->d_res[m] + 2 * z; }
+    }
+    return 0;
+}
+
 int engine_reset(xck_engine* e) {
     EngineImpl* im = (EngineImpl*)e->impl;
     if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     HIP_TRY(hipSetDevice(im->device));
     int rc = launch_queue(im, -1); if (rc) return rc;
     rc = complete_pending(im); if (rc) return rc;
+    if (im->copy_pending) { HIP_TRY(hipStreamSynchronize(im->s_copy)); im->copy_pending = false; }
     HIP_TRY(hipMemsetAsync(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long), im->s_comp));
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     im->cursor = 0; im->finished = false;
@@ -1317,10 +1378,12 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
       HIP_TRY(hipStreamCreateWithPriority(&im->s_comp, hipStreamNonBlocking, (cfg->flags & XCK_F_LOW_PRIORITY) ? lo : hi)); }
     HIP_TRY(hipEventCreate(&im->ev0)); HIP_TRY(hipEventCreate(&im->ev1));
+    HIP_TRY(hipEventCreate(&im->ev_res)); HIP_TRY(hipEventCreate(&im->ev_c0)); HIP_TRY(hipEventCreate(&im->ev_c1));
     HIP_TRY(hipMalloc((void**)&im->d_ctl, CTL_WORDS * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc((void**)&im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
     memset(im->h_ctl, 0, CTL_WORDS * sizeof(unsigned long long));
+    HIP_TRY(hipHostGetDevicePointer((void**)&im->d_hctl, im->h_ctl, 0));
     rc = ensure_hits(im, (size_t)1 << 20); if (rc) return rc;
     return 0;
 }
@@ -1339,6 +1402,9 @@ void engine_destroy(xck_engine* e) {
     if (im->h_ctl) hipHostFree(im->h_ctl);
     if (im->ev0) hipEventDestroy(im->ev0);
     if (im->ev1) hipEventDestroy(im->ev1);
+    if (im->ev_res) hipEventDestroy(im->ev_res);
+    if (im->ev_c0) hipEventDestroy(im->ev_c0);
+    if (im->ev_c1) hipEventDestroy(im->ev_c1);
     if (im->s_copy) hipStreamDestroy(im->s_copy);
     if (im->s_comp) hipStreamDestroy(im->s_comp);
     delete im; e->impl = nullptr;

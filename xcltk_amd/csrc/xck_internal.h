@@ -97,6 +97,8 @@ void engine_destroy(xck_engine* e);
 int  engine_push(xck_engine* e, const xck_batch* b, bool device_resident);
 int  engine_flush(xck_engine* e);
 int  engine_finish(xck_engine* e, xck_result* out);
+int  engine_finish_async(xck_engine* e);
+int  engine_result_device(xck_engine* e, xck_result* out);
 int  engine_reset(xck_engine* e);
 int  engine_stats(const xck_engine* e, xck_stats* out);
 int  engine_umi_bits(const xck_engine* e);

@@ -217,6 +217,10 @@ class Engine(object):
         finally:
             self.lib.xck_bam_close(b)
 
+    def finish_async(self):
+        """Run the fold on the GPU and enqueue the copy-out of the matrices without waiting for it."""
+        self._check(self.lib.xck_finish_async(self.h), "xck_finish_async")
+
     def finish(self, copy=True):
         """-> {"count": (row, col, val)} or {"ad": .., "dp": .., "oth": ..}; rows are 0-based
         region indices (input order), cols 0-based cell indices, sorted by (row, col).
@@ -229,6 +233,17 @@ class Engine(object):
             out["count"] = res.count.to_numpy(copy)
         if self.mode & XCK_MODE_BAF:
             out.update(ad=res.ad.to_numpy(copy), dp=res.dp.to_numpy(copy), oth=res.oth.to_numpy(copy))
+        return out
+
+    def result_device(self):
+        """Device-resident copy of the last finish(): {name: (device_ptr_of_[row|col|val], nnz)}."""
+        res = capi.Result()
+        self._check(self.lib.xck_get_result_device(self.h, C.byref(res)), "xck_get_result_device")
+        names = (["count"] if self.mode & XCK_MODE_BASEFC else []) + (["ad", "dp", "oth"] if self.mode & XCK_MODE_BAF else [])
+        out = {}
+        for k in names:
+            coo = getattr(res, k)
+            out[k] = (C.cast(coo.row, C.c_void_p).value or 0, int(coo.nnz))
         return out
 
     def write_mtx(self, path, name, row_map, n_rows_out):
