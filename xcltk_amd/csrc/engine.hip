@@ -481,7 +481,13 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     uint32_t acc = 0;
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
     constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? HS_SLOTS : JoinSmem<K, MODE>::QCAP;
-    constexpr int FLUSH_EVERY = (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2));
+#ifndef XCK_FLUSH_END_ONLY
+#define XCK_FLUSH_END_ONLY 1
+#endif
+    // set mode: the de-duplicated fill of a 1024-read tile is a few hundred keys, so flush once, at the end
+    // (better de-duplication, half the cursor atomics); saturation still spills correctly through emit_global()
+    constexpr int FLUSH_EVERY = (XCK_FLUSH_END_ONLY && JoinSmem<K, MODE>::USE_SET) ? TILE_ITEMS
+                              : ((CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)));
 #if XCK_UNROLL_TILE
 #pragma unroll
 #else
@@ -552,6 +558,58 @@ __global__ void k_count_distinct(const K* __restrict__ k, long long n, KeyLayout
         if (x != prev) { c++; prev = x; }
     }
     out[i] = c;
+}
+
+// basefc fold without a dense intermediate: pass A counts the (row, cell) run heads of every 2048-key tile,
+// a one-block scan turns that into output offsets, pass B writes (row, col, #distinct keys of the run)
+// straight into the COO arrays.  Heads walk their run (runs average ~2 keys; the walk stays in L2).
+constexpr int FD_BLOCK = 256, FD_ITEMS = 8, FD_TILE = FD_BLOCK * FD_ITEMS;
+
+template <class K>
+__global__ __launch_bounds__(FD_BLOCK) void k_fold_heads(const K* __restrict__ k, long long n, KeyLayout<K> kl, uint32_t* __restrict__ blk) {
+    __shared__ uint32_t s_wave[FD_BLOCK / 64];
+    const long long base = (long long)blockIdx.x * FD_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int t = 0; t < FD_ITEMS; t++) {                                  // striped: lane-contiguous, fully coalesced
+        const long long i = base + t * FD_BLOCK + threadIdx.x;
+        if (i < n) { if (i == 0 || kl.rc(k[i]) != kl.rc(k[i - 1])) c++; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+template <class K>
+__global__ __launch_bounds__(FD_BLOCK) void k_fold_emit(const K* __restrict__ k, long long n, KeyLayout<K> kl, const unsigned long long* __restrict__ off,
+                                                        int32_t* __restrict__ row, int32_t* __restrict__ col, int32_t* __restrict__ val) {
+    __shared__ uint32_t s_wave[FD_BLOCK / 64];
+    __shared__ K tile[FD_TILE + 1];                                       // tile[0] = key before the tile (halo)
+    const long long base = (long long)blockIdx.x * FD_TILE;
+    const int n_loc = (int)min((long long)FD_TILE, n - base);
+#pragma unroll
+    for (int t = 0; t < FD_ITEMS; t++) { const int e = t * FD_BLOCK + threadIdx.x; if (e < n_loc) tile[1 + e] = k[base + e]; }
+    if (threadIdx.x == 0) tile[0] = base > 0 ? k[base - 1] : K(0);
+    __syncthreads();
+    unsigned long long out = off[blockIdx.x];
+    for (int t = 0; t < FD_ITEMS; t++) {                                  // element order = sweep order, so offsets stay sorted
+        const int e = t * FD_BLOCK + threadIdx.x;
+        K me = K(0); bool head = false;
+        if (e < n_loc) { me = tile[1 + e]; head = (base + e == 0) || kl.rc(me) != kl.rc(tile[e]); }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(head ? 1u : 0u, s_wave, total);
+        if (head) {
+            const K rc = kl.rc(me);
+            int32_t cnt = 1; K last = me; int j = e + 1; bool open = true;
+            for (; j < n_loc; j++) { const K x = tile[1 + j]; if (kl.rc(x) != rc) { open = false; break; } if (x != last) { cnt++; last = x; } }
+            if (open) for (long long g = base + n_loc; g < n; g++) { const K x = k[g]; if (kl.rc(x) != rc) break; if (x != last) { cnt++; last = x; } }
+            const unsigned long long d = out + excl;
+            row[d] = (int32_t)kl.row(me); col[d] = (int32_t)kl.cell(me); val[d] = cnt;
+        }
+        out += total;
+    }
 }
 
 __device__ __forceinline__ int nib_bucket(int nib) { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4; }
@@ -1143,6 +1201,8 @@ static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout
     return 0;
 }
 
+static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total);
+
 // ordered compaction of dense[i] > 0 into pinned host COO arrays of matrix m
 template <class K>
 static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m) {
@@ -1164,6 +1224,11 @@ static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K*
     hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off,
                        d_o, d_o + total, d_o + 2 * total);
     HIP_TRY(hipGetLastError());
+    return copy_out(im, m, d_o, total);
+}
+
+// hand matrix m ([row|col|val] at d_o) to the host
+static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total) {
     im->d_res[m] = d_o;
     // copy-out on the copy stream, ordered behind the scatter: the compute stream (and other engines) keep
     // the CUs busy while the matrix crosses PCIe; xck_finish() waits for it, xck_finish_async() does not
@@ -1181,6 +1246,28 @@ static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K*
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+// basefc: sorted keys -> COO (row, col, count of distinct keys) without a dense intermediate
+template <class K>
+static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayout<K> kl, int m) {
+    size_t nb = (n + FD_TILE - 1) / FD_TILE;
+    uint32_t* d_blk = ws.get<uint32_t>(nb); unsigned long long* d_off = ws.get<unsigned long long>(nb);
+    if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (fold)"; return XCK_E_NOMEM; }
+    hipLaunchKernelGGL((k_fold_heads<K>), dim3(nb), dim3(FD_BLOCK), 0, im->s_comp, keys, (long long)n, kl, d_blk);
+    hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, im->d_ctl + CTL_SCRATCH);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->d_hctl + CTL_SCRATCH, 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    size_t total = im->h_ctl[CTL_SCRATCH];
+    im->res_nnz[m] = total; im->d_res[m] = nullptr;
+    if (!total) return 0;
+    int rc = res_reserve(im, m, total); if (rc) return rc;
+    int32_t* d_o = ws.get<int32_t>(total * 3);
+    if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
+    hipLaunchKernelGGL((k_fold_emit<K>), dim3(nb), dim3(FD_BLOCK), 0, im->s_comp, keys, (long long)n, kl, d_off, d_o, d_o + total, d_o + 2 * total);
+    HIP_TRY(hipGetLastError());
+    return copy_out(im, m, d_o, total);
 }
 
 // copy the used prefix of every shard slice into one contiguous array (sort input)
@@ -1224,9 +1311,8 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.start())) return rc;
         if ((rc = pack_shards(im, alt, (uint64_t*)nullptr))) return rc;             // shard slices -> contiguous
         if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top))) return rc;
-        hipLaunchKernelGGL((k_count_distinct<K>), dim3(gs), dim3(256), 0, im->s_comp, keys, (long long)n, kl, dense);
-        HIP_TRY(hipGetLastError());
-        if ((rc = compact_coo<K>(im, im->ws1, dense, keys, n, kl, 0))) return rc;
+        (void)dense;
+        if ((rc = fold_coo<K>(im, im->ws1, keys, n, kl, 0))) return rc;
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
