@@ -109,3 +109,76 @@ def test_large_scale_parity(large, mode, mats):
     got2, _, st2 = util.engine_vs_oracle(mode, names, regions, snps, 1500, batches)
     util.assert_coo_equal(got2, exp, mats)
     assert st2["n_hits"] == st["n_hits"]
+
+
+def test_deep_nesting_spill_and_overflow_replay():
+    """12 identical + 6 nested regions over every read: >12 accepted pairs per read saturates the LDS
+    set (spill through emit_global) and exceeds the 5-hits-per-read capacity estimate (overflow flag,
+    buffer growth, cursor rewind and replay).  Result must still equal the oracle."""
+    rng = np.random.default_rng(5)
+    regions = [("1", 1000, 900000, "big%d" % i) for i in range(12)] + [("1", 1000 + 50000 * i, 400000 + 50000 * i, "n%d" % i) for i in range(6)]
+    names = ["1"]
+    bs = soa.gen_reads(regions, names, 400000, 50, seed=9, max_batch=150000)
+    batches = [util.batch_from_dict(b) for b in bs]
+    for inc in (0, 0.9):
+        got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 50, batches, min_include=inc)
+        assert st["n_hits"] > 12 * 250000
+        util.assert_coo_equal(got, exp, ["count"])
+
+
+def test_many_batches_fused_queue_and_empty_batches(small):
+    """More device-resident-style pushes than one fused launch holds (host path here: each push is its own
+    launch), empty batches and a contig without regions in between."""
+    regions, snps, names, batches = small
+    tiny = []
+    for b, keep in batches:
+        n = b.n_reads
+        pos, flag, mapq, cell, umi, cig_off, cigar = keep[:7]
+        step = max(1, n // 30)
+        for s0 in range(0, n, step):
+            e0 = min(n, s0 + step)
+            c_lo, c_hi = int(cig_off[s0]), int(cig_off[e0])
+            args = [b.contig, int(b.ordinal_base) + s0, pos[s0:e0], flag[s0:e0], mapq[s0:e0], cell[s0:e0], umi[s0:e0],
+                    (cig_off[s0:e0 + 1] - cig_off[s0]).astype(np.uint32), cigar[c_lo:c_hi] if c_hi > c_lo else np.zeros(1, np.uint32)]
+            if len(keep) > 7:
+                so, sq = keep[7], keep[8]
+                q_lo, q_hi = int(so[s0]), int(so[e0])
+                args += [(so[s0:e0 + 1] - so[s0]).astype(np.uint32), sq[q_lo:q_hi] if q_hi > q_lo else np.zeros(1, np.uint8)]
+            tiny.append(capi.make_batch(*args))
+        tiny.append(capi.make_batch(b.contig, 0, np.zeros(0, np.int32), [], [], [], [], np.zeros(1, np.uint32), np.zeros(1, np.uint32),
+                                    np.zeros(1, np.uint32), np.zeros(1, np.uint8)))
+    assert len(tiny) > 60
+    for mode, mats in ((capi.XCK_MODE_BASEFC, ["count"]), (capi.XCK_MODE_BAF, ["ad", "dp", "oth"])):
+        got, exp, st = util.engine_vs_oracle(mode, names, regions, snps, 200, tiny)
+        got0, _, _ = util.engine_vs_oracle(mode, names, regions, snps, 200, batches)
+        util.assert_coo_equal(got, exp, mats)
+        util.assert_coo_equal(got0, exp, mats)
+
+
+def test_device_resident_batches_more_than_one_fused_launch():
+    """xck_push_batch_device: 70 HBM-resident batches (slices of contigs) need three fused launches of <= 24
+    batches; both modes must equal the oracle run on host copies of the same arrays."""
+    import torch
+    from xcltk_amd.engine import Engine
+    from xcltk_amd.synth import soa_torch
+    regions, snps, names = soa.make_tables(1500, 30000, soa.HG38_LENGTHS[:5], seed=31, max_len=200000)
+    arrays, contig_batches = soa_torch.gen_reads_device(regions, names, 1200000, 300, seed=32, device=torch.device("cuda", 0))
+    pieces = []
+    for c, s, e in contig_batches:
+        step = max(1, (e - s) // 14)
+        pieces += [(c, a, min(e, a + step)) for a in range(s, e, step)]
+    assert len(pieces) > 48
+    hb = [util.batch_from_dict(soa_torch.host_batch_dict(arrays, c, s, e, True)) for c, s, e in pieces]
+    for mode, mats in ((capi.XCK_MODE_BASEFC, ["count"]), (capi.XCK_MODE_BAF, ["ad", "dp", "oth"])):
+        eng = Engine(mode, names, regions, 300, snps=snps if mode == 2 else ())
+        for rep in range(2):                                   # second pass re-uses the engine after reset()
+            eng.reset()
+            for c, s, e in pieces:
+                eng.push(soa_torch.device_batch(capi, arrays, c, s, e, mode == 2), device_resident=True)
+            got = eng.finish()
+            st = eng.stats()
+            assert st["n_join_launches"] >= 3
+            cfg, keep = O.make_config(mode, names, regions, snps if mode == 2 else [], 300)
+            exp = O.run_oracle(cfg, [b for b, _ in hb])
+            util.assert_coo_equal(got, exp, mats)
+        eng.close()
