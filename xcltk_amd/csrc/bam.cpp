@@ -503,7 +503,12 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
-    if (!b->ranges_set) { set_ranges(b, o); if (b->use_ranges && !begin_range(b)) return 0; }
+    if (!b->ranges_set) {
+        // well mode without UMIs: the key is the read name and the column is the BAM itself, so names only
+        // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads)
+        if (!e->dec.use_barcodes && !e->dec.use_umi) e->intern.clear();
+        set_ranges(b, o); if (b->use_ranges && !begin_range(b)) return 0;
+    }
     if (!b->primed) { schedule_chunk(b, b->ch[0], crc); b->stitch_skip = b->first_skip; b->first_skip = 0; b->cur = 0; b->primed = true; }
     Chunk& c = b->ch[b->cur];
     if (!c.valid && !c.failed) {
