@@ -27,7 +27,7 @@ import torch
 
 from xcltk_amd import capi
 from xcltk_amd.engine import Engine
-from xcltk_amd.shard import gather_device_blocks, linear_partition
+from xcltk_amd.shard import BlockGatherer, linear_partition
 from xcltk_amd.synth import soa, soa_torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
@@ -109,17 +109,19 @@ def main():
             out.update(eng_baf.finish(copy=False))
             out.update(eng_fc.finish(copy=False))
         if world > 1:
-            # all-gatherv of the per-contig sparse blocks to the writer rank, GPU to GPU over xGMI (RCCL):
-            # sizes first, then the padded [row|col|val] blocks that are still resident in HBM.  Every rank
-            # has also delivered its own row range to pinned host memory (out), in parallel over its own PCIe link.
-            dev_blocks = dict(eng_fc.result_device()); dev_blocks.update(eng_baf.result_device())
-            gathered = {}
-            for k in ("count", "ad", "dp", "oth"):
-                gathered[k] = gather_device_blocks(dev_blocks[k], world, rank, device, backend_is_nccl=not shared_gpu)
-            out["_gathered_sizes"] = {k: v[1] for k, v in gathered.items()}
+            # all-gatherv of the per-contig sparse blocks to the writer rank, GPU to GPU over xGMI (RCCL): sizes
+            # first, then ONE gather of the padded [row|col|val] blocks that are still resident in HBM.  It is only
+            # enqueued here and overlaps the next pass (collected before the next exchange and at the end of the
+            # run).  Every rank has also delivered its own row range to pinned host memory (out) over its own PCIe link.
+            blocks = dict(eng_fc.result_device()); blocks.update(eng_baf.result_device())
+            out["_gathered_sizes"] = gatherer.start(blocks)
         return out
 
+    gatherer = BlockGatherer(world, rank, device, backend_is_nccl=not shared_gpu) if world > 1 else None
+
     def sync():
+        if gatherer is not None:
+            gatherer.wait()                               # the last exchange is inside the timed region
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -217,7 +219,7 @@ def main():
                 config=dict(workload="BASELINE.json configs[1]: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
                                      "basefc + pileup per step, SoA resident in HBM" % (n_reads, args.cells, len(snps), len(regions)),
                             reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world,
-                            nnz={kk: (int(sum(res["_gathered_sizes"][kk])) if world > 1 else int(len(v[0]))) for kk, v in res.items() if not kk.startswith("_")},
+                            nnz={kk: (int(sum(sz[j] for sz in res["_gathered_sizes"])) if world > 1 else int(len(res[kk][0]))) for j, kk in enumerate(("count", "ad", "dp", "oth"))},
                             hits=dict(basefc=int(hits_fc), pileup=int(hits_baf),
                                       basefc_after_lds_dedup=int(sfc["n_hits_unique"]))),
                 roofline=roofline, cpu_baseline=cpu)

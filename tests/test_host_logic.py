@@ -284,3 +284,13 @@ def test_indexed_contig_subset_decode(ds, mask):
                 assert np.array_equal(g[k], w[k]), k
     assert sum(b["n_reads"] for b in full if b["contig"] >= 0) <= int(counts.sum())
     assert sum(b["n_reads"] for b in want) == int(counts[np.array(mask)].sum())
+
+
+def test_linear_partition_contiguous_and_balanced():
+    from xcltk_amd.shard import linear_partition
+    from xcltk_amd.synth.soa import HG38_LENGTHS
+    for n in (1, 2, 3, 4, 8):
+        bins = linear_partition(HG38_LENGTHS, n)
+        assert sum(bins, []) == list(range(24)) and all(b for b in bins)
+        loads = [sum(HG38_LENGTHS[i] for i in b) for b in bins]
+        assert max(loads) <= 1.25 * sum(loads) / n

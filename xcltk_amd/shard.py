@@ -88,6 +88,64 @@ class _DevArray(object):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
+class BlockGatherer(object):
+    """all-gatherv of the per-rank sparse blocks to the writer rank (rank 0), GPU to GPU.
+
+    Every rank contributes, for each matrix, its [row|col|val] int32 block that is still resident in
+    HBM after xck_finish (Engine.result_device()).  One tiny all-gather exchanges the sizes, then ONE
+    gather moves all matrices (each padded to its largest block) to rank 0 - RCCL over xGMI with the
+    nccl backend.  start() only enqueues the exchange (async_op) so that the caller can overlap it with
+    the next pass; wait() returns, on rank 0, {name: [per-rank int32 tensors in rank order]}.
+    With contiguous per-rank row ranges the rank-order concatenation is already the (row, col) order.
+    """
+
+    def __init__(self, world, rank, device, names=("count", "ad", "dp", "oth"), backend_is_nccl=True):
+        self.world, self.rank, self.device, self.names = world, rank, device, tuple(names)
+        self.nccl = backend_is_nccl
+        self._pending = None
+
+    def start(self, blocks):
+        """blocks: {name: (device_ptr, nnz)}."""
+        import torch
+        import torch.distributed as dist
+        self.wait()
+        dev = self.device if self.nccl else "cpu"
+        mine = torch.tensor([blocks[k][1] for k in self.names], dtype=torch.int64, device=dev)
+        all_sizes = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(all_sizes, mine)
+        sizes = torch.stack(all_sizes).cpu().tolist()                 # [rank][matrix]
+        pad = [max(max(sizes[r][j] for r in range(self.world)), 1) * 3 for j in range(len(self.names))]
+        buf = torch.zeros(sum(pad), dtype=torch.int32, device=self.device)
+        off = 0
+        for j, k in enumerate(self.names):
+            ptr, nnz = blocks[k]
+            if nnz:                                                   # device-to-device copy out of the engine workspace
+                buf[off:off + 3 * nnz] = torch.as_tensor(_DevArray(ptr, 3 * nnz), device=self.device)
+            off += pad[j]
+        # the engine re-uses its workspace on the next pass: make sure the copy out of it has really run
+        torch.cuda.current_stream(self.device).synchronize()
+        if not self.nccl:
+            buf = buf.cpu()
+        outs = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
+        work = dist.gather(buf, outs, dst=0, async_op=True)
+        self._pending = (work, outs, sizes, pad, buf)
+        return sizes
+
+    def wait(self):
+        if self._pending is None:
+            return None
+        work, outs, sizes, pad, buf = self._pending
+        self._pending = None
+        work.wait()
+        if self.rank != 0:
+            return None
+        res, off = {}, 0
+        for j, k in enumerate(self.names):
+            res[k] = [outs[r][off:off + 3 * sizes[r][j]] for r in range(self.world)]
+            off += pad[j]
+        return res
+
+
 def gather_device_blocks(block, world, rank, device, backend_is_nccl=True):
     """all-gatherv for the writer rank: every rank contributes its [row|col|val] int32 block that is
     already resident in HBM; sizes are all-gathered first, then the padded blocks are gathered to
