@@ -18,6 +18,13 @@ from xcltk_amd.engine import Engine, XckError, resolve_contigs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def test_library_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "xck.h")).read()
     declared = set(re.findall(r"\b(xck_[a-z0-9_]+)\s*\(", hdr))
@@ -251,7 +258,7 @@ def test_gather_coo_gloo_world2(tmp_path):
     script.write_text(_GLOO_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout, r.stdout[-2000:]
 

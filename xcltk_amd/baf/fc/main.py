@@ -49,8 +49,7 @@ def prepare_config(conf):
     if not conf.out_dir:
         error("out dir needed!")
         return -1
-    if not os.path.isdir(conf.out_dir):
-        os.mkdir(conf.out_dir)
+    os.makedirs(conf.out_dir, exist_ok=True)          # every rank may get here first in a multi-GPU run
     pre = os.path.join(conf.out_dir, conf.out_prefix)
     conf.out_region_fn, conf.out_sample_fn = pre + "region.tsv", pre + "samples.tsv"
     conf.out_ad_fn, conf.out_dp_fn, conf.out_oth_fn = pre + "AD.mtx", pre + "DP.mtx", pre + "OTH.mtx"
@@ -81,7 +80,8 @@ def prepare_config(conf):
         warn("local phasing from '%s' is not implemented by this engine; using the given phase." % conf.cellsnp_dir)
     if fcc.resolve_tags(conf) < 0:
         return -1
-    fcc.write_samples(conf.out_sample_fn, conf.samples)
+    if fcc.is_writer_rank():
+        fcc.write_samples(conf.out_sample_fn, conf.samples)
     return 0
 
 

@@ -134,11 +134,33 @@ class XckLibraryError(RuntimeError):
     pass
 
 
+def _preload_torch_hip():
+    """PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64.so.1 (same sonames as /opt/rocm).
+    Two HIP runtimes cannot share a process: whichever is loaded first serves both libxck.so and torch.
+    If libxck.so pulled in the system runtime first, a later `import torch` finds "no ROCm-capable device".
+    So when torch is installed, load ITS runtime before libxck.so (no `import torch` needed); the dynamic
+    linker then binds libxck.so to the already loaded sonames."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.isfile(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load(path=None):
     """Load libxck.so (built by `make -C xcltk_amd/csrc` or __graft_entry__.build())."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    _preload_torch_hip()
     p = path or os.environ.get("XCK_LIB", LIB_PATH)
     if not os.path.isfile(p):
         raise XckLibraryError(

@@ -5,16 +5,17 @@
 //   xcltk/baf/fc/core.py:70-247  (fc_features -> fc_fet1 -> plp_snp -> MCount/SCount/UCount)
 // with ONE streaming pass over coordinate-sorted record batches:
 //
-//   k_join_fc   : read x region interval join through a per-contig window index, CIGAR-walk
-//                 include test, emits one 64/128-bit key (row | cell | umi) per accepted pair.
-//   k_join_snp  : read x SNP join, CIGAR walk to the query base at the SNP, emits
-//                 key (snp | cell | umi) and value (fetch ordinal | allele).
-//   finish      : radix sort of the keys, then hand-written segmented reductions:
-//                 distinct-UMI counts per (row, cell); "first read wins" per (snp, cell, umi);
-//                 per-SNP allele tallies + filters; SNP -> region expansion; haplotype set
-//                 algebra per (row, cell); ordered compaction into COO.
+//   k_tile_meta : one thread per 1024-read tile: extent, staged index windows (48-byte record).
+//   k_join      : one block per tile; CIGAR run, window CSR and regions / SNPs staged in LDS; read x region
+//                 interval join + CIGAR-walk include test, or read x SNP join + query base at the SNP;
+//                 accepted keys de-duplicated in an LDS hash set; fragments appended through sharded cursors.
+//   finish      : radix sort of the keys (rocPRIM), then hand-written segmented reductions:
+//                 k_fold_heads/k_fold_emit (distinct-UMI counts per (row, cell) straight into COO);
+//                 k_first_read ("first read wins" per (snp, cell, umi)) + per-SNP allele tallies,
+//                 k_expand (per-SNP filters, SNP -> region fan-out), k_hap_counts (haplotype set algebra),
+//                 k_cp_* (ordered compaction); copy-out on the copy stream (xck_finish_async).
 //
-// Integer / byte work only - HBM-bound, no MFMA.  See DESIGN.md for layouts and byte counts.
+// Integer / byte work only - HBM-bound, no MFMA.  See DESIGN.md for layouts, byte counts and measurements.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -542,24 +543,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
 // ------------------------------------------------------------------------------------------
 // finish kernels
 // ------------------------------------------------------------------------------------------
-// basefc: at the head of each (row, cell) run count the distinct keys of the run
-// (= len(umi_set), rdr/fc/mcount.py:52-53); dense output, 0 elsewhere.
-template <class K>
-__global__ void k_count_distinct(const K* __restrict__ k, long long n, KeyLayout<K> kl, int32_t* __restrict__ out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    K me = k[i];
-    K rc = kl.rc(me);
-    if (i > 0 && kl.rc(k[i - 1]) == rc) { out[i] = 0; return; }
-    int32_t c = 1; K prev = me;
-    for (long long j = i + 1; j < n; j++) {
-        K x = k[j];
-        if (kl.rc(x) != rc) break;
-        if (x != prev) { c++; prev = x; }
-    }
-    out[i] = c;
-}
-
 // basefc fold without a dense intermediate: pass A counts the (row, cell) run heads of every 2048-key tile,
 // a one-block scan turns that into output offsets, pass B writes (row, col, #distinct keys of the run)
 // straight into the COO arrays.  Heads walk their run (runs average ~2 keys; the walk stays in L2).
@@ -1306,12 +1289,11 @@ static int finish_t(EngineImpl* im) {
     K* keys = (K*)im->d_keys;
     if (im->mode == XCK_MODE_BASEFC) {
         const size_t tmpb = sort_tmp_bytes<K, rocprim::empty_type>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 4 + tmpb + nb * 12 + n * 12 + (1 << 16)))) return rc;
-        K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb); int32_t* dense = im->ws1.get<int32_t>(n);
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + nb * 12 + n * 12 + (1 << 16)))) return rc;
+        K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb);
         if ((rc = tm.start())) return rc;
         if ((rc = pack_shards(im, alt, (uint64_t*)nullptr))) return rc;             // shard slices -> contiguous
         if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top))) return rc;
-        (void)dense;
         if ((rc = fold_coo<K>(im, im->ws1, keys, n, kl, 0))) return rc;
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {

@@ -230,6 +230,11 @@ def write_region_tsv(path, regions, rm):
                          for (ch, s, e, name), r in zip(regions, rm) if r > 0))
 
 
+def is_writer_rank():
+    """True in a single-process run and on rank 0 of a multi-GPU run (the only rank that writes files)."""
+    return int(os.environ.get("RANK", "0")) == 0
+
+
 def write_samples(path, samples):
     with open(path, "w") as fp:
         fp.write("".join(smp + "\n" for smp in samples))

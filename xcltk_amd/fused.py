@@ -46,7 +46,8 @@ def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_lis
     regions, snps = conf.reg_list, conf.snp_list
     fc_dir = os.path.join(out_dir, "basefc")
     os.makedirs(fc_dir, exist_ok=True)
-    fcc.write_samples(os.path.join(fc_dir, "barcodes.tsv"), conf.samples)
+    if fcc.is_writer_rank():
+        fcc.write_samples(os.path.join(fc_dir, "barcodes.tsv"), conf.samples)
     names = fcc.contig_table(regions, snps)
     eng = Engine(XCK_MODE_BOTH, names, regions, len(conf.samples), snps=snps,
                  barcodes=conf.barcodes if conf.use_barcodes() else None, cell_tag=conf.cell_tag,

@@ -133,8 +133,7 @@ def prepare_config(conf):
     if not conf.out_dir:
         error("out dir needed!")
         return -1
-    if not os.path.isdir(conf.out_dir):
-        os.mkdir(conf.out_dir)
+    os.makedirs(conf.out_dir, exist_ok=True)          # every rank may get here first in a multi-GPU run
     conf.out_region_fn = os.path.join(conf.out_dir, conf.out_prefix + "features.tsv")
     conf.out_sample_fn = os.path.join(conf.out_dir, conf.out_prefix + "barcodes.tsv")
     conf.out_mtx_fn = os.path.join(conf.out_dir, conf.out_prefix + "matrix.mtx")
@@ -151,7 +150,8 @@ def prepare_config(conf):
     info("count %d regions in %d single cells." % (len(conf.reg_list), len(conf.samples)))
     if fcc.resolve_tags(conf) < 0:
         return -1
-    fcc.write_samples(conf.out_sample_fn, conf.samples)
+    if fcc.is_writer_rank():
+        fcc.write_samples(conf.out_sample_fn, conf.samples)
     return 0
 
 
