@@ -1,0 +1,75 @@
+"""Randomised end-to-end parity: seeded random datasets and option sets, product front-ends on the GPU vs
+the oracle's whole-run path (independent BAM reader, encoder, C restatement, writers), byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import util
+from xcltk_amd import capi
+from xcltk_amd.synth.generate import make_10x_dataset, make_smartseq_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp_dirs(a, b):
+    fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+    assert fa == fb
+    for f in fa:
+        assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_random_10x_dataset_and_options(seed, tmp_path):
+    from xcltk_amd.baf.fc.main import afc_wrapper
+    from xcltk_amd.rdr.fc.main import fc_wrapper
+    rng = np.random.default_rng(1000 + seed)
+    n_contigs = int(rng.integers(1, 4))
+    contigs = tuple(("chr%d" % (i + 1), int(rng.integers(150000, 600000))) for i in range(n_contigs))
+    n_bams = int(rng.integers(1, 3))
+    d = make_10x_dataset(str(tmp_path / "ds"), n_reads=int(rng.integers(1500, 6000)), n_barcodes=int(rng.integers(5, 120)),
+                         n_snps=int(rng.integers(50, 600)), n_genes=int(rng.integers(5, 60)), contigs=contigs, seed=seed,
+                         bam_contig_prefix=[None, "", "chr"][int(rng.integers(0, 3))], align_records=bool(rng.integers(0, 2)),
+                         n_bams=n_bams, paired=bool(rng.integers(0, 2)), umi_len=int(rng.integers(6, 15)),
+                         frac_cb_outside=float(rng.uniform(0, 0.1)), iupac_frac=float(rng.uniform(0, 0.03)))
+    sam = ",".join(d["bams"])
+    umi_tag = ["UB", "UB", "None"][int(rng.integers(0, 3))]
+    common = dict(min_mapq=int(rng.choice([0, 2, 20, 30])), min_len=int(rng.choice([0, 30, 60, 91])),
+                  incl_flag=int(rng.choice([0, 0, 16])), no_orphan=bool(rng.integers(0, 2)))
+    min_include = [0.9, 0.5, 0.1, 0, 1, 30, 91, 0.999][int(rng.integers(0, 8))]
+    all_reg = bool(rng.integers(0, 2))
+    # ---- basefc
+    out = str(tmp_path / "fc"); ref = str(tmp_path / "fc_ref")
+    assert fc_wrapper(sam, d["barcodes"], d["regions"], out, umi_tag=umi_tag, output_all_reg=all_reg,
+                      min_include=min_include, ncores=int(rng.integers(1, 5)), **common) == 0
+    O.run_files(capi.XCK_MODE_BASEFC, d["bams"], d["regions"], out_dir=ref, barcode_fn=d["barcodes"], umi_tag=umi_tag,
+                output_all_reg=all_reg, min_include=min_include, **common)
+    _cmp_dirs(out, ref)
+    # ---- baf
+    excl = [None, 0, 1024, 772][int(rng.integers(0, 4))]
+    bopts = dict(min_count=int(rng.choice([0, 1, 3, 11])), min_maf=float(rng.choice([0, 0.05, 0.1, 0.3])),
+                 no_dup_hap=bool(rng.integers(0, 2)))
+    snp_fn = d["snps_vcf"] if rng.integers(0, 2) else d["snps_tsv"]
+    out = str(tmp_path / "baf"); ref = str(tmp_path / "baf_ref")
+    assert afc_wrapper(sam, d["barcodes"], d["regions"], snp_fn, out, umi_tag=umi_tag, output_all_reg=all_reg,
+                       excl_flag=excl, ncores=2, **bopts, **common) == 0
+    O.run_files(capi.XCK_MODE_BAF, d["bams"], d["regions"], out_dir=ref, barcode_fn=d["barcodes"], snp_fn=snp_fn, umi_tag=umi_tag,
+                output_all_reg=all_reg, excl_flag=excl, **bopts, **common)
+    _cmp_dirs(out, ref)
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_well_mode(seed, tmp_path):
+    from xcltk_amd.fused import fused_wrapper
+    rng = np.random.default_rng(2000 + seed)
+    d = make_smartseq_dataset(str(tmp_path / "ds"), n_cells=int(rng.integers(3, 9)), reads_per_cell=int(rng.integers(300, 900)),
+                              n_snps=200, n_genes=30, contigs=(("1", 300000), ("2", 200000)), seed=seed)
+    out = str(tmp_path / "fused")
+    assert fused_wrapper(None, None, d["regions"], d["snps_tsv"], out, sam_list_fn=d["sam_list"], sample_id_fn=d["sample_list"],
+                         cell_tag="None", umi_tag="None", ncores=2, no_orphan=bool(seed & 1)) == 0
+    common = dict(cell_tag=None, umi_tag=None, sample_ids=d["sample_ids"], no_orphan=bool(seed & 1))
+    O.run_files(capi.XCK_MODE_BASEFC, d["bams"], d["regions"], out_dir=str(tmp_path / "r1"), **common)
+    O.run_files(capi.XCK_MODE_BAF, d["bams"], d["regions"], out_dir=str(tmp_path / "r2"), snp_fn=d["snps_tsv"], **common)
+    _cmp_dirs(os.path.join(out, "basefc"), str(tmp_path / "r1"))
+    _cmp_dirs(os.path.join(out, "baf"), str(tmp_path / "r2"))
