@@ -301,3 +301,36 @@ def test_linear_partition_contiguous_and_balanced():
         assert sum(bins, []) == list(range(24)) and all(b for b in bins)
         loads = [sum(HG38_LENGTHS[i] for i in b) for b in bins]
         assert max(loads) <= 1.25 * sum(loads) / n
+
+
+def test_fast_inflate_matches_zlib_on_every_block():
+    """inflate_fast.h vs zlib: every BGZF block of the golden BAMs plus 600 synthetic streams (stored, fixed and
+    dynamic blocks, all levels / strategies, corrupted and truncated inputs must not write out of bounds)."""
+    exe = os.path.join(ROOT, "xcltk_amd", "csrc", "xck_inflate_test")
+    if not os.path.isfile(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "xcltk_amd", "csrc"), "xck_inflate_test"])
+    import glob
+    bams = sorted(glob.glob(os.path.join(util.GOLDEN, "datasets", "*", "*.bam")))
+    r = subprocess.run([exe] + bams, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "mismatches 0 fast-decoder-declined 0" in r.stdout, r.stdout[-500:]
+
+
+def test_decoder_same_output_with_zlib_and_fast_inflate():
+    """XCK_INFLATE=zlib forces the library decoder: both must give identical SoA batches."""
+    code = ("import sys, hashlib, numpy as np; sys.path[:0]=[%r, %r, %r]\n"
+            "import util, oracle as O\nfrom xcltk_amd import capi\nfrom xcltk_amd.engine import Engine\n"
+            "import os\nd=os.path.join(util.GOLDEN,'datasets','dense')\nregions,snps=util.load_tables(d)\nnames=O.contig_table(regions,snps)\n"
+            "bc=sorted(x.strip() for x in open(d+'/barcodes.tsv'))\n"
+            "e=Engine(2,names,regions,len(bc),snps=snps,barcodes=bc,cell_tag='CB',umi_tag='UB',decode_only=True,n_threads=2)\n"
+            "h=hashlib.md5()\n"
+            "for b in e.decode_bam(d+'/possorted.bam'):\n"
+            "    [h.update(np.ascontiguousarray(b[k]).tobytes()) for k in ('pos','flag','mapq','cell','umi','cig_off','cigar','seq_off','seq')]\n"
+            "print(h.hexdigest())\n") % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"))
+    outs = []
+    for mode in ("fast", "zlib"):
+        env = dict(os.environ, XCK_INFLATE=mode)
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 32

@@ -21,6 +21,7 @@
 #include <functional>
 #include <thread>
 #include "xck_internal.h"
+#include "inflate_fast.h"
 
 namespace xck {
 
@@ -147,13 +148,24 @@ static bool bgzf_peek(const uint8_t* map, uint64_t fsize, uint64_t coff, BlockRe
     return true;
 }
 
+static std::atomic<long> g_inflate_fallbacks{0};
+static const bool g_use_fast_inflate = [] { const char* e = getenv("XCK_INFLATE"); return !(e && strcmp(e, "zlib") == 0); }();
+static thread_local InflateTables t_inflate_tables;
+
 static bool bgzf_inflate(const uint8_t* map, const BlockRef& b, uint8_t* dst, bool verify_crc, z_stream* zs, std::string* err) {
     if (b.isize == 0) return true;
-    inflateReset(zs);
-    zs->next_in = const_cast<Bytef*>(map + b.coff + b.data_off); zs->avail_in = b.data_len;
-    zs->next_out = dst; zs->avail_out = b.isize;
-    int rc = inflate(zs, Z_FINISH);
-    if (rc != Z_STREAM_END || zs->avail_out != 0) { if (err) *err = "BGZF inflate failed"; return false; }
+    bool done = false;
+    if (g_use_fast_inflate) {                                  // own whole-buffer decoder (inflate_fast.h); zlib on any irregularity
+        done = inflate_raw(map + b.coff + b.data_off, b.data_len, dst, b.isize, &t_inflate_tables) == 0;
+        if (!done) g_inflate_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (!done) {
+        inflateReset(zs);
+        zs->next_in = const_cast<Bytef*>(map + b.coff + b.data_off); zs->avail_in = b.data_len;
+        zs->next_out = dst; zs->avail_out = b.isize;
+        int rc = inflate(zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs->avail_out != 0) { if (err) *err = "BGZF inflate failed"; return false; }
+    }
     if (verify_crc) {
         uint32_t want = le32(map + b.coff + b.clen - 8);
         if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) != want) { if (err) *err = "BGZF CRC mismatch"; return false; }
