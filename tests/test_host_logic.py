@@ -334,3 +334,23 @@ def test_decoder_same_output_with_zlib_and_fast_inflate():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and len(outs[0]) == 32
+
+
+def test_fraction_bounds():
+    """engine.hip frac_bounds/frac_below: integer bounds around RN(f*n) decide `m / float(n) < f`
+    (rdr/fc/core.py:160-165) exactly like the IEEE divide for every (m, n) - checked exhaustively for
+    n <= 1500 and for thresholds that make f*n land on / next to integers."""
+    fs = [0.9, 0.5, 0.25, 0.75, 0.1, 1.0 / 3.0, 2.0 / 3.0, 0.999999, 1e-9, 0.3, 0.7, np.nextafter(0.5, 0), np.nextafter(0.5, 1)]
+    n = np.arange(1, 1501, dtype=np.int64)
+    for f in fs:
+        p = f * n.astype(np.float64)
+        m_rej = np.ceil(p * (1.0 - 2.0 ** -50)).astype(np.int64)
+        m_acc = np.floor(p * (1.0 + 2.0 ** -50)).astype(np.int64) + 1
+        assert np.all(m_acc - m_rej <= 1)                   # at most one m per n needs the divide
+        for m in range(0, 1501):
+            ok = n >= m
+            exact = (m / n.astype(np.float64)) < f
+            fast = np.where(m < m_rej, True, np.where(m >= m_acc, False, exact))
+            assert np.array_equal(fast[ok], exact[ok])
+            # and the bounds alone are never wrong where they decide
+            assert np.all(exact[ok & (m < m_rej)]) and not np.any(exact[ok & (m >= m_acc)])

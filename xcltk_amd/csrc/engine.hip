@@ -33,6 +33,18 @@ typedef unsigned __int128 u128;
 #ifndef XCK_WS
 #define XCK_WS 15
 #endif
+#ifndef XCK_EXP
+#define XCK_EXP 0          // timing experiments only (wrong results): 1 no emit, 2 no fp64 divide, 4 no CIGAR re-walk, 8 no flush, 16 no join
+#endif
+#ifndef XCK_HASH_MUL64
+#define XCK_HASH_MUL64 0
+#endif
+#ifndef XCK_PREFETCH_ALL
+#define XCK_PREFETCH_ALL 1   // all TILE_ITEMS reads of a thread are loaded in the prologue (one HBM round trip per tile)
+#endif
+#ifndef XCK_DENSE
+#define XCK_DENSE 0           // region-major evaluation (4 reads in registers): measured equal-to-slower, 100 VGPRs cost a wave of occupancy
+#endif
 constexpr int WS = XCK_WS;             // window shift of the interval index (2^WS bp windows)
 constexpr int JOIN_BLOCK = 256;
 
@@ -95,7 +107,7 @@ struct TileMeta {
     uint32_t c_lo, cg_n;                  // CIGAR words of the tile: [c_lo, c_lo + cg_n) are staged
     int32_t  w0, nw, e0, n_ent;           // basefc: staged windows [w0, w0+nw), their entries [e0, e0+n_ent)
     int32_t  k0, nk;                      // pileup: staged SNPs [k0, k0+nk)
-    int32_t  b, r0, r1, pad;              // batch index, first / one-past-last read of the tile
+    int32_t  b, r0, r1, n0;               // batch index, first / one-past-last read of the tile, entries of window w0
 };
 
 template <class K> struct JoinArgs {
@@ -119,9 +131,28 @@ constexpr int NSHARD = 16;
 constexpr int CTL_OVERFLOW = 1, CTL_SCRATCH = 3, CTL_SHARD0 = 16, CTL_STRIDE = 16;
 constexpr int CTL_WORDS = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
 __host__ __device__ inline int ctl_cursor(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE; }
+__host__ __device__ inline int ctl_umi_or(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE + 1; }   // OR of the UMI codes seen
 __host__ __device__ inline int ctl_accepted(int shard) { return CTL_SHARD0 + (NSHARD + shard) * CTL_STRIDE; }
 
-struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint64_t umi; bool ok; };
+struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint64_t umi; bool ok;
+                  int32_t m_rej, m_acc; };   // fraction mode: m < m_rej fails, m >= m_acc passes, between: divide
+
+// `m / float(n) < min_include` (rdr/fc/core.py:160-165) is an IEEE double comparison of a ROUNDED quotient.  The
+// fp64 divide costs ~40 VALU per (read, region) pair, so each read carries two integer bounds instead: with
+// p = RN(f * n), any m < p(1 - 2^-50) has RN(m/n) < f and any m > p(1 + 2^-50) has RN(m/n) >= f (three roundings
+// of 2^-53 each stay inside the 2^-50 margin); only an m between the bounds (f * n within 2^-50 of an integer)
+// takes the exact divide.  tests/test_host_logic.py::test_fraction_bounds checks the equivalence exhaustively.
+__device__ __forceinline__ void frac_bounds(ReadInfo& r, double f) {
+    const double p = f * (double)r.n_al;
+    r.m_rej = (int32_t)ceil(p * (1.0 - 0x1p-50));
+    r.m_acc = (int32_t)floor(p * (1.0 + 0x1p-50)) + 1;
+}
+__device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r, double f) {
+    if (XCK_EXP & 2) return false;
+    if (m < r.m_rej) return true;
+    if (m >= r.m_acc) return false;
+    return (double)m / (double)r.n_al < f;
+}
 
 // ---- join kernel: one 256-thread block per tile of 2048 consecutive reads ---------------------
 // Reads are coordinate sorted, so a tile touches a handful of index windows, regions / SNPs and
@@ -175,6 +206,8 @@ template <class K, int MODE> struct JoinSmem {
     int32_t  w0, nw;                     // staged windows [w0, w0 + nw)          (basefc)
     int32_t  k0, nk;                     // staged SNPs    [k0, k0 + nk)          (pileup)
     uint32_t count;                      // entries currently in the set / queue
+    uint32_t nuniq;                      // regions in the tile's duplicate-free list (dense basefc path)
+    uint32_t wuor[2 * (JOIN_BLOCK / 64)];  // per-wave OR of the UMI codes
     uint32_t wcnt[JOIN_BLOCK / 64];
     unsigned long long base;
     __device__ K* keys() { return reinterpret_cast<K*>(store); }
@@ -199,7 +232,7 @@ __device__ __forceinline__ RawRead fetch_read(const BatchDesc& d, int i) {
 // filter + CIGAR summary of a read (endpos = htslib bam_endpos, n_al = len(read.positions))
 template <class K, int MODE>
 __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const RawRead& w) {
-    ReadInfo r; r.ok = false; r.pos = 0; r.endpos = 0; r.n_al = 0; r.c0 = r.c1 = 0; r.cell = -1; r.umi = 0;
+    ReadInfo r; r.ok = false; r.pos = 0; r.endpos = 0; r.n_al = 0; r.c0 = r.c1 = 0; r.cell = -1; r.umi = 0; r.m_rej = 0; r.m_acc = 0;
     if (!w.valid) return r;
     uint32_t flag = w.flag;
     int32_t mapq = w.mapq;
@@ -224,13 +257,16 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchD
     r.endpos = r.pos + rlen;
     r.n_al = n_al;
     r.ok = n_al >= a.f.min_len;
+    if (MODE == XCK_MODE_BASEFC && a.f.frac_mode) frac_bounds(r, a.f.min_inc_frac);
     return r;
 }
 
 // __get_include_len(): aligned bases with s0 <= p < e0
 template <class K, int MODE>
 __device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const ReadInfo& r, int32_t s0, int32_t e0) {
-    if (r.pos >= s0 && r.endpos <= e0) return r.n_al;
+    if ((XCK_EXP & 4) || (r.pos >= s0 && r.endpos <= e0)) return r.n_al;
+    // no D / N in the CIGAR (reference span == aligned length): the aligned bases are one block, no walk needed
+    if (r.endpos - r.pos == r.n_al) return max(min(r.endpos, e0) - max(r.pos, s0), 0);
     int32_t p = r.pos, m = 0;
     for (uint32_t c = r.c0; c < r.c1; c++) {
         uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
@@ -273,12 +309,25 @@ __device__ __forceinline__ void emit_global(const JoinArgs<K>& a, K key, uint64_
     else atomicExch(&a.ctl[CTL_OVERFLOW], 1ull);
 }
 
+// slot of a 64-bit key: full-rate VALU only (a 64-bit multiply is four quarter-rate v_mul ops on CDNA)
+__device__ __forceinline__ uint32_t set_slot(unsigned long long kk) {
+#if XCK_HASH_MUL64
+    return (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (HS_SLOTS - 1);
+#else
+    const uint32_t lo = (uint32_t)kk, hi = (uint32_t)(kk >> 32);
+    uint32_t x = lo ^ ((hi << 9) | (hi >> 23));
+    x ^= x >> 15;
+    return (__umul24(x, 0x9E3779u) >> 12) & (HS_SLOTS - 1);
+#endif
+}
+
 template <class K, int MODE>
 __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, K key, uint64_t val) {
+    if (XCK_EXP & 1) return;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
         const unsigned long long kk = (unsigned long long)key;
-        uint32_t slot = (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (HS_SLOTS - 1);
+        uint32_t slot = set_slot(kk);
 #if !XCK_UNROLL_PROBE
 #pragma unroll 1
 #endif
@@ -300,6 +349,7 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
 template <class K, int MODE>
 __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (XCK_EXP & 8) return;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
         constexpr int PER_WAVE = HS_SLOTS / (JOIN_BLOCK / 64);
@@ -377,15 +427,41 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
             int32_t s0, e0, row;
             if (staged) { s0 = sm.st_a[k]; e0 = sm.st_b[k]; row = sm.st_c[k]; }
             else { s0 = as_global(a.win_s0)[k]; e0 = as_global(a.win_e0)[k]; row = as_global(a.win_row)[k]; }
+            row &= 0x7fffffff;
             if (w != max(w_lo, s0 >> WS)) continue;                 // report each (read, region) pair once
             if (!(r.pos < e0 && r.endpos > s0)) continue;           // htslib fetch overlap
             int32_t m = included_len(a, d, sm, r, s0, e0);
             if (a.f.frac_mode) {
                 if (r.n_al <= 0) continue;
                 // m == n gives exactly 1.0, never below a threshold in (0,1): skip the fp64 divide
-                if (m != r.n_al && (double)m / (double)r.n_al < a.f.min_inc_frac) continue;   // IEEE double, as m / float(n)
+                if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue;   // IEEE double, as m / float(n)
             } else if (m < a.f.min_inc_len) continue;
             emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
+            n_acc++;
+        }
+    }
+    return n_acc;
+}
+
+// per-read join over the GLOBAL tables for windows >= w_from; regions whose first window is below w_from belong
+// to the tile's staged duplicate-free list and are skipped here (w_from = 0: the plain per-read join)
+template <class K, int MODE>
+__device__ __forceinline__ uint32_t join_regions_global(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r, int32_t w_from) {
+    uint32_t n_acc = 0;
+    const int32_t w_lo = r.pos >> WS;
+    if (w_lo >= d.n_win) return 0;
+    const int32_t w_hi = min((r.endpos - 1) >> WS, d.n_win - 1);
+    for (int32_t w = max(w_lo, w_from); w <= w_hi; w++) {
+        const int32_t k0 = as_global(d.win_off)[w], k1 = as_global(d.win_off)[w + 1];
+        for (int32_t k = k0; k < k1; k++) {
+            const int32_t s0 = as_global(a.win_s0)[k], e0 = as_global(a.win_e0)[k];
+            const int32_t fw = s0 >> WS;
+            if (fw < w_from || w != max(w_lo, fw)) continue;
+            if (!(r.pos < e0 && r.endpos > s0)) continue;
+            const int32_t m = included_len(a, d, sm, r, s0, e0);
+            if (a.f.frac_mode) { if (r.n_al <= 0) continue; if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue; }
+            else if (m < a.f.min_inc_len) continue;
+            emit<K, MODE>(a, sm, a.kl.make((uint32_t)(as_global(a.win_row)[k] & 0x7fffffff), (uint32_t)r.cell, r.umi), 0);
             n_acc++;
         }
     }
@@ -420,7 +496,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (bt.desc[mid].tile0 <= t) lo = mid; else hi = mid - 1; }
     const BatchDesc& d = bt.desc[lo];
     TileMeta m;
-    m.b = lo; m.r0 = (t - d.tile0) * TILE; m.r1 = min(m.r0 + TILE, d.n); m.pad = 0;
+    m.b = lo; m.r0 = (t - d.tile0) * TILE; m.r1 = min(m.r0 + TILE, d.n); m.n0 = 0;
     const uint32_t c_lo = as_global(d.cig_off)[m.r0], c_hi = as_global(d.cig_off)[m.r1];
     const int32_t p_first = max(as_global(d.pos)[m.r0], 0), p_last = max(as_global(d.pos)[m.r1 - 1], 0);
     m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
@@ -432,6 +508,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
             int a_ = 0, z_ = nw_max;                              // largest nw with entries <= ST_CAP (offsets are monotone)
             while (a_ < z_) { int mid = (a_ + z_ + 1) >> 1; if (as_global(d.win_off)[m.w0 + mid] - e0 <= ST_CAP) a_ = mid; else z_ = mid - 1; }
             m.nw = a_; m.e0 = e0; m.n_ent = as_global(d.win_off)[m.w0 + a_] - e0;
+            m.n0 = a_ > 0 ? as_global(d.win_off)[m.w0 + 1] - e0 : 0;
         }
     } else {
         if (m.w0 < d.n_swin) { m.k0 = as_global(d.snp_win)[m.w0]; m.nk = min(d.snp_end - m.k0, ST_CAP); m.nw = min(d.n_swin - m.w0, ST_WIN); }
@@ -452,28 +529,55 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     // ---- prologue: one record from k_tile_meta, then ONE round of independent loads ----
     const XCK_GLOBAL TileMeta* mp = as_global(a.meta) + blockIdx.x;
     const uint32_t c_lo = mp->c_lo, cg_n = mp->cg_n;
-    const int32_t w0 = mp->w0, nw = mp->nw, e0 = mp->e0, n_ent = mp->n_ent, k0 = mp->k0, nk = mp->nk;
+    const int32_t w0 = mp->w0, nw = mp->nw, e0 = mp->e0, n_ent = mp->n_ent, k0 = mp->k0, nk = mp->nk, n0 = mp->n0;
+    constexpr bool DENSE = XCK_DENSE && MODE == XCK_MODE_BASEFC && JoinSmem<K, MODE>::USE_SET;
     const int b = __builtin_amdgcn_readfirstlane(mp->b);
     const int tile0 = __builtin_amdgcn_readfirstlane(mp->r0);
     const BatchDesc& d = a.bt.desc[b];                                // kernarg: scalar loads through the constant cache
+    unsigned long long uor = 0;
     STAMP(0);
-    RawRead nxt = fetch_read(d, tile0 + tid);                         // first sweep's loads overlap the staging
+    RawRead nxt; RawRead W[TILE_ITEMS];
+    if (DENSE || XCK_PREFETCH_ALL) {
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read(d, tile0 + j * JOIN_BLOCK + tid);   // the whole tile's loads fly during the staging
+    } else nxt = fetch_read(d, tile0 + tid);                           // first sweep's loads overlap the staging
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
         for (int s = tid; s < HS_SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; }
-    for (uint32_t c = tid; c < cg_n; c += JOIN_BLOCK) sm.cig[c] = as_global(d.cigar)[c_lo + c];
+    if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; sm.nuniq = 0; }
+    if (DENSE) __syncthreads();                                      // nuniq must be 0 before the appends below
+    // Every global load of the prologue is issued BEFORE the first LDS store: written as load/store loops the
+    // compiler waits (s_waitcnt vmcnt(0)) inside each iteration, which serialised ~7 HBM round trips per tile.
+    static_assert(ST_CAP <= JOIN_BLOCK && ST_WIN + 1 <= JOIN_BLOCK, "staging assumes one element per thread");
+    constexpr int CG_IT = (CG_CAP + JOIN_BLOCK - 1) / JOIN_BLOCK;
+    uint32_t cw[CG_IT];
+#pragma unroll
+    for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; cw[q] = c < cg_n ? as_global(d.cigar)[c_lo + c] : 0u; }
+    int32_t g_a = 0, g_b = 0, g_c = 0, g_w = 0;
     if (MODE == XCK_MODE_BASEFC) {
         if (nw > 0) {
-            for (int32_t t = tid; t <= nw; t += JOIN_BLOCK) sm.st_w[t] = as_global(d.win_off)[w0 + t] - e0;
-            for (int32_t t = tid; t < n_ent; t += JOIN_BLOCK) {
-                sm.st_a[t] = as_global(a.win_s0)[e0 + t]; sm.st_b[t] = as_global(a.win_e0)[e0 + t]; sm.st_c[t] = as_global(a.win_row)[e0 + t];
-            }
+            if (tid < n_ent) { g_a = as_global(a.win_s0)[e0 + tid]; g_b = as_global(a.win_e0)[e0 + tid]; g_c = as_global(a.win_row)[e0 + tid]; }
+            if (!DENSE && tid <= nw) g_w = as_global(d.win_off)[w0 + tid] - e0;
         }
     } else {
-        for (int32_t t = tid; t < nk; t += JOIN_BLOCK) sm.st_a[t] = as_global(a.snp_p0)[k0 + t];
-        for (int32_t t = tid; t < nw; t += JOIN_BLOCK) sm.st_w[t] = as_global(d.snp_win)[w0 + t];     // first SNP of each window
+        if (tid < nk) g_a = as_global(a.snp_p0)[k0 + tid];
+        if (tid < nw) g_w = as_global(d.snp_win)[w0 + tid];           // first SNP of each window
+    }
+#pragma unroll
+    for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; if (c < cg_n) sm.cig[c] = cw[q]; }
+    if (MODE == XCK_MODE_BASEFC) {
+        if (nw > 0 && DENSE) {
+            // duplicate-free region list of the tile: an entry counts in window w0, or in the first window of its region
+            if (tid < n_ent && (tid < n0 || g_c < 0)) { const uint32_t u = atomicAdd(&sm.nuniq, 1u);
+                sm.st_a[u] = g_a; sm.st_b[u] = g_b; sm.st_c[u] = g_c & 0x7fffffff; }
+        } else if (nw > 0) {
+            if (tid <= nw) sm.st_w[tid] = g_w;
+            if (tid < n_ent) { sm.st_a[tid] = g_a; sm.st_b[tid] = g_b; sm.st_c[tid] = g_c; }
+        }
+    } else {
+        if (tid < nk) sm.st_a[tid] = g_a;
+        if (tid < nw) sm.st_w[tid] = g_w;
     }
     STAMP(1);
     __syncthreads();
@@ -489,6 +593,42 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     // (better de-duplication, half the cursor atomics); saturation still spills correctly through emit_global()
     constexpr int FLUSH_EVERY = (XCK_FLUSH_END_ONLY && JoinSmem<K, MODE>::USE_SET) ? TILE_ITEMS
                               : ((CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)));
+    if (DENSE) {
+        // ---- region-major evaluation: every thread keeps its 4 reads in registers; the loop over the tile's
+        //      duplicate-free region list is UNIFORM (same trip count in every lane, broadcast LDS reads), so the
+        //      divergent per-read window / candidate loops disappear from the common path
+        ReadInfo R[TILE_ITEMS]; bool in_list[TILE_ITEMS];
+        const int32_t w_end = nw > 0 ? w0 + nw : 0;                   // first window that is NOT covered by the list
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; j++) {
+            R[j] = load_read<K, MODE>(a, d, sm, W[j]);
+            if (R[j].ok) uor |= R[j].umi;
+            in_list[j] = R[j].ok && nw > 0 && (R[j].pos >> WS) >= w0;  // reads before the staged range (unsorted input) go global
+        }
+        const int32_t nu = (XCK_EXP & 16) ? 0 : (int32_t)sm.nuniq;
+        for (int32_t k = 0; k < nu; k++) {
+            const int32_t s0 = sm.st_a[k], e0r = sm.st_b[k], row = sm.st_c[k];
+#pragma unroll
+            for (int j = 0; j < TILE_ITEMS; j++) {
+                const ReadInfo& r = R[j];
+                if (!in_list[j] || !(r.pos < e0r && r.endpos > s0)) continue;
+                const int32_t m = included_len(a, d, sm, r, s0, e0r);
+                if (a.f.frac_mode) { if (r.n_al <= 0) continue; if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue; }
+                else if (m < a.f.min_inc_len) continue;
+                emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
+                acc++;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; j++) {                         // what the list does not cover (rare)
+            const ReadInfo& r = R[j];
+            if (!r.ok) continue;
+            if (!in_list[j]) acc += join_regions_global<K, MODE>(a, d, sm, r, 0);
+            else if (((r.endpos - 1) >> WS) >= w_end) acc += join_regions_global<K, MODE>(a, d, sm, r, w_end);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        flush<K, MODE>(a, sm);
+    } else
 #if XCK_UNROLL_TILE
 #pragma unroll
 #else
@@ -496,10 +636,11 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
 #endif
     for (int j = 0; j < TILE_ITEMS; j++) {
         const int i = tile0 + j * JOIN_BLOCK + tid;
-        const RawRead cur = nxt;
-        if (j + 1 < TILE_ITEMS) nxt = fetch_read(d, i + JOIN_BLOCK);      // next sweep's loads fly during this sweep's work
+        const RawRead cur = XCK_PREFETCH_ALL ? W[j] : nxt;
+        if (!XCK_PREFETCH_ALL && j + 1 < TILE_ITEMS) nxt = fetch_read(d, i + JOIN_BLOCK);      // next sweep's loads fly during this sweep's work
         ReadInfo r = load_read<K, MODE>(a, d, sm, cur);
         if (r.ok) {
+            uor |= r.umi;
             if (MODE == XCK_MODE_BASEFC) acc += join_regions<K, MODE>(a, d, sm, r);
             else acc += join_snps<K, MODE>(a, d, sm, r, i);
         }
@@ -518,8 +659,22 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     // accepted (read, region|SNP) pairs before the LDS de-duplication: the algorithmic unit of the join
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd, 64);
+    if (MODE == XCK_MODE_BASEFC) {
+        // highest UMI-code bit in use: finish() drops the dead bits between the UMI codes and the cell field before the sort
+        uint32_t ulo = (uint32_t)uor, uhi = (uint32_t)(uor >> 32);
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { ulo |= __shfl_xor(ulo, dd, 64); uhi |= __shfl_xor(uhi, dd, 64); }
+        if (lane == 0) { sm.wuor[2 * (tid >> 6)] = ulo; sm.wuor[2 * (tid >> 6) + 1] = uhi; }
+    }
     if (lane == 0) sm.wcnt[tid >> 6] = acc;
     __syncthreads();
+    if (tid == 0 && MODE == XCK_MODE_BASEFC) {
+        uor = 0;
+#pragma unroll
+        for (int w = 0; w < JOIN_BLOCK / 64; w++) uor |= ((unsigned long long)sm.wuor[2 * w + 1] << 32) | sm.wuor[2 * w];
+        // one word per shard, on the shard cursor's cache line (a single shared word serialises at ~90 atomics/us)
+        if (uor) atomicOr(&a.ctl[ctl_umi_or(blockIdx.x & (NSHARD - 1))], uor);
+    }
     if (tid == 0) { acc = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
                     if (acc) atomicAdd(&a.ctl[ctl_accepted(blockIdx.x & (NSHARD - 1))], (unsigned long long)acc); }
     STAMP(6);
@@ -943,6 +1098,10 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
     {   // window-list entries carry their region inline (one load level less in the join)
         std::vector<int32_t> ws0(win_list.size()), we0(win_list.size()), wrow(win_list.size());
         for (size_t k = 0; k < win_list.size(); k++) { int32_t g = win_list[k]; ws0[k] = reg_s0[g]; we0[k] = reg_e0[g]; wrow[k] = reg_row[g]; }
+        // top bit of the row: this entry sits in the FIRST window of its region (lets a tile build a duplicate-free list)
+        for (int c = 0; c < nc; c++) { const ContigTab& t = im->ctab[c];
+            for (int32_t w = 0; w < t.n_win; w++) for (int32_t k = win_off[t.win_base + w]; k < win_off[t.win_base + w + 1]; k++)
+                if ((ws0[k] >> WS) == w) wrow[k] |= (int32_t)0x80000000; }
         if ((rc = dev_upload(im, &im->d_win_s0, ws0))) return rc;
         if ((rc = dev_upload(im, &im->d_win_e0, we0))) return rc;
         if ((rc = dev_upload(im, &im->d_win_row, wrow))) return rc;
@@ -1253,6 +1412,22 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
     return copy_out(im, m, d_o, total);
 }
 
+// shard slices -> one contiguous array, with the UMI field narrowed from `ubits` to `used` bits (the row and cell
+// fields move down): every dead bit removed is one bit the radix sort does not have to pass over
+struct ShardSpan { unsigned long long start[NSHARD + 1]; };
+__global__ void __launch_bounds__(256) k_pack_squeeze(const unsigned long long* __restrict__ src, unsigned long long cap, ShardSpan sp,
+                                                        int ubits, int used, unsigned long long* __restrict__ dst) {
+    const unsigned long long n = sp.start[NSHARD];
+    const unsigned long long lowmask = (1ull << used) - 1;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        int sh = 0;
+#pragma unroll
+        for (int q = 1; q < NSHARD; q++) sh += (i >= sp.start[q]) ? 1 : 0;
+        const unsigned long long k = src[(unsigned long long)sh * cap + (i - sp.start[sh])];
+        dst[i] = ((k >> ubits) << used) | (k & lowmask);
+    }
+}
+
 // copy the used prefix of every shard slice into one contiguous array (sort input)
 template <class K>
 static int pack_shards(EngineImpl* im, K* dst_keys, uint64_t* dst_vals) {
@@ -1292,8 +1467,18 @@ static int finish_t(EngineImpl* im) {
         if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + nb * 12 + n * 12 + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb);
         if ((rc = tm.start())) return rc;
+        int used = im->ubits;                                                       // UMI bits actually in use
+        if (sizeof(K) == 8) { unsigned long long uor = 0; for (int sh = 0; sh < NSHARD; sh++) uor |= im->h_ctl[ctl_umi_or(sh)]; used = uor ? 64 - __builtin_clzll(uor) : 1; if (used > im->ubits) used = im->ubits; }
+        if (used < im->ubits) {
+            ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
+            hipLaunchKernelGGL(k_pack_squeeze, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, im->s_comp,
+                               (const unsigned long long*)im->d_keys, (unsigned long long)im->hit_cap, sp, im->ubits, used, (unsigned long long*)alt);
+            HIP_TRY(hipGetLastError());
+            kl.ubits = used;
+        } else
         if ((rc = pack_shards(im, alt, (uint64_t*)nullptr))) return rc;             // shard slices -> contiguous
-        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top))) return rc;
+        const int top_fc = kl.ubits + im->cbits + im->rbits;
+        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top_fc))) return rc;
         if ((rc = fold_coo<K>(im, im->ws1, keys, n, kl, 0))) return rc;
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
