@@ -723,30 +723,56 @@ __global__ __launch_bounds__(FD_BLOCK) void k_fold_heads(const K* __restrict__ k
 template <class K>
 __global__ __launch_bounds__(FD_BLOCK) void k_fold_emit(const K* __restrict__ k, long long n, KeyLayout<K> kl, const unsigned long long* __restrict__ off,
                                                         int32_t* __restrict__ row, int32_t* __restrict__ col, int32_t* __restrict__ val) {
+    // val[] is zero on entry.  A tile knows the distinct keys of every (row, cell) run that STARTS in it only up to
+    // the tile end; what a later tile holds of that run (its "lead": distinct keys before its first head) is added
+    // with one atomicAdd to the slot of the last head before it.  No thread ever walks a run, so a hot (gene, cell)
+    // pair with thousands of UMIs costs the same per key as a cold one.
     __shared__ uint32_t s_wave[FD_BLOCK / 64];
     __shared__ K tile[FD_TILE + 1];                                       // tile[0] = key before the tile (halo)
+    __shared__ uint16_t s_hx[FD_TILE + 1], s_he[FD_TILE];                 // per head: distinct keys before it / its element
     const long long base = (long long)blockIdx.x * FD_TILE;
     const int n_loc = (int)min((long long)FD_TILE, n - base);
 #pragma unroll
     for (int t = 0; t < FD_ITEMS; t++) { const int e = t * FD_BLOCK + threadIdx.x; if (e < n_loc) tile[1 + e] = k[base + e]; }
     if (threadIdx.x == 0) tile[0] = base > 0 ? k[base - 1] : K(0);
     __syncthreads();
-    unsigned long long out = off[blockIdx.x];
-    for (int t = 0; t < FD_ITEMS; t++) {                                  // element order = sweep order, so offsets stay sorted
-        const int e = t * FD_BLOCK + threadIdx.x;
-        K me = K(0); bool head = false;
-        if (e < n_loc) { me = tile[1 + e]; head = (base + e == 0) || kl.rc(me) != kl.rc(tile[e]); }
-        uint32_t total;
-        const uint32_t excl = block_excl_scan(head ? 1u : 0u, s_wave, total);
-        if (head) {
-            const K rc = kl.rc(me);
-            int32_t cnt = 1; K last = me; int j = e + 1; bool open = true;
-            for (; j < n_loc; j++) { const K x = tile[1 + j]; if (kl.rc(x) != rc) { open = false; break; } if (x != last) { cnt++; last = x; } }
-            if (open) for (long long g = base + n_loc; g < n; g++) { const K x = k[g]; if (kl.rc(x) != rc) break; if (x != last) { cnt++; last = x; } }
-            const unsigned long long d = out + excl;
-            row[d] = (int32_t)kl.row(me); col[d] = (int32_t)kl.cell(me); val[d] = cnt;
+    // blocked arrangement: thread t owns elements [t*FD_ITEMS, (t+1)*FD_ITEMS)
+    const int e0 = threadIdx.x * FD_ITEMS;
+    uint32_t hmask = 0, dmask = 0;
+    K prev = tile[e0];
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        const int e = e0 + q;
+        if (e < n_loc) {
+            const K me = tile[1 + e];
+            const bool first = base + e == 0;
+            if (first || kl.rc(me) != kl.rc(prev)) hmask |= 1u << q;
+            if (first || me != prev) dmask |= 1u << q;
+            prev = me;
         }
-        out += total;
+    }
+    uint32_t total;
+    const uint32_t excl = block_excl_scan((uint32_t)__popc(hmask) | ((uint32_t)__popc(dmask) << 16), s_wave, total);
+    const uint32_t n_heads = total & 0xffffu, n_dist = total >> 16;
+    uint32_t r = excl & 0xffffu, xd = excl >> 16;
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        if (hmask & (1u << q)) { s_hx[r] = (uint16_t)xd; s_he[r] = (uint16_t)(e0 + q); r++; }
+        if (dmask & (1u << q)) xd++;
+    }
+    if (threadIdx.x == 0) s_hx[n_heads] = (uint16_t)n_dist;
+    __syncthreads();
+    const unsigned long long out = off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n_heads; i += FD_BLOCK) {
+        const K me = tile[1 + s_he[i]];
+        const int32_t cnt = (int32_t)s_hx[i + 1] - (int32_t)s_hx[i];
+        const unsigned long long d = out + i;
+        row[d] = (int32_t)kl.row(me); col[d] = (int32_t)kl.cell(me);
+        if (i + 1 == n_heads) atomicAdd(&val[d], cnt); else val[d] = cnt;  // the last run may continue in later tiles
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t lead = n_heads ? s_hx[0] : n_dist;
+        if (lead && out > 0) atomicAdd(&val[out - 1], (int32_t)lead);
     }
 }
 
@@ -1407,6 +1433,7 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
     int rc = res_reserve(im, m, total); if (rc) return rc;
     int32_t* d_o = ws.get<int32_t>(total * 3);
     if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
+    HIP_TRY(hipMemsetAsync(d_o + 2 * total, 0, total * sizeof(int32_t), im->s_comp));       // k_fold_emit accumulates run pieces into val[]
     hipLaunchKernelGGL((k_fold_emit<K>), dim3(nb), dim3(FD_BLOCK), 0, im->s_comp, keys, (long long)n, kl, d_off, d_o, d_o + total, d_o + 2 * total);
     HIP_TRY(hipGetLastError());
     return copy_out(im, m, d_o, total);
