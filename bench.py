@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--genes", type=int, default=33472)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--serial", action="store_true", help="no overlap between the basefc and pileup engines")
+    ap.add_argument("--depth", type=int, default=2, help="basefc engines used in rotation: the copy-out of pass i drains while pass i+1 computes (1 = overlap with the pileup pass only)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -81,7 +82,8 @@ def main():
     data_checksum = [int(arrays["pos"].to(torch.int64).sum().item()), int((arrays["umi"] & 0xFFFFFF).sum().item()),
                      int(arrays["cell"].to(torch.int64).sum().item())]
     filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
-    eng_fc = Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=dev_idx, min_include=0.9, **filt)
+    depth = 1 if args.serial else max(1, args.depth)
+    engs_fc = [Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=dev_idx, min_include=0.9, **filt) for _ in range(depth)]
     eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=dev_idx,
                      min_count=1, min_maf=0, no_dup_hap=True, **filt)
     b_fc = [soa_torch.device_batch(capi, arrays, c, s, e, False) for c, s, e in batches]
@@ -93,33 +95,61 @@ def main():
             eng.push(b, device_resident=True)             # queued; fused into one launch
         eng.flush()                                        # join kernel done (timed on its own stream)
 
-    def step():
-        # basefc and pileup are independent engines (own streams, own accumulators).  The basefc fold ends
-        # with a 170 MB copy-out of the count matrix over PCIe: it is only ENQUEUED (xck_finish_async), the
-        # whole pileup pass then runs on the CUs while the copy engine drains it, and xck_finish collects it.
-        out = {}
+    acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0, ms_d2h_fc=0.0)
+    last = {}                                              # latest host views of the four matrices + stats
+    pending = []                                           # basefc engines whose copy-out is still in flight
+
+    def collect_fc(eng):
+        last.update(eng.finish(copy=False))                # waits for the copy stream; views of the pinned result buffers
+        st = eng.stats(); last["sfc"] = st
+        acc["ms_join_fc"] += st["ms_join"]; acc["ms_fin_fc"] += st["ms_sort"]; acc["ms_d2h_fc"] += st["ms_d2h"]
+
+    def pass_fc(i):
+        eng_fc = engs_fc[i % depth]
         push_all(eng_fc, b_fc)
         if args.serial:
-            out.update(eng_fc.finish(copy=False))          # views of the pinned result buffers
-            push_all(eng_baf, b_baf)
-            out.update(eng_baf.finish(copy=False))
+            collect_fc(eng_fc)
         else:
-            eng_fc.finish_async()
-            push_all(eng_baf, b_baf)
-            out.update(eng_baf.finish(copy=False))
-            out.update(eng_fc.finish(copy=False))
+            eng_fc.finish_async(); pending.append(eng_fc)
+        return eng_fc
+
+    def pass_baf():
+        push_all(eng_baf, b_baf)
+        last.update(eng_baf.finish(copy=False))
+        st = eng_baf.stats(); last["sbaf"] = st
+        acc["ms_join_baf"] += st["ms_join"]; acc["ms_fin_baf"] += st["ms_sort"]
+
+    def step(i):
+        # basefc and pileup are independent engines (own handles, streams and accumulators).  The basefc
+        # fold ends with a 170 MB copy-out of the count matrix over PCIe (~3 ms): it is only ENQUEUED (xck_finish_async)
+        # and drains on the copy stream while the CUs run the pileup pass and - with --depth 2, two basefc engines used
+        # in rotation, as a multi-sample run does - the next pass's join and fold.  Every pass's matrices are collected
+        # (xck_finish) inside the timed region, at the latest in sync().
+        # (driving the two passes from two host threads was measured: the kernels of both passes then share the CUs
+        # and the step gets slower, 5.2 vs 4.7 ms)
+        eng_fc = pass_fc(i)
+        pass_baf()
         if world > 1:
             # all-gatherv of the per-contig sparse blocks to the writer rank, GPU to GPU over xGMI (RCCL): sizes
             # first, then ONE gather of the padded [row|col|val] blocks that are still resident in HBM.  It is only
             # enqueued here and overlaps the next pass (collected before the next exchange and at the end of the
-            # run).  Every rank has also delivered its own row range to pinned host memory (out) over its own PCIe link.
+            # run).  Every rank has also delivered its own row range to pinned host memory over its own PCIe link.
             blocks = dict(eng_fc.result_device()); blocks.update(eng_baf.result_device())
-            out["_gathered_sizes"] = gatherer.start(blocks)
-        return out
+            last["_gathered_sizes"] = gatherer.start(blocks)
+        while len(pending) > depth - 1:
+            collect_fc(pending.pop(0))
+
+    # setup, not a step: every engine sizes its device buffers on first use (hit buffers grow by replay, workspaces
+    # and pinned result buffers are allocated) - do that once per engine before the warmup passes
+    for e in engs_fc:
+        push_all(e, b_fc); e.finish(copy=False)
+    push_all(eng_baf, b_baf); eng_baf.finish(copy=False)
 
     gatherer = BlockGatherer(world, rank, device, backend_is_nccl=not shared_gpu) if world > 1 else None
 
     def sync():
+        while pending:
+            collect_fc(pending.pop(0))
         if gatherer is not None:
             gatherer.wait()                               # the last exchange is inside the timed region
         torch.cuda.synchronize()
@@ -127,18 +157,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
+    for i in range(args.warmup):
+        step(i)
     sync()
-    acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0, ms_d2h_fc=0.0)
+    for kk in acc:
+        acc[kk] = 0.0                                      # HIP-event stage times of the timed passes only
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        sfc, sbaf = eng_fc.stats(), eng_baf.stats()     # HIP-event times of this step (reset() clears them)
-        acc["ms_join_fc"] += sfc["ms_join"]; acc["ms_fin_fc"] += sfc["ms_sort"]; acc["ms_d2h_fc"] += sfc["ms_d2h"]
-        acc["ms_join_baf"] += sbaf["ms_join"]; acc["ms_fin_baf"] += sbaf["ms_sort"]
-    sync()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()                                                 # collects the last pass's matrices: inside the timed region
     dt = time.perf_counter() - t0
+    res, sfc, sbaf = last, last["sfc"], last["sbaf"]
     t = torch.tensor([dt], dtype=torch.float64, device=gather_device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -218,7 +247,7 @@ def main():
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64", data="synthetic",
                 config=dict(workload="BASELINE.json configs[1]: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
                                      "basefc + pileup per step, SoA resident in HBM" % (n_reads, args.cells, len(snps), len(regions)),
-                            reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world,
+                            reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world, pipeline="serial" if args.serial else "copy-out overlapped, %d basefc engine(s) in rotation" % depth,
                             nnz={kk: (int(sum(sz[j] for sz in res["_gathered_sizes"])) if world > 1 else int(len(res[kk][0]))) for j, kk in enumerate(("count", "ad", "dp", "oth"))},
                             hits=dict(basefc=int(hits_fc), pileup=int(hits_baf),
                                       basefc_after_lds_dedup=int(sfc["n_hits_unique"]))),

@@ -129,7 +129,10 @@ static_assert(sizeof(JoinArgs<unsigned __int128>) <= 4000, "kernel arguments mus
 // its own slice [shard*cap, (shard+1)*cap) of the hit buffer; finish() packs the slices.
 constexpr int NSHARD = 16;
 constexpr int CTL_OVERFLOW = 1, CTL_SCRATCH = 3, CTL_SHARD0 = 16, CTL_STRIDE = 16;
-constexpr int CTL_WORDS = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
+constexpr int XSHARD = 32;                 // k_expand: sharded totals / cursors (one shared word serialises at ~90 atomics/us)
+constexpr int CTL_X0 = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
+constexpr int CTL_WORDS = CTL_X0 + XSHARD * CTL_STRIDE;
+struct XBases { unsigned long long base[XSHARD]; };
 __host__ __device__ inline int ctl_cursor(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE; }
 __host__ __device__ inline int ctl_umi_or(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE + 1; }   // OR of the UMI codes seen
 __host__ __device__ inline int ctl_accepted(int shard) { return CTL_SHARD0 + (NSHARD + shard) * CTL_STRIDE; }
@@ -814,7 +817,7 @@ template <class K, bool EMIT>
 __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, const uint8_t* __restrict__ al, long long n,
                                   KeyLayout<K> kl, const uint32_t* __restrict__ tally, const uint32_t* __restrict__ info,
                                   SnpFilter f, const int32_t* __restrict__ csr_off, const int32_t* __restrict__ csr_reg,
-                                  K* __restrict__ k2, uint8_t* __restrict__ v2, unsigned long long* ctl) {
+                                  K* __restrict__ k2, uint8_t* __restrict__ v2, unsigned long long* ctl, XBases xb) {
     __shared__ uint32_t s_wave[JOIN_BLOCK / 64];
     __shared__ unsigned long long s_base;
     long long i = (long long)blockIdx.x * JOIN_BLOCK + threadIdx.x;
@@ -829,7 +832,10 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
     uint32_t total;
     uint32_t excl = block_excl_scan(cnt, s_wave, total);
     if (total == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&ctl[0], (unsigned long long)total);
+    // count pass: per-shard totals in word 0 of the shard's line; emit pass: per-shard cursor in word 1, inside the
+    // shard's slice [xb.base[sh], xb.base[sh] + total_sh) of the output (the order of k2 is irrelevant: it is sorted next)
+    const int sh = blockIdx.x & (XSHARD - 1);
+    if (threadIdx.x == 0) s_base = xb.base[sh] + atomicAdd(&ctl[CTL_X0 + sh * CTL_STRIDE + (EMIT ? 1 : 0)], (unsigned long long)total);
     if (!EMIT) return;
     __syncthreads();
     if (!cnt) return;
@@ -1519,15 +1525,16 @@ static int finish_t(EngineImpl* im) {
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
         hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, im->d_tally);
         HIP_TRY(hipGetLastError());
-        unsigned long long zero = 0;
-        HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_SCRATCH, 0, sizeof zero, im->s_comp));
+        XBases xb; memset(&xb, 0, sizeof xb);
+        HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_X0, 0, XSHARD * CTL_STRIDE * sizeof(unsigned long long), im->s_comp));
         hipLaunchKernelGGL((k_expand<K, false>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (uint8_t*)nullptr, im->d_ctl + CTL_SCRATCH);
+                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (uint8_t*)nullptr, im->d_ctl, xb);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->d_hctl + CTL_SCRATCH, 1);
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_X0), im->d_hctl + CTL_X0, XSHARD * CTL_STRIDE);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(im->s_comp));
-        const size_t n2 = im->h_ctl[CTL_SCRATCH];
+        size_t n2 = 0;
+        for (int sh = 0; sh < XSHARD; sh++) { xb.base[sh] = n2; n2 += im->h_ctl[CTL_X0 + sh * CTL_STRIDE]; }
         if (n2 >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 region hits"; return XCK_E_CAPACITY; }
         if (n2) {
             const size_t tmpb2 = sort_tmp_bytes<K, uint8_t>(n2, top);
@@ -1535,9 +1542,8 @@ static int finish_t(EngineImpl* im) {
             if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + (1 << 16)))) return rc;
             K* k2 = im->ws2.get<K>(n2); K* k2b = im->ws2.get<K>(n2); uint8_t* v2 = im->ws2.get<uint8_t>(n2); uint8_t* v2b = im->ws2.get<uint8_t>(n2);
             void* tmp2 = im->ws2.get<char>(tmpb2); int32_t* dense = im->ws2.get<int32_t>(3 * n2);
-            HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_SCRATCH, 0, sizeof zero, im->s_comp));
             hipLaunchKernelGGL((k_expand<K, true>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                               im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl + CTL_SCRATCH);
+                               im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
             HIP_TRY(hipGetLastError());
             if ((rc = sort_run<K, uint8_t>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
             const unsigned gs2 = (unsigned)((n2 + 255) / 256);
