@@ -89,18 +89,27 @@ def main():
     b_fc = [soa_torch.device_batch(capi, arrays, c, s, e, False) for c, s, e in batches]
     b_baf = [soa_torch.device_batch(capi, arrays, c, s, e, True) for c, s, e in batches]
 
+    host = dict(reset=0.0, push=0.0, flush=0.0, fin_async=0.0, fin_baf=0.0, collect=0.0)   # host wall time per call site
+
     def push_all(eng, bs):
+        t_a = time.perf_counter()
         eng.reset()
+        t_b = time.perf_counter()
         for b in bs:
             eng.push(b, device_resident=True)             # queued; fused into one launch
+        t_c = time.perf_counter()
         eng.flush()                                        # join kernel done (timed on its own stream)
+        t_d = time.perf_counter()
+        host["reset"] += t_b - t_a; host["push"] += t_c - t_b; host["flush"] += t_d - t_c
 
     acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0, ms_d2h_fc=0.0)
     last = {}                                              # latest host views of the four matrices + stats
     pending = []                                           # basefc engines whose copy-out is still in flight
 
     def collect_fc(eng):
+        t_a = time.perf_counter()
         last.update(eng.finish(copy=False))                # waits for the copy stream; views of the pinned result buffers
+        host["collect"] += time.perf_counter() - t_a
         st = eng.stats(); last["sfc"] = st
         acc["ms_join_fc"] += st["ms_join"]; acc["ms_fin_fc"] += st["ms_sort"]; acc["ms_d2h_fc"] += st["ms_d2h"]
 
@@ -110,12 +119,16 @@ def main():
         if args.serial:
             collect_fc(eng_fc)
         else:
+            t_a = time.perf_counter()
             eng_fc.finish_async(); pending.append(eng_fc)
+            host["fin_async"] += time.perf_counter() - t_a
         return eng_fc
 
     def pass_baf():
         push_all(eng_baf, b_baf)
+        t_a = time.perf_counter()
         last.update(eng_baf.finish(copy=False))
+        host["fin_baf"] += time.perf_counter() - t_a
         st = eng_baf.stats(); last["sbaf"] = st
         acc["ms_join_baf"] += st["ms_join"]; acc["ms_fin_baf"] += st["ms_sort"]
 
@@ -162,6 +175,8 @@ def main():
     sync()
     for kk in acc:
         acc[kk] = 0.0                                      # HIP-event stage times of the timed passes only
+    for kk in host:
+        host[kk] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -204,7 +219,8 @@ def main():
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     launches_per_step=n_launch, avg_launch_ms=round(avg_ms, 4),
                     algorithmic_bytes_per_launch=int(dom[2] / n_launch),
-                    stage_ms_per_step={a: round(b, 3) for a, b in k.items()})
+                    stage_ms_per_step={a: round(b, 3) for a, b in k.items()},
+                    host_ms_per_step={a: round(b / args.steps * 1e3, 3) for a, b in host.items()})
 
     # ---- CPU baseline: the oracle (C restatement of the reference's per-region loops), 1 core ----
     cpu = None

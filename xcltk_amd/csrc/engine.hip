@@ -895,12 +895,33 @@ __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned l
 __global__ void k_copy_words(const int32_t* __restrict__ src, int32_t* __restrict__ host_alias, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) host_alias[i] = src[i];
 }
+struct ShardSpan { unsigned long long start[NSHARD + 1]; };               // first packed index of every shard slice
+struct CopySeg3 { const int32_t* src[3]; int32_t* dst[3]; size_t n[3]; };
+__global__ void k_copy_words3(CopySeg3 sg) {                              // blockIdx.y = segment
+    const int32_t* __restrict__ src = sg.src[blockIdx.y]; int32_t* __restrict__ dst = sg.dst[blockIdx.y]; const size_t n = sg.n[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// shard slices of (key, value) pairs -> contiguous arrays, one launch (the shard count would be that many copy commands)
+template <class K>
+__global__ void __launch_bounds__(256) k_pack_pairs(const K* __restrict__ sk, const uint64_t* __restrict__ sv, unsigned long long cap, ShardSpan sp,
+                                                      K* __restrict__ dk, uint64_t* __restrict__ dv) {
+    const unsigned long long n = sp.start[NSHARD];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        int sh = 0;
+#pragma unroll
+        for (int q = 1; q < NSHARD; q++) sh += (i >= sp.start[q]) ? 1 : 0;
+        const unsigned long long j = (unsigned long long)sh * cap + (i - sp.start[sh]);
+        dk[i] = sk[j]; dv[i] = sv[j];
+    }
+}
 
 // ordered compaction of the non-zero entries of a dense int32 array into COO --------------------
 constexpr int CP_BLOCK = 256, CP_ITEMS = 8, CP_TILE = CP_BLOCK * CP_ITEMS;
 
+// (the three haplotype matrices AD / DP / OTH are compacted together: blockIdx.y = matrix, dense arrays n apart)
 __global__ __launch_bounds__(CP_BLOCK) void k_cp_count(const int32_t* __restrict__ v, long long n, uint32_t* __restrict__ blk) {
     __shared__ uint32_t s_wave[CP_BLOCK / 64];
+    v += (long long)blockIdx.y * n; blk += (size_t)blockIdx.y * gridDim.x;
     long long base = (long long)blockIdx.x * CP_TILE;
     uint32_t c = 0;
     for (int t = 0; t < CP_ITEMS; t++) { long long i = base + t * CP_BLOCK + threadIdx.x; if (i < n && v[i] > 0) c++; }
@@ -915,6 +936,7 @@ __global__ __launch_bounds__(1024) void k_cp_scan(const uint32_t* __restrict__ b
                                                   unsigned long long* out_total) {
     __shared__ unsigned long long s_w[16];
     __shared__ unsigned long long s_carry;
+    blk += (long long)blockIdx.x * nb; off += (long long)blockIdx.x * nb; out_total += blockIdx.x;   // one block per matrix
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (long long b0 = 0; b0 < nb; b0 += 1024) {
@@ -935,11 +957,13 @@ __global__ __launch_bounds__(1024) void k_cp_scan(const uint32_t* __restrict__ b
     if (threadIdx.x == 0) *out_total = s_carry;
 }
 
+struct CooOut3 { int32_t* o[3]; unsigned long long total[3]; };       // per matrix: [row | col | val] block and its nnz
 template <class K>
 __global__ __launch_bounds__(CP_BLOCK) void k_cp_scatter(const int32_t* __restrict__ v, const K* __restrict__ k, long long n,
-                                                         KeyLayout<K> kl, const unsigned long long* __restrict__ off,
-                                                         int32_t* __restrict__ row, int32_t* __restrict__ col, int32_t* __restrict__ val) {
+                                                         KeyLayout<K> kl, const unsigned long long* __restrict__ off, CooOut3 out) {
     __shared__ uint32_t s_wave[CP_BLOCK / 64];
+    v += (long long)blockIdx.y * n; off += (size_t)blockIdx.y * gridDim.x;
+    int32_t* __restrict__ row = out.o[blockIdx.y]; int32_t* __restrict__ col = row + out.total[blockIdx.y]; int32_t* __restrict__ val = col + out.total[blockIdx.y];
     long long base = (long long)blockIdx.x * CP_TILE;
     unsigned long long o = off[blockIdx.x];
     // blocked arrangement keeps output order == input order
@@ -1377,28 +1401,50 @@ static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout
 
 static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total);
 
-// ordered compaction of dense[i] > 0 into pinned host COO arrays of matrix m
+// ordered compaction of dense[y][i] > 0 (y = 0..nm-1, arrays n apart) into the COO blocks of matrices m0..m0+nm-1:
+// counts and scans of all matrices first, ONE read-back of the totals, then the scatters and the copy-out
 template <class K>
-static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m) {
+static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m0, int nm) {
     size_t nb = (n + CP_TILE - 1) / CP_TILE;
-    uint32_t* d_blk = ws.get<uint32_t>(nb); unsigned long long* d_off = ws.get<unsigned long long>(nb);
+    uint32_t* d_blk = ws.get<uint32_t>(nb * nm); unsigned long long* d_off = ws.get<unsigned long long>(nb * nm);
     if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (compaction)"; return XCK_E_NOMEM; }
-    hipLaunchKernelGGL(k_cp_count, dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
-    hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, im->d_ctl + CTL_SCRATCH);
+    unsigned long long* d_tot = im->d_ctl + CTL_X0;                       // the k_expand words are free again at this point
+    hipLaunchKernelGGL(k_cp_count, dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
+    hipLaunchKernelGGL(k_cp_scan, dim3(nm), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, d_tot);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->d_hctl + CTL_SCRATCH, 1);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)d_tot, im->d_hctl + CTL_X0, nm);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(im->s_comp));
-    size_t total = im->h_ctl[CTL_SCRATCH];
-    im->res_nnz[m] = total; im->d_res[m] = nullptr;
-    if (!total) return 0;
-    int rc = res_reserve(im, m, total); if (rc) return rc;
-    int32_t* d_o = ws.get<int32_t>(total * 3);
-    if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
-    hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off,
-                       d_o, d_o + total, d_o + 2 * total);
+    CooOut3 out; memset(&out, 0, sizeof out);
+    bool any = false;
+    for (int y = 0; y < nm; y++) {
+        const size_t total = im->h_ctl[CTL_X0 + y];
+        im->res_nnz[m0 + y] = total; im->d_res[m0 + y] = nullptr; out.total[y] = total;
+        if (!total) continue;
+        int rc = res_reserve(im, m0 + y, total); if (rc) return rc;
+        out.o[y] = ws.get<int32_t>(total * 3);
+        if (!out.o[y]) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
+        any = true;
+    }
+    if (!any) return 0;
+    hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off, out);
     HIP_TRY(hipGetLastError());
-    return copy_out(im, m, d_o, total);
+    // copy-out: large blocks go through copy_out() (copy stream); the small ones share one store kernel into mapped pinned memory
+    CopySeg3 sg; memset(&sg, 0, sizeof sg); size_t mx = 0;
+    for (int y = 0; y < nm; y++) {
+        const size_t total = out.total[y];
+        if (!total) continue;
+        if (total * 3 * sizeof(int32_t) >= (size_t(8) << 20)) { int rc = copy_out(im, m0 + y, out.o[y], total); if (rc) return rc; continue; }
+        im->d_res[m0 + y] = out.o[y];
+        int32_t* alias = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void**)&alias, im->h_res[m0 + y], 0));
+        sg.src[y] = out.o[y]; sg.dst[y] = alias; sg.n[y] = total * 3; mx = std::max(mx, total * 3);
+    }
+    if (mx) {
+        hipLaunchKernelGGL(k_copy_words3, dim3((unsigned)std::min<size_t>((mx + 255) / 256, 1024), nm), dim3(256), 0, im->s_comp, sg);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 // hand matrix m ([row|col|val] at d_o) to the host
@@ -1447,7 +1493,6 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
 
 // shard slices -> one contiguous array, with the UMI field narrowed from `ubits` to `used` bits (the row and cell
 // fields move down): every dead bit removed is one bit the radix sort does not have to pass over
-struct ShardSpan { unsigned long long start[NSHARD + 1]; };
 __global__ void __launch_bounds__(256) k_pack_squeeze(const unsigned long long* __restrict__ src, unsigned long long cap, ShardSpan sp,
                                                         int ubits, int used, unsigned long long* __restrict__ dst) {
     const unsigned long long n = sp.start[NSHARD];
@@ -1519,7 +1564,10 @@ static int finish_t(EngineImpl* im) {
         if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
-        if ((rc = pack_shards(im, alt, valt))) return rc;
+        { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
+          hipLaunchKernelGGL((k_pack_pairs<K>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, im->s_comp,
+                             (const K*)im->d_keys, (const uint64_t*)im->d_vals, (unsigned long long)im->hit_cap, sp, alt, valt);
+          HIP_TRY(hipGetLastError()); }
         if ((rc = sort_run<K, uint64_t>(im, tmp, tmpb, alt, keys, valt, im->d_vals, n, top))) return rc;
         std::swap(alt, keys); { uint64_t* t_ = valt; valt = im->d_vals; (void)t_; }   // sorted data now lives in d_keys / d_vals
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
@@ -1550,7 +1598,7 @@ static int finish_t(EngineImpl* im) {
             hipLaunchKernelGGL((k_hap_counts<K>), dim3(gs2), dim3(256), 0, im->s_comp, k2b, v2b, (long long)n2, kl, im->no_dup_hap,
                                dense, dense + n2, dense + 2 * n2);
             HIP_TRY(hipGetLastError());
-            for (int m = 0; m < 3; m++) if ((rc = compact_coo<K>(im, im->ws2, dense + m * n2, k2b, n2, kl, 1 + m))) return rc;
+            if ((rc = compact_coo<K>(im, im->ws2, dense, k2b, n2, kl, 1, 3))) return rc;          // AD, DP, OTH together
         }
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     }
@@ -1579,7 +1627,12 @@ int engine_finish(xck_engine* e, xck_result* out) {
     if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     int rc = engine_finish_async(e); if (rc) return rc;
     if (im->copy_pending) {
+        static const bool dbg = getenv("XCK_DEBUG_TIMING") != nullptr;
+        const auto t0_ = std::chrono::steady_clock::now();
+        const hipError_t q_ = dbg ? hipStreamQuery(im->s_copy) : hipSuccess;
         HIP_TRY(hipStreamSynchronize(im->s_copy));
+        if (dbg) fprintf(stderr, "[xck] finish: copy stream %s at entry, waited %.3f ms\n", q_ == hipSuccess ? "idle" : "busy",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
         if (im->copy_timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, im->ev_c0, im->ev_c1)); im->st.ms_d2h += ms; }
         im->copy_pending = false;
     }
