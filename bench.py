@@ -36,11 +36,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARC
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
-    ap.add_argument("--cells", type=int, default=5000)
-    ap.add_argument("--snps", type=int, default=100_000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=500_000_000, help="reads per GPU (BASELINE.json configs[2]; configs[1] = --reads 50000000 --cells 5000 --snps 100000)")
+    ap.add_argument("--cells", type=int, default=10000)
+    ap.add_argument("--snps", type=int, default=1_000_000)
     ap.add_argument("--genes", type=int, default=33472)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--serial", action="store_true", help="no overlap between the basefc and pileup engines")
@@ -230,7 +230,7 @@ def main():
         import oracle as O
         import util
         take, tot = [], 0
-        for c, s, e in batches:                        # whole contigs only, so that their matrix rows are complete
+        for c, s, e in sorted(batches, key=lambda b: b[2] - b[1]):   # whole contigs only (their matrix rows are complete), smallest first
             if tot >= args.cpu_sample:
                 break
             take.append((c, s, e)); tot += e - s
@@ -258,15 +258,16 @@ def main():
         if parity != "ok":
             sys.exit("bench.py: GPU result differs from the oracle on the sampled contigs: " + parity)
 
+    cfg_name = {(500_000_000, 10000, 1_000_000): "configs[2]", (50_000_000, 5000, 100_000): "configs[1]"}.get((args.reads, args.cells, args.snps), "configs[2] shape at a custom size")
     line = dict(metric="reads/sec into AD/DP+basefc matrices", value=round(value, 1), unit="reads/s",
                 n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3),
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64", data="synthetic",
-                config=dict(workload="BASELINE.json configs[1]: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
-                                     "basefc + pileup per step, SoA resident in HBM" % (n_reads, args.cells, len(snps), len(regions)),
+                config=dict(workload="BASELINE.json %s: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
+                                     "basefc + pileup per step, SoA resident in HBM" % (cfg_name, n_reads, args.cells, len(snps), len(regions)),
                             reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world, pipeline="serial" if args.serial else "copy-out overlapped, %d basefc engine(s) in rotation" % depth,
                             nnz={kk: (int(sum(sz[j] for sz in res["_gathered_sizes"])) if world > 1 else int(len(res[kk][0]))) for j, kk in enumerate(("count", "ad", "dp", "oth"))},
                             hits=dict(basefc=int(hits_fc), pileup=int(hits_baf),
-                                      basefc_after_lds_dedup=int(sfc["n_hits_unique"]))),
+                                      basefc_after_lds_dedup=int(sfc["n_hits_unique"]), pileup_after_lds_dedup=int(sbaf["n_hits_unique"]))),
                 roofline=roofline, cpu_baseline=cpu)
     print(json.dumps(line))
     if dist is not None:

@@ -179,6 +179,24 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r, double 
 #ifndef XCK_TILE_ITEMS
 #define XCK_TILE_ITEMS 4
 #endif
+#ifndef XCK_BAF_FLUSH_EVERY
+#define XCK_BAF_FLUSH_EVERY XCK_TILE_ITEMS   // sweeps between two flushes of the pileup map
+#endif
+#ifndef XCK_BAF_BALANCED
+#define XCK_BAF_BALANCED 1        // pileup: (read, SNP) pairs of a sweep are spread evenly over the block's threads
+#endif
+#ifndef XCK_BAF_SEQ_PREFETCH
+#define XCK_BAF_SEQ_PREFETCH 1   // 1: seq_off is streamed with every read; 0: looked up per (read, SNP) pair (measured slower)
+#endif
+#ifndef XCK_BAF_MAP
+#define XCK_BAF_MAP 0             // 1: pileup hits go through the LDS key -> min(value) map instead of the queue
+#endif
+#ifndef XCK_BAF_QUEUE_BYTES
+#define XCK_BAF_QUEUE_BYTES 6144
+#endif
+#ifndef XCK_MAP_SLOTS
+#define XCK_MAP_SLOTS 1024
+#endif
 #ifndef XCK_HS_BYTES
 #define XCK_HS_BYTES 16384
 #endif
@@ -192,15 +210,21 @@ constexpr int TILE_ITEMS = XCK_TILE_ITEMS;
 constexpr int TILE = JOIN_BLOCK * TILE_ITEMS;
 constexpr int HS_BYTES = XCK_HS_BYTES;   // LDS set / queue storage per block
 constexpr int HS_SLOTS = HS_BYTES / 8;   // slots of the 64-bit key set
+constexpr int MAP_SLOTS = XCK_MAP_SLOTS; // slots of the pileup key -> min(value) map (16 B each)
 constexpr int CG_CAP = XCK_CG_CAP;       // staged CIGAR words
 constexpr int ST_CAP = XCK_ST_CAP;       // staged regions / SNPs
 constexpr int ST_WIN = 64;               // staged index windows
 
 template <class K, int MODE> struct JoinSmem {
-    static constexpr bool USE_SET = (MODE == XCK_MODE_BASEFC) && sizeof(K) == 8;
-    // pileup emits ~0.1 hits per read: a small queue is enough and buys occupancy (LDS is the limiter)
-    static constexpr int  STORE_BYTES = MODE == XCK_MODE_BAF ? 6144 : HS_BYTES;
-    static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (MODE == XCK_MODE_BAF ? 8 : 0));
+    // 64-bit keys go through an LDS hash table: basefc a SET of keys (duplicate (region, cell, UMI) dropped), pileup a
+    // MAP key -> min(value) ("first read in fetch order wins", baf/fc/mcount.py:118-119: the value's high bits are the
+    // read ordinal).  The PCR / UMI duplicates that sit next to each other in a sorted BAM never reach HBM.
+    // 128-bit keys use a plain queue.
+    static constexpr bool USE_SET = sizeof(K) == 8 && (MODE == XCK_MODE_BASEFC || XCK_BAF_MAP);
+    static constexpr bool HAS_VAL = MODE == XCK_MODE_BAF;
+    static constexpr int  SLOTS = HAS_VAL ? MAP_SLOTS : HS_SLOTS;
+    static constexpr int  STORE_BYTES = USE_SET ? SLOTS * (HAS_VAL ? 16 : 8) : (HAS_VAL ? XCK_BAF_QUEUE_BYTES : HS_BYTES);
+    static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (HAS_VAL ? 8 : 0));
     alignas(16) unsigned char store[STORE_BYTES];
     uint32_t cig[CG_CAP];
     int32_t  st_a[ST_CAP], st_b[ST_CAP], st_c[ST_CAP];
@@ -213,8 +237,15 @@ template <class K, int MODE> struct JoinSmem {
     uint32_t wuor[2 * (JOIN_BLOCK / 64)];  // per-wave OR of the UMI codes
     uint32_t wcnt[JOIN_BLOCK / 64];
     unsigned long long base;
+    // pileup, balanced (read, SNP) pairs: the sweep's reads parked in LDS so that any thread can work on any pair
+    static constexpr int PR = (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) ? JOIN_BLOCK : 1;
+    uint64_t pr_umi[PR];
+    int32_t  pr_pos[PR], pr_cell[PR], pr_klo[PR];
+    uint32_t pr_c0[PR], pr_c1[PR], pr_s0[PR], pr_sl[PR], pr_off[PR];
     __device__ K* keys() { return reinterpret_cast<K*>(store); }
     __device__ uint64_t* vals() { return reinterpret_cast<uint64_t*>(store + (size_t)QCAP * sizeof(K)); }
+    __device__ unsigned long long* hkeys() { return reinterpret_cast<unsigned long long*>(store); }            // hashed mode
+    __device__ unsigned long long* hvals() { return reinterpret_cast<unsigned long long*>(store) + SLOTS; }
 };
 
 template <class K, int MODE>
@@ -224,11 +255,13 @@ __device__ __forceinline__ uint32_t cig_at(const JoinArgs<K>& a, const BatchDesc
 }
 
 // the seven SoA fields of one read, fetched one sweep ahead of their use (software prefetch)
-struct RawRead { int32_t pos, cell; uint64_t umi; uint32_t c0, c1; uint32_t flag; int32_t mapq; bool valid; };
+struct RawRead { int32_t pos, cell; uint64_t umi; uint32_t c0, c1; uint32_t flag; int32_t mapq; uint32_t s0, s1; bool valid; };
+template <bool WITH_SEQ>
 __device__ __forceinline__ RawRead fetch_read(const BatchDesc& d, int i) {
-    RawRead w; w.valid = i < d.n; w.pos = 0; w.cell = -1; w.umi = 0; w.c0 = w.c1 = 0; w.flag = 0; w.mapq = 0;
+    RawRead w; w.valid = i < d.n; w.pos = 0; w.cell = -1; w.umi = 0; w.c0 = w.c1 = 0; w.flag = 0; w.mapq = 0; w.s0 = w.s1 = 0;
     if (w.valid) { w.flag = as_global(d.flag)[i]; w.mapq = as_global(d.mapq)[i]; w.cell = as_global(d.cell)[i]; w.umi = as_global(d.umi)[i];
-                   w.pos = as_global(d.pos)[i]; w.c0 = as_global(d.cig_off)[i]; w.c1 = as_global(d.cig_off)[i + 1]; }
+                   w.pos = as_global(d.pos)[i]; w.c0 = as_global(d.cig_off)[i]; w.c1 = as_global(d.cig_off)[i + 1];
+                   if (WITH_SEQ) { w.s0 = as_global(d.seq_off)[i]; w.s1 = as_global(d.seq_off)[i + 1]; } }
     return w;
 }
 
@@ -313,14 +346,15 @@ __device__ __forceinline__ void emit_global(const JoinArgs<K>& a, K key, uint64_
 }
 
 // slot of a 64-bit key: full-rate VALU only (a 64-bit multiply is four quarter-rate v_mul ops on CDNA)
+template <int SLOTS>
 __device__ __forceinline__ uint32_t set_slot(unsigned long long kk) {
 #if XCK_HASH_MUL64
-    return (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (HS_SLOTS - 1);
+    return (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (SLOTS - 1);
 #else
     const uint32_t lo = (uint32_t)kk, hi = (uint32_t)(kk >> 32);
     uint32_t x = lo ^ ((hi << 9) | (hi >> 23));
     x ^= x >> 15;
-    return (__umul24(x, 0x9E3779u) >> 12) & (HS_SLOTS - 1);
+    return (__umul24(x, 0x9E3779u) >> 12) & (SLOTS - 1);
 #endif
 }
 
@@ -328,17 +362,20 @@ template <class K, int MODE>
 __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, K key, uint64_t val) {
     if (XCK_EXP & 1) return;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
-        unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
+        constexpr int SLOTS = JoinSmem<K, MODE>::SLOTS;
+        unsigned long long* set = sm.hkeys();
         const unsigned long long kk = (unsigned long long)key;
-        uint32_t slot = set_slot(kk);
+        uint32_t slot = set_slot<SLOTS>(kk);
 #if !XCK_UNROLL_PROBE
 #pragma unroll 1
 #endif
         for (int probe = 0; probe < 24; probe++) {
             unsigned long long prev = atomicCAS(&set[slot], ~0ull, kk);
-            if (prev == ~0ull) return;                               // new key (no shared counter: flush points are static)
-            if (prev == kk) return;                                  // duplicate (same region, cell, UMI)
-            slot = (slot + 1) & (HS_SLOTS - 1);
+            if (prev == ~0ull || prev == kk) {                       // new key, or a duplicate (same region|SNP, cell, UMI)
+                if (JoinSmem<K, MODE>::HAS_VAL) atomicMin(&sm.hvals()[slot], (unsigned long long)val);   // smallest ordinal wins
+                return;                                              // (no shared counter: flush points are static)
+            }
+            slot = (slot + 1) & (SLOTS - 1);
         }
         emit_global<K, MODE>(a, key, val);
     } else {
@@ -354,8 +391,8 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (XCK_EXP & 8) return;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
-        unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
-        constexpr int PER_WAVE = HS_SLOTS / (JOIN_BLOCK / 64);
+        unsigned long long* set = sm.hkeys();
+        constexpr int PER_WAVE = JoinSmem<K, MODE>::SLOTS / (JOIN_BLOCK / 64);
         uint32_t c = 0;
         for (int s = wave * PER_WAVE + lane; s < (wave + 1) * PER_WAVE; s += 64) c += (set[s] != ~0ull) ? 1u : 0u;
 #pragma unroll
@@ -385,6 +422,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
                 uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (fits) a.keys[dst + pre] = (K)v;
                 set[s] = ~0ull;
+                if (JoinSmem<K, MODE>::HAS_VAL) { if (fits) a.vals[dst + pre] = sm.hvals()[s]; sm.hvals()[s] = ~0ull; }
             }
             dst += __popcll(m);
         }
@@ -471,6 +509,57 @@ __device__ __forceinline__ uint32_t join_regions_global(const JoinArgs<K>& a, co
     return n_acc;
 }
 
+// position of SNP k (staged slice first)
+template <class K, int MODE>
+__device__ __forceinline__ int32_t snp_p0(const JoinArgs<K>& a, const JoinSmem<K, MODE>& sm, int32_t k) {
+    const uint32_t dl = (uint32_t)(k - sm.k0);
+    return dl < (uint32_t)sm.nk ? sm.st_a[dl] : as_global(a.snp_p0)[k];
+}
+template <class K, int MODE>
+__device__ __forceinline__ int32_t lower_snp_tail(const JoinArgs<K>& a, const BatchDesc& d, int32_t k, int32_t x) {
+    while (k < d.snp_end && as_global(a.snp_p0)[k] < x) k++;
+    return k;
+}
+// first SNP k >= k_from of the contig with position >= x: binary search in the staged slice, linear beyond it
+template <class K, int MODE>
+__device__ __forceinline__ int32_t lower_snp(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int32_t k_from, int32_t x) {
+    int32_t k = k_from;
+    const uint32_t dl = (uint32_t)(k - sm.k0);
+    if (dl < (uint32_t)sm.nk) {
+        int32_t lo = (int32_t)dl, hi = sm.nk;
+#pragma unroll
+        for (int q = 0; q < 3; q++) if (lo < hi && sm.st_a[lo] < x) lo++;       // the answer is usually 0-2 SNPs away
+        if (lo < hi && sm.st_a[lo] >= x) return sm.k0 + lo;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (sm.st_a[mid] < x) lo = mid + 1; else hi = mid; }
+        k = sm.k0 + lo;
+        if (lo < sm.nk) return k;
+    }
+    return lower_snp_tail<K, MODE>(a, d, k, x);
+}
+// UCount.push_read + get_query_bases for a read parked in LDS slot u: BAM nibble of the query base at reference p0, or -1
+template <class K, int MODE>
+__device__ __forceinline__ int allele_at_slot(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int u, int i, int32_t p0) {
+    uint32_t s0, sl;
+    if (XCK_BAF_SEQ_PREFETCH) { s0 = sm.pr_s0[u]; sl = sm.pr_sl[u]; }
+    else { s0 = as_global(d.seq_off)[i]; sl = as_global(d.seq_off)[i + 1] - s0; }     // in flight during the CIGAR walk
+    int32_t rp = sm.pr_pos[u], q = 0;
+    const uint32_t c1 = sm.pr_c1[u];
+    for (uint32_t c = sm.pr_c0[u]; c < c1; c++) {
+        uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
+        if (op_aligned(op)) {
+            if (p0 >= rp && p0 < rp + l) {
+                const int32_t qi = q + (p0 - rp);
+                if ((uint32_t)(qi >> 1) >= sl) return -1;
+                const uint32_t by = as_global(d.seq)[s0 + (qi >> 1)];
+                return (qi & 1) ? int(by & 15u) : int(by >> 4);
+            }
+            rp += l; q += l;
+        } else if (op == 1u || op == 4u) q += l;
+        else if (op_ref(op)) rp += l;
+    }
+    return -1;
+}
+
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r, int i) {
     uint32_t n_acc = 0;
@@ -542,11 +631,11 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     RawRead nxt; RawRead W[TILE_ITEMS];
     if (DENSE || XCK_PREFETCH_ALL) {
 #pragma unroll
-        for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read(d, tile0 + j * JOIN_BLOCK + tid);   // the whole tile's loads fly during the staging
-    } else nxt = fetch_read(d, tile0 + tid);                           // first sweep's loads overlap the staging
+        for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read<MODE == XCK_MODE_BAF && XCK_BAF_BALANCED && XCK_BAF_SEQ_PREFETCH>(d, tile0 + j * JOIN_BLOCK + tid);   // the whole tile's loads fly during the staging
+    } else nxt = fetch_read<MODE == XCK_MODE_BAF && XCK_BAF_BALANCED && XCK_BAF_SEQ_PREFETCH>(d, tile0 + tid);                           // first sweep's loads overlap the staging
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
-        unsigned long long* set = reinterpret_cast<unsigned long long*>(sm.store);
-        for (int s = tid; s < HS_SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
+        unsigned long long* set = sm.hkeys();                         // keys, then (pileup) values: all ones = empty / +inf
+        for (int s = tid; s < JoinSmem<K, MODE>::SLOTS * (JoinSmem<K, MODE>::HAS_VAL ? 2 : 1); s += JOIN_BLOCK) set[s] = ~0ull;
     }
     if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; sm.nuniq = 0; }
     if (DENSE) __syncthreads();                                      // nuniq must be 0 before the appends below
@@ -588,13 +677,13 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     // ---- 8 coalesced sweeps over the tile ----
     uint32_t acc = 0;
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
-    constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? HS_SLOTS : JoinSmem<K, MODE>::QCAP;
+    constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? JoinSmem<K, MODE>::SLOTS : JoinSmem<K, MODE>::QCAP;
 #ifndef XCK_FLUSH_END_ONLY
 #define XCK_FLUSH_END_ONLY 1
 #endif
     // set mode: the de-duplicated fill of a 1024-read tile is a few hundred keys, so flush once, at the end
     // (better de-duplication, half the cursor atomics); saturation still spills correctly through emit_global()
-    constexpr int FLUSH_EVERY = (XCK_FLUSH_END_ONLY && JoinSmem<K, MODE>::USE_SET) ? TILE_ITEMS
+    constexpr int FLUSH_EVERY = JoinSmem<K, MODE>::USE_SET ? (JoinSmem<K, MODE>::HAS_VAL ? XCK_BAF_FLUSH_EVERY : TILE_ITEMS)
                               : ((CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)));
     if (DENSE) {
         // ---- region-major evaluation: every thread keeps its 4 reads in registers; the loop over the tile's
@@ -640,9 +729,46 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     for (int j = 0; j < TILE_ITEMS; j++) {
         const int i = tile0 + j * JOIN_BLOCK + tid;
         const RawRead cur = XCK_PREFETCH_ALL ? W[j] : nxt;
-        if (!XCK_PREFETCH_ALL && j + 1 < TILE_ITEMS) nxt = fetch_read(d, i + JOIN_BLOCK);      // next sweep's loads fly during this sweep's work
+        if (!XCK_PREFETCH_ALL && j + 1 < TILE_ITEMS) nxt = fetch_read<MODE == XCK_MODE_BAF && XCK_BAF_BALANCED && XCK_BAF_SEQ_PREFETCH>(d, i + JOIN_BLOCK);      // next sweep's loads fly during this sweep's work
         ReadInfo r = load_read<K, MODE>(a, d, sm, cur);
-        if (r.ok) {
+        if constexpr (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) {
+            // A spliced read spans thousands of bases and tens of SNPs, most reads none: looping per read leaves the
+            // wave waiting for its longest read.  So: every read only COUNTS its SNPs, the counts are scanned, and the
+            // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
+            int32_t k_lo = 0; uint32_t c = 0;
+            const int32_t w_lo = r.pos >> WS;
+            if (r.ok && w_lo < d.n_swin) {
+                const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
+                k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
+                c = (uint32_t)(lower_snp<K, MODE>(a, d, sm, k_lo, r.endpos) - k_lo);
+            }
+            // wave-level: each wave parks its 64 reads in its own LDS segment and deals its pairs out over its 64
+            // lanes - no block barrier (a wave's LDS operations execute in order)
+            uint32_t inc = c;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t_ = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t_; }
+            const uint32_t total = __shfl(inc, 63, 64);
+            if (total) {
+                const int wb = tid & ~63;                                   // first slot of this wave's segment
+                sm.pr_pos[tid] = r.pos; sm.pr_c0[tid] = r.c0; sm.pr_c1[tid] = r.c1; sm.pr_cell[tid] = r.cell; sm.pr_umi[tid] = r.umi;
+                sm.pr_klo[tid] = k_lo; sm.pr_s0[tid] = cur.s0; sm.pr_sl[tid] = cur.s1 - cur.s0; sm.pr_off[tid] = inc - c;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t pi = lane; pi < total; pi += 64) {
+                    int lo = 0, hi = 63;                                    // the read this pair belongs to: last u with pr_off[u] <= pi
+#pragma unroll
+                    for (int st = 0; st < 6; st++) { const int mid = (lo + hi + 1) >> 1; if (sm.pr_off[wb + mid] <= pi) lo = mid; else hi = mid - 1; }
+                    const int u = wb + lo;
+                    const int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
+                    const int al = allele_at_slot<K, MODE>(a, d, sm, u, tile0 + j * JOIN_BLOCK + u, snp_p0<K, MODE>(a, sm, k));
+                    emit<K, MODE>(a, sm, a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]),
+                                  ((d.ordinal_base + (uint64_t)(tile0 + j * JOIN_BLOCK + u)) << ALLELE_BITS) | (uint64_t)(al + 1));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();                            // the segment is overwritten by the wave's next sweep
+            }
+            acc += c;
+        } else if (r.ok) {
             uor |= r.umi;
             if (MODE == XCK_MODE_BASEFC) acc += join_regions<K, MODE>(a, d, sm, r);
             else acc += join_snps<K, MODE>(a, d, sm, r, i);
