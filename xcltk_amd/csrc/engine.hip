@@ -118,6 +118,7 @@ template <class K> struct JoinArgs {
     const int32_t* snp_p0;
     KeyLayout<K> kl;
     K* keys; uint64_t* vals; unsigned long long cap;   // cap = capacity of ONE shard
+    K* nkeys; uint64_t* nvals;                          // pileup split mode: the stream of hits without a base (same shard capacity)
     unsigned long long* ctl;             // control block, see CTL_* below
 };
 
@@ -133,8 +134,10 @@ constexpr int XSHARD = 32;                 // k_expand: sharded totals / cursors
 constexpr int CTL_X0 = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
 constexpr int CTL_WORDS = CTL_X0 + XSHARD * CTL_STRIDE;
 struct XBases { unsigned long long base[XSHARD]; };
+struct ShardSpan { unsigned long long start[NSHARD + 1]; };               // first packed index of every shard slice
 __host__ __device__ inline int ctl_cursor(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE; }
 __host__ __device__ inline int ctl_umi_or(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE + 1; }   // OR of the UMI codes seen
+__host__ __device__ inline int ctl_ncursor(int shard) { return CTL_SHARD0 + shard * CTL_STRIDE + 2; }  // cursor of the no-base stream
 __host__ __device__ inline int ctl_accepted(int shard) { return CTL_SHARD0 + (NSHARD + shard) * CTL_STRIDE; }
 
 struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint64_t umi; bool ok;
@@ -188,6 +191,15 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r, double 
 #ifndef XCK_BAF_SEQ_PREFETCH
 #define XCK_BAF_SEQ_PREFETCH 1   // 1: seq_off is streamed with every read; 0: looked up per (read, SNP) pair (measured slower)
 #endif
+#ifndef XCK_BAF_SPLIT
+#define XCK_BAF_SPLIT 1           // pileup, 64-bit keys: hits without a base go to a second stream that is never sorted
+#endif
+#ifndef XCK_BAF_NQUEUE_BYTES
+#define XCK_BAF_NQUEUE_BYTES 6144   // split mode: queue of the hits without a base (16 B each)
+#endif
+#ifndef XCK_BAF_BQUEUE_BYTES
+#define XCK_BAF_BQUEUE_BYTES 2048   // split mode: queue of the hits with a base (~1 in 10)
+#endif
 #ifndef XCK_BAF_MAP
 #define XCK_BAF_MAP 0             // 1: pileup hits go through the LDS key -> min(value) map instead of the queue
 #endif
@@ -223,7 +235,8 @@ template <class K, int MODE> struct JoinSmem {
     static constexpr bool USE_SET = sizeof(K) == 8 && (MODE == XCK_MODE_BASEFC || XCK_BAF_MAP);
     static constexpr bool HAS_VAL = MODE == XCK_MODE_BAF;
     static constexpr int  SLOTS = HAS_VAL ? MAP_SLOTS : HS_SLOTS;
-    static constexpr int  STORE_BYTES = USE_SET ? SLOTS * (HAS_VAL ? 16 : 8) : (HAS_VAL ? XCK_BAF_QUEUE_BYTES : HS_BYTES);
+    static constexpr bool SPLIT_ = MODE == XCK_MODE_BAF && sizeof(K) == 8 && XCK_BAF_SPLIT && !XCK_BAF_MAP;
+    static constexpr int  STORE_BYTES = USE_SET ? SLOTS * (HAS_VAL ? 16 : 8) : (HAS_VAL ? (SPLIT_ ? XCK_BAF_BQUEUE_BYTES : XCK_BAF_QUEUE_BYTES) : HS_BYTES);
     static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (HAS_VAL ? 8 : 0));
     alignas(16) unsigned char store[STORE_BYTES];
     uint32_t cig[CG_CAP];
@@ -237,6 +250,15 @@ template <class K, int MODE> struct JoinSmem {
     uint32_t wuor[2 * (JOIN_BLOCK / 64)];  // per-wave OR of the UMI codes
     uint32_t wcnt[JOIN_BLOCK / 64];
     unsigned long long base;
+    // pileup split mode (64-bit keys): a hit whose read shows NO base at the SNP (the SNP sits in an N / D gap - the
+    // bulk of the hits of spliced reads) only matters if a read of the same (SNP, cell, UMI) WITH a base comes later in
+    // fetch order (baf/fc/mcount.py:118-119: the earlier read holds the key).  Those hits go to their own queue / HBM
+    // stream, which finish() never sorts: it is only looked up against the (small) sorted stream of hits with a base.
+    static constexpr bool SPLIT = MODE == XCK_MODE_BAF && sizeof(K) == 8 && XCK_BAF_SPLIT && !XCK_BAF_MAP;
+    static constexpr int  NQCAP = SPLIT ? XCK_BAF_NQUEUE_BYTES / 16 : 1;
+    uint64_t nq_key[NQCAP], nq_val[NQCAP];
+    uint32_t ncount;
+    unsigned long long nbase;
     // pileup, balanced (read, SNP) pairs: the sweep's reads parked in LDS so that any thread can work on any pair
     static constexpr int PR = (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) ? JOIN_BLOCK : 1;
     uint64_t pr_umi[PR];
@@ -383,6 +405,43 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
         if (idx < (uint32_t)JoinSmem<K, MODE>::QCAP) { sm.keys()[idx] = key; if (MODE == XCK_MODE_BAF) sm.vals()[idx] = val; }
         else emit_global<K, MODE>(a, key, val);
     }
+}
+
+// no-base pileup hit (split mode): second LDS queue, spill straight to the second HBM stream
+template <class K, int MODE>
+__device__ __forceinline__ void emit_nobase(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, K key, uint64_t val) {
+    if (XCK_EXP & 1) return;
+    const uint32_t idx = atomicAdd(&sm.ncount, 1u);
+    if (idx < (uint32_t)JoinSmem<K, MODE>::NQCAP) { sm.nq_key[idx] = (uint64_t)key; sm.nq_val[idx] = val; }
+    else {
+        const int shard = blockIdx.x & (NSHARD - 1);
+        unsigned long long g = atomicAdd(&a.ctl[ctl_ncursor(shard)], 1ull);
+        if (g < a.cap) { g += (unsigned long long)shard * a.cap; a.nkeys[g] = key; a.nvals[g] = val; }
+        else atomicExch(&a.ctl[CTL_OVERFLOW], 1ull);
+    }
+}
+// split mode: both queues leave in ONE round (two cursor atomics in flight together, one set of barriers)
+template <class K, int MODE>
+__device__ __forceinline__ void flush_split(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm) {   // block-wide; all inserts are complete (barrier before)
+    const uint32_t tb = min(sm.count, (uint32_t)JoinSmem<K, MODE>::QCAP), tn = min(sm.ncount, (uint32_t)JoinSmem<K, MODE>::NQCAP);
+    if (threadIdx.x < 2) {
+        const uint32_t total = threadIdx.x ? tn : tb;
+        unsigned long long b = 0;
+        if (total) {
+            const int shard = blockIdx.x & (NSHARD - 1);
+            b = atomicAdd(&a.ctl[threadIdx.x ? ctl_ncursor(shard) : ctl_cursor(shard)], (unsigned long long)total);
+            if (b + total > a.cap) { atomicExch(&a.ctl[CTL_OVERFLOW], 1ull); b = ~0ull; }
+            else b += (unsigned long long)shard * a.cap;
+        }
+        if (threadIdx.x) sm.nbase = b; else sm.base = b;
+    }
+    __syncthreads();
+    const unsigned long long db = sm.base, dn = sm.nbase;
+    if (db != ~0ull) for (uint32_t t = threadIdx.x; t < tb; t += JOIN_BLOCK) { a.keys[db + t] = sm.keys()[t]; a.vals[db + t] = sm.vals()[t]; }
+    if (dn != ~0ull) for (uint32_t t = threadIdx.x; t < tn; t += JOIN_BLOCK) { a.nkeys[dn + t] = (K)sm.nq_key[t]; a.nvals[dn + t] = sm.nq_val[t]; }
+    __syncthreads();
+    if (threadIdx.x == 0) { sm.count = 0; sm.ncount = 0; }
+    __syncthreads();
 }
 
 // write the LDS set / queue to HBM as one contiguous fragment; block-wide call
@@ -572,8 +631,10 @@ __device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchD
         int32_t p0 = p0_of(k);
         if (p0 >= r.endpos) break;
         int al = allele_at(a, d, sm, r, i, p0);
-        emit<K, MODE>(a, sm, a.kl.make((uint32_t)k, (uint32_t)r.cell, r.umi),
-                      ((d.ordinal_base + (uint64_t)i) << ALLELE_BITS) | (uint64_t)(al + 1));
+        const K key = a.kl.make((uint32_t)k, (uint32_t)r.cell, r.umi);
+        const uint64_t val = ((d.ordinal_base + (uint64_t)i) << ALLELE_BITS) | (uint64_t)(al + 1);
+        if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val);
+        else emit<K, MODE>(a, sm, key, val);
         n_acc++;
     }
     return n_acc;
@@ -637,7 +698,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         unsigned long long* set = sm.hkeys();                         // keys, then (pileup) values: all ones = empty / +inf
         for (int s = tid; s < JoinSmem<K, MODE>::SLOTS * (JoinSmem<K, MODE>::HAS_VAL ? 2 : 1); s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    if (tid == 0) { sm.count = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; sm.nuniq = 0; }
+    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; sm.nuniq = 0; }
     if (DENSE) __syncthreads();                                      // nuniq must be 0 before the appends below
     // Every global load of the prologue is issued BEFORE the first LDS store: written as load/store loops the
     // compiler waits (s_waitcnt vmcnt(0)) inside each iteration, which serialised ~7 HBM round trips per tile.
@@ -761,8 +822,10 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                     const int u = wb + lo;
                     const int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
                     const int al = allele_at_slot<K, MODE>(a, d, sm, u, tile0 + j * JOIN_BLOCK + u, snp_p0<K, MODE>(a, sm, k));
-                    emit<K, MODE>(a, sm, a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]),
-                                  ((d.ordinal_base + (uint64_t)(tile0 + j * JOIN_BLOCK + u)) << ALLELE_BITS) | (uint64_t)(al + 1));
+                    const K key = a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]);
+                    const uint64_t val = ((d.ordinal_base + (uint64_t)(tile0 + j * JOIN_BLOCK + u)) << ALLELE_BITS) | (uint64_t)(al + 1);
+                    if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val);
+                    else emit<K, MODE>(a, sm, key, val);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();                            // the segment is overwritten by the wave's next sweep
@@ -781,7 +844,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             STAMP(3);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: global prefetches stay in flight
             STAMP(4);
-            flush<K, MODE>(a, sm);
+            if constexpr (JoinSmem<K, MODE>::SPLIT) flush_split<K, MODE>(a, sm); else flush<K, MODE>(a, sm);
             STAMP(5);
         }
     }
@@ -923,6 +986,64 @@ __global__ void k_first_read(const K* __restrict__ k, const uint64_t* __restrict
     if (code) atomicAdd(&tally[(size_t)kl.row(me) * 5 + nib_bucket(int(code) - 1)], 1u);
 }
 
+// ---- split mode (64-bit keys): the sorted stream holds only hits WITH a base; the hits without one are looked up ----
+// per key run: allele code + ordinal of its first read with a base, at the run head; first / one-past-last index of every SNP
+template <class K>
+__global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
+                             uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, uint32_t* __restrict__ row_lo, uint32_t* __restrict__ row_hi) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const K me = k[i];
+    const uint32_t row = kl.row(me);
+    if (i == 0 || kl.row(k[i - 1]) != row) row_lo[row] = (uint32_t)i;
+    if (i + 1 == n || kl.row(k[i + 1]) != row) row_hi[row] = (uint32_t)(i + 1);
+    if (i > 0 && k[i - 1] == me) { al_out[i] = 0; return; }
+    uint64_t best = v[i];
+    for (long long j = i + 1; j < n && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
+    al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));          // nibble + 1 (never 0 here)
+    ord_out[i] = best >> ALLELE_BITS;
+}
+// every hit without a base: if its (SNP, cell, UMI) has a run and this read comes EARLIER in fetch order than the run's
+// first read with a base, the key belongs to this read (baf/fc/mcount.py:118-119) and the run contributes nothing.
+// The stream is in tile order, so neighbouring threads search the same few SNPs: the lookups stay in L2.
+template <class K>
+__global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp,
+                                                 const K* __restrict__ keys, KeyLayout<K> kl, const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ row_hi,
+                                                 const uint64_t* __restrict__ ord, uint8_t* __restrict__ al) {
+    // (running several searches per lane in lockstep was measured: 17 ms instead of 10 ms at 330 M entries - the kernel is
+    // bound by L2 transactions, not by the latency of one chain)
+    const unsigned long long n = sp.start[NSHARD];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        int sh = 0;
+#pragma unroll
+        for (int q = 1; q < NSHARD; q++) sh += (i >= sp.start[q]) ? 1 : 0;
+        const unsigned long long j = (unsigned long long)sh * cap + (i - sp.start[sh]);
+        const K key = nk[j];
+        const uint32_t row = kl.row(key);
+        uint32_t lo = row_lo[row], hi = row_hi[row];
+        if (lo >= hi) continue;                                         // no read shows a base at this SNP
+        const uint32_t end = hi;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+        if (lo < end && keys[lo] == key && (nv[j] >> ALLELE_BITS) < ord[lo]) al[lo] = 0;   // benign race: every writer stores 0
+    }
+}
+template <class K>
+__global__ void k_tally(const K* __restrict__ k, const uint8_t* __restrict__ al, long long n, KeyLayout<K> kl, uint32_t* __restrict__ tally) {
+    // keys are sorted by SNP: a wave usually sits inside ONE SNP's run, and the five counters of a deep SNP would
+    // take thousands of same-address atomics - count with ballots and let one lane add
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t code = i < n ? al[i] : 0u;
+    const uint32_t row = i < n ? kl.row(k[i]) : 0xffffffffu;
+    const int bucket = code ? nib_bucket(int(code) - 1) : -1;
+    const uint32_t row0 = __shfl(row, 0, 64);
+    if (__all(row == row0 || i >= n)) {
+        for (int b = 0; b < 5; b++) {
+            const unsigned long long m = __ballot(bucket == b);
+            if (m && (threadIdx.x & 63) == 0) atomicAdd(&tally[(size_t)row0 * 5 + b], (uint32_t)__popcll(m));
+        }
+    } else if (code) atomicAdd(&tally[(size_t)row * 5 + bucket], 1u);
+}
+
 struct SnpFilter { int32_t min_count; double min_maf; };
 
 // plp_snp() filters, baf/fc/core.py:238-246.  info: ref nibble | alt nibble << 4 | ref_hap << 8 | alt_hap << 9
@@ -1021,7 +1142,6 @@ __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned l
 __global__ void k_copy_words(const int32_t* __restrict__ src, int32_t* __restrict__ host_alias, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) host_alias[i] = src[i];
 }
-struct ShardSpan { unsigned long long start[NSHARD + 1]; };               // first packed index of every shard slice
 struct CopySeg3 { const int32_t* src[3]; int32_t* dst[3]; size_t n[3]; };
 __global__ void k_copy_words3(CopySeg3 sg) {                              // blockIdx.y = segment
     const int32_t* __restrict__ src = sg.src[blockIdx.y]; int32_t* __restrict__ dst = sg.dst[blockIdx.y]; const size_t n = sg.n[blockIdx.y];
@@ -1151,6 +1271,8 @@ struct EngineImpl {
     int64_t max_batch_reads = 0;
     // hit accumulators (ping-pong pair so that sort results can stay where they land)
     void* d_keys = nullptr; uint64_t* d_vals = nullptr; size_t hit_cap = 0;
+    void* d_nkeys = nullptr; uint64_t* d_nvals = nullptr;   // pileup split mode: hits without a base (same per-shard capacity)
+    unsigned long long ncur[NSHARD] = {0}, ncur_before[NSHARD] = {0}, ncursor = 0;
     unsigned long long* d_ctl = nullptr;       // CTL_WORDS control words (overflow flag, scratch, sharded cursors)
     unsigned long long* h_ctl = nullptr;       // pinned + mapped mirror
     unsigned long long* d_hctl = nullptr;      // device alias of h_ctl (written by k_publish)
@@ -1324,6 +1446,8 @@ static int res_reserve(EngineImpl* im, int m, size_t nnz) {
     return 0;
 }
 
+static inline bool split_mode(const EngineImpl* im) { return XCK_BAF_SPLIT && !XCK_BAF_MAP && im->mode == XCK_MODE_BAF && im->key_bits == 64; }
+
 static int ensure_hits(EngineImpl* im, size_t need) {           // need = elements per shard
     if (need <= im->hit_cap) return 0;
     size_t ncap = std::max<size_t>(need, im->hit_cap * 2);
@@ -1335,10 +1459,20 @@ static int ensure_hits(EngineImpl* im, size_t need) {           // need = elemen
                                im->cur[sh] * key_bytes(im), hipMemcpyDeviceToDevice, im->s_comp));
         if (nv) HIP_TRY(hipMemcpyAsync(nv + (size_t)sh * ncap, im->d_vals + (size_t)sh * im->hit_cap, im->cur[sh] * sizeof(uint64_t), hipMemcpyDeviceToDevice, im->s_comp));
     }
+    void* nnk = nullptr; uint64_t* nnv = nullptr;
+    if (split_mode(im)) {
+        HIP_TRY(hipMalloc(&nnk, ncap * NSHARD * sizeof(uint64_t))); HIP_TRY(hipMalloc((void**)&nnv, ncap * NSHARD * sizeof(uint64_t)));
+        for (int sh = 0; sh < NSHARD; sh++) if (im->ncur[sh]) {
+            HIP_TRY(hipMemcpyAsync((uint64_t*)nnk + (size_t)sh * ncap, (uint64_t*)im->d_nkeys + (size_t)sh * im->hit_cap, im->ncur[sh] * sizeof(uint64_t), hipMemcpyDeviceToDevice, im->s_comp));
+            HIP_TRY(hipMemcpyAsync(nnv + (size_t)sh * ncap, im->d_nvals + (size_t)sh * im->hit_cap, im->ncur[sh] * sizeof(uint64_t), hipMemcpyDeviceToDevice, im->s_comp));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     if (im->d_keys) HIP_TRY(hipFree(im->d_keys));
     if (im->d_vals) HIP_TRY(hipFree(im->d_vals));
-    im->d_keys = nk; im->d_vals = nv; im->hit_cap = ncap;
+    if (im->d_nkeys) HIP_TRY(hipFree(im->d_nkeys));
+    if (im->d_nvals) HIP_TRY(hipFree(im->d_nvals));
+    im->d_keys = nk; im->d_vals = nv; im->d_nkeys = nnk; im->d_nvals = nnv; im->hit_cap = ncap;
     return 0;
 }
 
@@ -1376,6 +1510,7 @@ static int launch_join_t(EngineImpl* im) {
     a.snp_p0 = im->d_snp_p0;
     a.kl.ubits = im->ubits; a.kl.cbits = im->cbits;
     a.keys = (K*)im->d_keys; a.vals = im->d_vals; a.cap = im->hit_cap; a.ctl = im->d_ctl;
+    a.nkeys = (K*)im->d_nkeys; a.nvals = im->d_nvals;
     dim3 grid(tiles), block(JOIN_BLOCK);
     HIP_TRY(hipEventRecord(im->ev0, im->s_comp));
     const dim3 mgrid((tiles + 255) / 256), mblock(256);
@@ -1402,17 +1537,19 @@ static int complete_pending(EngineImpl* im) {
         im->st.ms_join += ms; im->st.ms_device += ms; im->n_join_launches++;
         if (im->h_ctl[CTL_OVERFLOW]) {                       // some fragment did not fit: grow, rewind, replay
             unsigned long long mx = 0;
-            for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, im->h_ctl[ctl_cursor(sh)]);
+            for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, std::max(im->h_ctl[ctl_cursor(sh)], im->h_ctl[ctl_ncursor(sh)]));
             int rc = ensure_hits(im, std::max<size_t>(mx + mx / 4 + 65536, im->hit_cap * 2)); if (rc) return rc;
-            for (int sh = 0; sh < NSHARD; sh++) { im->h_ctl[ctl_cursor(sh)] = im->cur_before[sh]; im->h_ctl[ctl_accepted(sh)] = im->acc_before[sh]; }
+            for (int sh = 0; sh < NSHARD; sh++) { im->h_ctl[ctl_cursor(sh)] = im->cur_before[sh]; im->h_ctl[ctl_ncursor(sh)] = im->ncur_before[sh];
+                                                  im->h_ctl[ctl_accepted(sh)] = im->acc_before[sh]; }
             im->h_ctl[CTL_OVERFLOW] = 0;
             HIP_TRY(hipMemcpyAsync(im->d_ctl, im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipMemcpyHostToDevice, im->s_comp));
             HIP_TRY(hipStreamSynchronize(im->s_comp));
             rc = launch_join(im); if (rc) return rc;
             continue;
         }
-        im->cursor = 0;
-        for (int sh = 0; sh < NSHARD; sh++) { im->cur[sh] = im->h_ctl[ctl_cursor(sh)]; im->cursor += im->cur[sh]; }
+        im->cursor = 0; im->ncursor = 0;
+        for (int sh = 0; sh < NSHARD; sh++) { im->cur[sh] = im->h_ctl[ctl_cursor(sh)]; im->cursor += im->cur[sh];
+                                              im->ncur[sh] = split_mode(im) ? im->h_ctl[ctl_ncursor(sh)] : 0; im->ncursor += im->ncur[sh]; }
         if (im->inflight_slot >= 0) im->slot[im->inflight_slot].busy = false;
         im->inflight.clear(); im->inflight_slot = -1; im->inflight_reads = 0;
     }
@@ -1424,12 +1561,12 @@ static int launch_queue(EngineImpl* im, int slot_idx) {
     if (im->queue.empty()) return 0;
     int rc = complete_pending(im); if (rc) return rc;
     { unsigned long long mx = 0;
-      for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, im->cur[sh]);
+      for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, std::max(im->cur[sh], im->ncur[sh]));
       rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / NSHARD + 65536); if (rc) return rc; }
     im->inflight.swap(im->queue); im->queue.clear();
     im->inflight_reads = im->queued_reads; im->queued_reads = 0;
     im->inflight_slot = slot_idx;
-    for (int sh = 0; sh < NSHARD; sh++) { im->cur_before[sh] = im->cur[sh]; im->acc_before[sh] = im->h_ctl[ctl_accepted(sh)]; }
+    for (int sh = 0; sh < NSHARD; sh++) { im->cur_before[sh] = im->cur[sh]; im->ncur_before[sh] = im->ncur[sh]; im->acc_before[sh] = im->h_ctl[ctl_accepted(sh)]; }
     if (slot_idx >= 0) im->slot[slot_idx].busy = true;
     return launch_join(im);
 }
@@ -1653,7 +1790,7 @@ static int finish_t(EngineImpl* im) {
     for (int m = 0; m < 4; m++) { im->res_nnz[m] = 0; im->d_res[m] = nullptr; }
     { int64_t acc = 0; for (int sh = 0; sh < NSHARD; sh++) acc += (int64_t)im->h_ctl[ctl_accepted(sh)];
       im->st.n_hits = acc; }                          // accepted pairs (before the LDS de-duplication)
-    im->st.n_hits_unique = (int64_t)n;                // keys that reached HBM
+    im->st.n_hits_unique = (int64_t)(n + im->ncursor);   // keys that reached HBM
 #if XCK_STAMPS
     fprintf(stderr, "[stamps mode=%d] desc=%llu extent=%llu stage=%llu sweeps=%llu barrier=%llu flush=%llu tail=%llu (cycles summed over blocks)\n", im->mode,
             im->h_ctl[4], im->h_ctl[5], im->h_ctl[6], im->h_ctl[7], im->h_ctl[8], im->h_ctl[9], im->h_ctl[10]);
@@ -1687,7 +1824,7 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 8 + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
         { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
@@ -1697,8 +1834,26 @@ static int finish_t(EngineImpl* im) {
         if ((rc = sort_run<K, uint64_t>(im, tmp, tmpb, alt, keys, valt, im->d_vals, n, top))) return rc;
         std::swap(alt, keys); { uint64_t* t_ = valt; valt = im->d_vals; (void)t_; }   // sorted data now lives in d_keys / d_vals
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
+        if (sizeof(K) == 8 && split_mode(im)) {
+            const size_t ns = std::max<size_t>((size_t)im->n_snps_sorted, 1);
+            uint64_t* ordv = im->ws1.get<uint64_t>(n); uint32_t* row_lo = im->ws1.get<uint32_t>(2 * ns); uint32_t* row_hi = row_lo + ns;
+            if (!ordv || !row_lo) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
+            HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(uint32_t), im->s_comp));
+            hipLaunchKernelGGL((k_first_base<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, ordv, row_lo, row_hi);
+            HIP_TRY(hipGetLastError());
+            if (im->ncursor) {
+                ShardSpan nsp; nsp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh];
+                hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<size_t>((im->ncursor + 255) / 256, 16384)), dim3(256), 0, im->s_comp,
+                                   (const K*)im->d_nkeys, (const uint64_t*)im->d_nvals, (unsigned long long)im->hit_cap, nsp,
+                                   (const K*)alt, kl, (const uint32_t*)row_lo, (const uint32_t*)row_hi, (const uint64_t*)ordv, al);
+                HIP_TRY(hipGetLastError());
+            }
+            hipLaunchKernelGGL((k_tally<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally);
+            HIP_TRY(hipGetLastError());
+        } else {
         hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, im->d_tally);
         HIP_TRY(hipGetLastError());
+        }
         XBases xb; memset(&xb, 0, sizeof xb);
         HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_X0, 0, XSHARD * CTL_STRIDE * sizeof(unsigned long long), im->s_comp));
         hipLaunchKernelGGL((k_expand<K, false>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
@@ -1796,9 +1951,9 @@ int engine_reset(xck_engine* e) {
     if (im->copy_pending) { HIP_TRY(hipStreamSynchronize(im->s_copy)); im->copy_pending = false; }
     HIP_TRY(hipMemsetAsync(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long), im->s_comp));
     HIP_TRY(hipStreamSynchronize(im->s_comp));
-    im->cursor = 0; im->finished = false;
+    im->cursor = 0; im->ncursor = 0; im->finished = false;
     for (int i = 0; i < CTL_WORDS; i++) im->h_ctl[i] = 0;
-    for (int sh = 0; sh < NSHARD; sh++) im->cur[sh] = 0;
+    for (int sh = 0; sh < NSHARD; sh++) { im->cur[sh] = 0; im->ncur[sh] = 0; }
     int kb = im->key_bits, ub = im->ubits;
     memset(&im->st, 0, sizeof im->st);
     im->st.key_bits = kb; im->st.umi_bits = ub; im->n_join_launches = 0;
@@ -1859,7 +2014,7 @@ void engine_destroy(xck_engine* e) {
     hipSetDevice(im->device);
     if (im->s_comp) hipStreamSynchronize(im->s_comp);
     void* ptrs[] = { im->d_win_s0, im->d_win_e0, im->d_win_row, im->d_win_off, im->d_snp_p0, im->d_snp_win,
-                     im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_ctl, im->d_meta,
+                     im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_nkeys, im->d_nvals, im->d_ctl, im->d_meta,
                      im->ws1.base, im->ws2.base };
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& s : im->slot) { void* q[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.cigar, s.seq_off, s.seq }; for (void* p : q) if (p) hipFree(p); }
