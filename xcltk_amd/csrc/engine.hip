@@ -195,7 +195,7 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r, double 
 #define XCK_BAF_SPLIT 1           // pileup, 64-bit keys: hits without a base go to a second stream that is never sorted
 #endif
 #ifndef XCK_BAF_NQUEUE_BYTES
-#define XCK_BAF_NQUEUE_BYTES 6144   // split mode: queue of the hits without a base (16 B each)
+#define XCK_BAF_NQUEUE_BYTES 2048   // split mode: queue of the gap records (16 B each, about one per spliced read)
 #endif
 #ifndef XCK_BAF_BQUEUE_BYTES
 #define XCK_BAF_BQUEUE_BYTES 2048   // split mode: queue of the hits with a base (~1 in 10)
@@ -262,7 +262,7 @@ template <class K, int MODE> struct JoinSmem {
     // pileup, balanced (read, SNP) pairs: the sweep's reads parked in LDS so that any thread can work on any pair
     static constexpr int PR = (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) ? JOIN_BLOCK : 1;
     uint64_t pr_umi[PR];
-    int32_t  pr_pos[PR], pr_cell[PR], pr_klo[PR];
+    int32_t  pr_pos[PR], pr_end[PR], pr_cell[PR], pr_klo[PR];
     uint32_t pr_c0[PR], pr_c1[PR], pr_s0[PR], pr_sl[PR], pr_off[PR];
     __device__ K* keys() { return reinterpret_cast<K*>(store); }
     __device__ uint64_t* vals() { return reinterpret_cast<uint64_t*>(store + (size_t)QCAP * sizeof(K)); }
@@ -619,6 +619,32 @@ __device__ __forceinline__ int allele_at_slot(const JoinArgs<K>& a, const BatchD
     return -1;
 }
 
+// split mode: the jn-th SNP (in reference order) that lies under an ALIGNED block of the read parked in slot u:
+// returns its query base (BAM nibble, or -1 when the read has no sequence there) and the SNP index in k
+template <class K, int MODE>
+__device__ __forceinline__ int nth_aligned_snp(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int u, uint32_t jn, int32_t& k_out) {
+    int32_t rp = sm.pr_pos[u], q = 0, k = sm.pr_klo[u];
+    const int32_t endpos = sm.pr_end[u];
+    const uint32_t c1 = sm.pr_c1[u];
+    for (uint32_t c = sm.pr_c0[u]; c < c1 && rp < endpos; c++) {
+        const uint32_t w = cig_at(a, d, sm, c); const uint32_t op = w & 15u; const int32_t l = int32_t(w >> 4);
+        if (op_aligned(op)) {
+            const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, min(rp + l, endpos));
+            if (jn < (uint32_t)(k2 - k)) {
+                k_out = k + (int32_t)jn;
+                const int32_t qi = q + (snp_p0<K, MODE>(a, sm, k_out) - rp);
+                if ((uint32_t)(qi >> 1) >= sm.pr_sl[u]) return -1;
+                const uint32_t by = as_global(d.seq)[sm.pr_s0[u] + (qi >> 1)];
+                return (qi & 1) ? int(by & 15u) : int(by >> 4);
+            }
+            jn -= (uint32_t)(k2 - k); k = k2; rp += l; q += l;
+        } else if (op == 1u || op == 4u) q += l;
+        else if (op_ref(op)) { k = lower_snp<K, MODE>(a, d, sm, k, min(rp + l, endpos)); rp += l; }
+    }
+    k_out = k;
+    return -1;                                                           // not reached for jn < the read's pair count
+}
+
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r, int i) {
     uint32_t n_acc = 0;
@@ -796,11 +822,35 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             // A spliced read spans thousands of bases and tens of SNPs, most reads none: looping per read leaves the
             // wave waiting for its longest read.  So: every read only COUNTS its SNPs, the counts are scanned, and the
             // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
-            int32_t k_lo = 0; uint32_t c = 0;
+            int32_t k_lo = 0; uint32_t c = 0, n_gap = 0;
             const int32_t w_lo = r.pos >> WS;
             if (r.ok && w_lo < d.n_swin) {
                 const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
                 k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
+                if constexpr (JoinSmem<K, MODE>::SPLIT) {
+                    // split mode: one CIGAR walk per read.  SNPs under aligned blocks become (read, SNP) pairs (c); the SNPs
+                    // inside an N / D gap - where the read holds the key but shows no base - leave as ONE range record per
+                    // gap, (first SNP, cell, UMI | ordinal, count - 1), in pieces of 32 SNPs: a spliced read over 20 SNPs
+                    // costs one 16-byte record instead of 20 hits.
+                    const uint64_t ordv = (d.ordinal_base + (uint64_t)i) << ALLELE_BITS;
+                    auto gap = [&](int32_t ka, int32_t kb) {
+                        for (int32_t ks = ka; ks < kb; ks += 32)
+                            emit_nobase<K, MODE>(a, sm, a.kl.make((uint32_t)ks, (uint32_t)r.cell, r.umi), ordv | (uint64_t)(min(kb - ks, 32) - 1));
+                        n_gap += (uint32_t)(kb - ka);
+                    };
+                    int32_t k = k_lo, rp = r.pos;
+                    for (uint32_t cc = r.c0; cc < r.c1 && rp < r.endpos; cc++) {
+                        const uint32_t w = cig_at(a, d, sm, cc); const uint32_t op = w & 15u; const int32_t l = int32_t(w >> 4);
+                        if (!op_ref(op) || l == 0) continue;                 // I, S, H, P: no reference bases
+                        const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, min(rp + l, r.endpos));
+                        if (op_aligned(op)) c += (uint32_t)(k2 - k); else if (k2 > k) gap(k, k2);
+                        k = k2; rp += l;
+                    }
+                    if (rp < r.endpos) {                                      // no CIGAR / zero reference length: the position itself, without a base
+                        const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, r.endpos);
+                        if (k2 > k) gap(k, k2);
+                    }
+                } else
                 c = (uint32_t)(lower_snp<K, MODE>(a, d, sm, k_lo, r.endpos) - k_lo);
             }
             // wave-level: each wave parks its 64 reads in its own LDS segment and deals its pairs out over its 64
@@ -811,7 +861,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             const uint32_t total = __shfl(inc, 63, 64);
             if (total) {
                 const int wb = tid & ~63;                                   // first slot of this wave's segment
-                sm.pr_pos[tid] = r.pos; sm.pr_c0[tid] = r.c0; sm.pr_c1[tid] = r.c1; sm.pr_cell[tid] = r.cell; sm.pr_umi[tid] = r.umi;
+                sm.pr_pos[tid] = r.pos; sm.pr_end[tid] = r.endpos; sm.pr_c0[tid] = r.c0; sm.pr_c1[tid] = r.c1; sm.pr_cell[tid] = r.cell; sm.pr_umi[tid] = r.umi;
                 sm.pr_klo[tid] = k_lo; sm.pr_s0[tid] = cur.s0; sm.pr_sl[tid] = cur.s1 - cur.s0; sm.pr_off[tid] = inc - c;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -820,17 +870,19 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
 #pragma unroll
                     for (int st = 0; st < 6; st++) { const int mid = (lo + hi + 1) >> 1; if (sm.pr_off[wb + mid] <= pi) lo = mid; else hi = mid - 1; }
                     const int u = wb + lo;
-                    const int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
-                    const int al = allele_at_slot<K, MODE>(a, d, sm, u, tile0 + j * JOIN_BLOCK + u, snp_p0<K, MODE>(a, sm, k));
+                    int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
+                    int al;
+                    if constexpr (JoinSmem<K, MODE>::SPLIT) al = nth_aligned_snp<K, MODE>(a, d, sm, u, pi - sm.pr_off[u], k);
+                    else al = allele_at_slot<K, MODE>(a, d, sm, u, tile0 + j * JOIN_BLOCK + u, snp_p0<K, MODE>(a, sm, k));
                     const K key = a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]);
                     const uint64_t val = ((d.ordinal_base + (uint64_t)(tile0 + j * JOIN_BLOCK + u)) << ALLELE_BITS) | (uint64_t)(al + 1);
-                    if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val);
+                    if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val & ~(uint64_t)((1u << ALLELE_BITS) - 1));   // a record of one SNP
                     else emit<K, MODE>(a, sm, key, val);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();                            // the segment is overwritten by the wave's next sweep
             }
-            acc += c;
+            acc += c + n_gap;
         } else if (r.ok) {
             uor |= r.umi;
             if (MODE == XCK_MODE_BASEFC) acc += join_regions<K, MODE>(a, d, sm, r);
@@ -987,10 +1039,19 @@ __global__ void k_first_read(const K* __restrict__ k, const uint64_t* __restrict
 }
 
 // ---- split mode (64-bit keys): the sorted stream holds only hits WITH a base; the hits without one are looked up ----
+// Blocked Bloom filter over (cell, UMI, SNP >> 5) of the runs: one 64-bit word, two bits per entry.  A gap record asks it
+// whether its molecule shows a base anywhere in the same block of 32 SNPs before any exact lookup is made.
+__device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t blk, unsigned long long mask_words, unsigned long long& word, unsigned long long& bits) {
+    unsigned long long x = cellumi ^ ((unsigned long long)blk * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    word = x & mask_words;
+    bits = (1ull << ((x >> 40) & 63)) | (1ull << ((x >> 48) & 63));
+}
 // per key run: allele code + ordinal of its first read with a base, at the run head; first / one-past-last index of every SNP
 template <class K>
 __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
-                             uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, uint32_t* __restrict__ row_lo, uint32_t* __restrict__ row_hi) {
+                             uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, uint32_t* __restrict__ row_lo, uint32_t* __restrict__ row_hi,
+                             unsigned long long* __restrict__ bloom, unsigned long long bloom_mask) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const K me = k[i];
@@ -1002,29 +1063,45 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
     for (long long j = i + 1; j < n && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
     al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));          // nibble + 1 (never 0 here)
     ord_out[i] = best >> ALLELE_BITS;
+    unsigned long long word, bits;
+    bloom_slot((unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1)), row >> 5, bloom_mask, word, bits);
+    atomicOr(&bloom[word], bits);
 }
-// every hit without a base: if its (SNP, cell, UMI) has a run and this read comes EARLIER in fetch order than the run's
-// first read with a base, the key belongs to this read (baf/fc/mcount.py:118-119) and the run contributes nothing.
-// The stream is in tile order, so neighbouring threads search the same few SNPs: the lookups stay in L2.
+// every gap record (first SNP, cell, UMI | ordinal, count - 1): for each of its SNPs, if (SNP, cell, UMI) has a run and
+// this read comes EARLIER in fetch order than the run's first read with a base, the key belongs to this read
+// (baf/fc/mcount.py:118-119) and the run contributes nothing.  The Bloom filter answers "no" for almost every record;
+// the exact lookups that remain are binary searches inside one SNP's run (the stream is in tile order, so
+// neighbouring threads search the same few SNPs and stay in L2).
 template <class K>
 __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp,
                                                  const K* __restrict__ keys, KeyLayout<K> kl, const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ row_hi,
-                                                 const uint64_t* __restrict__ ord, uint8_t* __restrict__ al) {
-    // (running several searches per lane in lockstep was measured: 17 ms instead of 10 ms at 330 M entries - the kernel is
-    // bound by L2 transactions, not by the latency of one chain)
+                                                 const uint64_t* __restrict__ ord, uint8_t* __restrict__ al,
+                                                 const unsigned long long* __restrict__ bloom, unsigned long long bloom_mask, uint32_t n_rows) {
     const unsigned long long n = sp.start[NSHARD];
+    const int low = kl.cbits + kl.ubits;
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
         int sh = 0;
 #pragma unroll
         for (int q = 1; q < NSHARD; q++) sh += (i >= sp.start[q]) ? 1 : 0;
         const unsigned long long j = (unsigned long long)sh * cap + (i - sp.start[sh]);
-        const K key = nk[j];
-        const uint32_t row = kl.row(key);
-        uint32_t lo = row_lo[row], hi = row_hi[row];
-        if (lo >= hi) continue;                                         // no read shows a base at this SNP
-        const uint32_t end = hi;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
-        if (lo < end && keys[lo] == key && (nv[j] >> ALLELE_BITS) < ord[lo]) al[lo] = 0;   // benign race: every writer stores 0
+        const K rec = nk[j];
+        const uint64_t v = nv[j];
+        const uint64_t ordn = v >> ALLELE_BITS;
+        const uint32_t k1 = kl.row(rec), k2 = min(k1 + (uint32_t)(v & ((1u << ALLELE_BITS) - 1)) + 1u, n_rows);
+        const K cellumi = rec & ((K(1) << low) - 1);
+        for (uint32_t blk = k1 >> 5; blk <= (k2 - 1) >> 5; blk++) {
+            unsigned long long word, bits;
+            bloom_slot((unsigned long long)cellumi, blk, bloom_mask, word, bits);
+            if ((bloom[word] & bits) != bits) continue;                 // this molecule shows no base in this block of SNPs
+            for (uint32_t srow = max(k1, blk << 5); srow < min(k2, (blk + 1) << 5); srow++) {
+                uint32_t lo = row_lo[srow], hi = row_hi[srow];
+                if (lo >= hi) continue;
+                const uint32_t end = hi;
+                const K key = (K(srow) << low) | cellumi;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+                if (lo < end && keys[lo] == key && ordn < ord[lo]) al[lo] = 0;   // benign race: every writer stores 0
+            }
+        }
     }
 }
 template <class K>
@@ -1824,7 +1901,7 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 8 + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 8 + std::max<size_t>(n * 4, 8192) + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
         { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
@@ -1837,15 +1914,20 @@ static int finish_t(EngineImpl* im) {
         if (sizeof(K) == 8 && split_mode(im)) {
             const size_t ns = std::max<size_t>((size_t)im->n_snps_sorted, 1);
             uint64_t* ordv = im->ws1.get<uint64_t>(n); uint32_t* row_lo = im->ws1.get<uint32_t>(2 * ns); uint32_t* row_hi = row_lo + ns;
-            if (!ordv || !row_lo) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
+            size_t bw = 1024; while (bw < n / 4) bw <<= 1;                // ~4 runs (8 bits) per 64-bit word
+            unsigned long long* bloom = im->ws1.get<unsigned long long>(bw);
+            if (!ordv || !row_lo || !bloom) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
             HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(uint32_t), im->s_comp));
-            hipLaunchKernelGGL((k_first_base<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, ordv, row_lo, row_hi);
+            HIP_TRY(hipMemsetAsync(bloom, 0, bw * sizeof(unsigned long long), im->s_comp));
+            hipLaunchKernelGGL((k_first_base<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, ordv, row_lo, row_hi,
+                               bloom, (unsigned long long)(bw - 1));
             HIP_TRY(hipGetLastError());
             if (im->ncursor) {
                 ShardSpan nsp; nsp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh];
                 hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<size_t>((im->ncursor + 255) / 256, 16384)), dim3(256), 0, im->s_comp,
                                    (const K*)im->d_nkeys, (const uint64_t*)im->d_nvals, (unsigned long long)im->hit_cap, nsp,
-                                   (const K*)alt, kl, (const uint32_t*)row_lo, (const uint32_t*)row_hi, (const uint64_t*)ordv, al);
+                                   (const K*)alt, kl, (const uint32_t*)row_lo, (const uint32_t*)row_hi, (const uint64_t*)ordv, al,
+                                   (const unsigned long long*)bloom, (unsigned long long)(bw - 1), (uint32_t)ns);
                 HIP_TRY(hipGetLastError());
             }
             hipLaunchKernelGGL((k_tally<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally);
