@@ -1039,8 +1039,9 @@ __global__ void k_first_read(const K* __restrict__ k, const uint64_t* __restrict
 }
 
 // ---- split mode (64-bit keys): the sorted stream holds only hits WITH a base; the hits without one are looked up ----
-// Blocked Bloom filter over (cell, UMI, SNP >> 5) of the runs: one 64-bit word, two bits per entry.  A gap record asks it
-// whether its molecule shows a base anywhere in the same block of 32 SNPs before any exact lookup is made.
+// Blocked Bloom filter over the runs, two levels in one table: (cell, UMI, SNP >> 5) and (cell, UMI, SNP); one 64-bit word,
+// two bits per entry.  A gap record first asks whether its molecule shows a base anywhere in the same block of 32 SNPs, then
+// per SNP, before any exact lookup is made.
 __device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t blk, unsigned long long mask_words, unsigned long long& word, unsigned long long& bits) {
     unsigned long long x = cellumi ^ ((unsigned long long)blk * 0x9E3779B97F4A7C15ull);
     x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
@@ -1064,7 +1065,10 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
     al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));          // nibble + 1 (never 0 here)
     ord_out[i] = best >> ALLELE_BITS;
     unsigned long long word, bits;
-    bloom_slot((unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1)), row >> 5, bloom_mask, word, bits);
+    const unsigned long long cu = (unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1));
+    bloom_slot(cu, row >> 5, bloom_mask, word, bits);                 // level 1: (molecule, block of 32 SNPs)
+    atomicOr(&bloom[word], bits);
+    bloom_slot(cu, 0x80000000u | row, bloom_mask, word, bits);       // level 2: (molecule, SNP)
     atomicOr(&bloom[word], bits);
 }
 // every gap record (first SNP, cell, UMI | ordinal, count - 1): for each of its SNPs, if (SNP, cell, UMI) has a run and
@@ -1094,6 +1098,8 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
             bloom_slot((unsigned long long)cellumi, blk, bloom_mask, word, bits);
             if ((bloom[word] & bits) != bits) continue;                 // this molecule shows no base in this block of SNPs
             for (uint32_t srow = max(k1, blk << 5); srow < min(k2, (blk + 1) << 5); srow++) {
+                bloom_slot((unsigned long long)cellumi, 0x80000000u | srow, bloom_mask, word, bits);
+                if ((bloom[word] & bits) != bits) continue;             // ... and none at this SNP
                 uint32_t lo = row_lo[srow], hi = row_hi[srow];
                 if (lo >= hi) continue;
                 const uint32_t end = hi;
@@ -1901,7 +1907,7 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 8 + std::max<size_t>(n * 4, 8192) + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 8 + std::max<size_t>(n * 8, 8192) + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
         { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
@@ -1914,7 +1920,7 @@ static int finish_t(EngineImpl* im) {
         if (sizeof(K) == 8 && split_mode(im)) {
             const size_t ns = std::max<size_t>((size_t)im->n_snps_sorted, 1);
             uint64_t* ordv = im->ws1.get<uint64_t>(n); uint32_t* row_lo = im->ws1.get<uint32_t>(2 * ns); uint32_t* row_hi = row_lo + ns;
-            size_t bw = 1024; while (bw < n / 4) bw <<= 1;                // ~4 runs (8 bits) per 64-bit word
+            size_t bw = 1024; while (bw < n / 2) bw <<= 1;                // two entries per run, ~4 entries (8 bits) per 64-bit word
             unsigned long long* bloom = im->ws1.get<unsigned long long>(bw);
             if (!ordv || !row_lo || !bloom) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
             HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(uint32_t), im->s_comp));
