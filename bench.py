@@ -84,8 +84,8 @@ def main():
     filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
     depth = 1 if args.serial else max(1, args.depth)
     engs_fc = [Engine(capi.XCK_MODE_BASEFC, names, regions, args.cells, device=dev_idx, min_include=0.9, **filt) for _ in range(depth)]
-    eng_baf = Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=dev_idx,
-                     min_count=1, min_maf=0, no_dup_hap=True, **filt)
+    engs_baf = [Engine(capi.XCK_MODE_BAF, names, regions, args.cells, snps=snps, device=dev_idx,
+                       min_count=1, min_maf=0, no_dup_hap=True, **filt) for _ in range(depth)]
     b_fc = [soa_torch.device_batch(capi, arrays, c, s, e, False) for c, s, e in batches]
     b_baf = [soa_torch.device_batch(capi, arrays, c, s, e, True) for c, s, e in batches]
 
@@ -105,6 +105,7 @@ def main():
     acc = dict(ms_join_fc=0.0, ms_join_baf=0.0, ms_fin_fc=0.0, ms_fin_baf=0.0, ms_d2h_fc=0.0)
     last = {}                                              # latest host views of the four matrices + stats
     pending = []                                           # basefc engines whose copy-out is still in flight
+    pending_baf = []                                       # pileup engines, likewise (AD / DP / OTH are 0.36 GB at configs[2])
 
     def collect_fc(eng):
         t_a = time.perf_counter()
@@ -124,24 +125,34 @@ def main():
             host["fin_async"] += time.perf_counter() - t_a
         return eng_fc
 
-    def pass_baf():
-        push_all(eng_baf, b_baf)
+    def collect_baf(eng):
         t_a = time.perf_counter()
-        last.update(eng_baf.finish(copy=False))
-        host["fin_baf"] += time.perf_counter() - t_a
-        st = eng_baf.stats(); last["sbaf"] = st
+        last.update(eng.finish(copy=False))
+        host["collect"] += time.perf_counter() - t_a
+        st = eng.stats(); last["sbaf"] = st
         acc["ms_join_baf"] += st["ms_join"]; acc["ms_fin_baf"] += st["ms_sort"]
 
+    def pass_baf(i):
+        eng_baf = engs_baf[i % depth]
+        push_all(eng_baf, b_baf)
+        if args.serial:
+            collect_baf(eng_baf)
+        else:
+            t_a = time.perf_counter()
+            eng_baf.finish_async(); pending_baf.append(eng_baf)
+            host["fin_baf"] += time.perf_counter() - t_a
+        return eng_baf
+
     def step(i):
-        # basefc and pileup are independent engines (own handles, streams and accumulators).  The basefc
-        # fold ends with a 170 MB copy-out of the count matrix over PCIe (~3 ms): it is only ENQUEUED (xck_finish_async)
-        # and drains on the copy stream while the CUs run the pileup pass and - with --depth 2, two basefc engines used
-        # in rotation, as a multi-sample run does - the next pass's join and fold.  Every pass's matrices are collected
-        # (xck_finish) inside the timed region, at the latest in sync().
+        # basefc and pileup are independent engines (own handles, streams and accumulators).  Each fold ends with the
+        # copy-out of its matrices over PCIe (1.2 GB + 0.4 GB at configs[2], ~27 ms): it is only ENQUEUED
+        # (xck_finish_async) and drains on the copy stream while the CUs run the other pass and - with --depth 2, two
+        # engines per mode used in rotation, as a multi-sample run does - the next pass's join and fold.  Every pass's
+        # matrices are collected (xck_finish) inside the timed region, at the latest in sync().
         # (driving the two passes from two host threads was measured: the kernels of both passes then share the CUs
         # and the step gets slower, 5.2 vs 4.7 ms)
         eng_fc = pass_fc(i)
-        pass_baf()
+        eng_baf = pass_baf(i)
         if world > 1:
             # all-gatherv of the per-contig sparse blocks to the writer rank, GPU to GPU over xGMI (RCCL): sizes
             # first, then ONE gather of the padded [row|col|val] blocks that are still resident in HBM.  It is only
@@ -151,18 +162,23 @@ def main():
             last["_gathered_sizes"] = gatherer.start(blocks)
         while len(pending) > depth - 1:
             collect_fc(pending.pop(0))
+        while len(pending_baf) > depth - 1:
+            collect_baf(pending_baf.pop(0))
 
     # setup, not a step: every engine sizes its device buffers on first use (hit buffers grow by replay, workspaces
     # and pinned result buffers are allocated) - do that once per engine before the warmup passes
     for e in engs_fc:
         push_all(e, b_fc); e.finish(copy=False)
-    push_all(eng_baf, b_baf); eng_baf.finish(copy=False)
+    for e in engs_baf:
+        push_all(e, b_baf); e.finish(copy=False)
 
     gatherer = BlockGatherer(world, rank, device, backend_is_nccl=not shared_gpu) if world > 1 else None
 
     def sync():
         while pending:
             collect_fc(pending.pop(0))
+        while pending_baf:
+            collect_baf(pending_baf.pop(0))
         if gatherer is not None:
             gatherer.wait()                               # the last exchange is inside the timed region
         torch.cuda.synchronize()
@@ -264,7 +280,7 @@ def main():
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64", data="synthetic",
                 config=dict(workload="BASELINE.json %s: %d reads/GPU, %d barcodes, %d het SNPs, %d genes, 24 hg38 contigs; "
                                      "basefc + pileup per step, SoA resident in HBM" % (cfg_name, n_reads, args.cells, len(snps), len(regions)),
-                            reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world, pipeline="serial" if args.serial else "copy-out overlapped, %d basefc engine(s) in rotation" % depth,
+                            reads_per_gpu=n_reads, data_checksum=data_checksum, parallelism="contig-shard x%d" % world, pipeline="serial" if args.serial else "copy-out overlapped, %d engine(s) per mode in rotation" % depth,
                             nnz={kk: (int(sum(sz[j] for sz in res["_gathered_sizes"])) if world > 1 else int(len(res[kk][0]))) for j, kk in enumerate(("count", "ad", "dp", "oth"))},
                             hits=dict(basefc=int(hits_fc), pileup=int(hits_baf),
                                       basefc_after_lds_dedup=int(sfc["n_hits_unique"]), pileup_after_lds_dedup=int(sbaf["n_hits_unique"]))),

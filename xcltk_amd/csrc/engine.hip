@@ -1645,7 +1645,9 @@ static int launch_queue(EngineImpl* im, int slot_idx) {
     int rc = complete_pending(im); if (rc) return rc;
     { unsigned long long mx = 0;
       for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, std::max(im->cur[sh], im->ncur[sh]));
-      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / NSHARD + 65536); if (rc) return rc; }
+      // first guess: 1.25 keys per queued read (after the LDS de-duplication a 10x run leaves ~0.8); a launch that needs
+      // more sets the overflow flag and is replayed into grown buffers, and the capacity is kept for the next pass
+      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / 4 / NSHARD + 65536); if (rc) return rc; }
     im->inflight.swap(im->queue); im->queue.clear();
     im->inflight_reads = im->queued_reads; im->queued_reads = 0;
     im->inflight_slot = slot_idx;
