@@ -34,7 +34,7 @@ typedef unsigned __int128 u128;
 #define XCK_WS 15
 #endif
 #ifndef XCK_EXP
-#define XCK_EXP 0          // timing experiments only (wrong results): 1 no emit, 2 no fp64 divide, 4 no CIGAR re-walk, 8 no flush, 16 no join
+#define XCK_EXP 0          // timing experiments only (wrong results): 1 no emit, 2 no fp64 divide, 4 no CIGAR re-walk, 8 no flush, 16 no join, 32 pileup: no SNP work, 64 pileup: count only
 #endif
 #ifndef XCK_HASH_MUL64
 #define XCK_HASH_MUL64 0
@@ -195,10 +195,10 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r, double 
 #define XCK_BAF_SPLIT 1           // pileup, 64-bit keys: hits without a base go to a second stream that is never sorted
 #endif
 #ifndef XCK_BAF_NQUEUE_BYTES
-#define XCK_BAF_NQUEUE_BYTES 2048   // split mode: queue of the gap records (16 B each, about one per spliced read)
+#define XCK_BAF_NQUEUE_BYTES 4096   // split mode: queue of the gap records (16 B each, about one per spliced read), flushed at the tile end
 #endif
 #ifndef XCK_BAF_BQUEUE_BYTES
-#define XCK_BAF_BQUEUE_BYTES 2048   // split mode: queue of the hits with a base (~1 in 10)
+#define XCK_BAF_BQUEUE_BYTES 4096   // split mode: queue of the hits with a base (~1 in 10), flushed at the tile end
 #endif
 #ifndef XCK_BAF_MAP
 #define XCK_BAF_MAP 0             // 1: pileup hits go through the LDS key -> min(value) map instead of the queue
@@ -263,7 +263,7 @@ template <class K, int MODE> struct JoinSmem {
     static constexpr int PR = (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) ? JOIN_BLOCK : 1;
     uint64_t pr_umi[PR];
     int32_t  pr_pos[PR], pr_end[PR], pr_cell[PR], pr_klo[PR];
-    uint32_t pr_c0[PR], pr_c1[PR], pr_s0[PR], pr_sl[PR], pr_off[PR];
+    uint32_t pr_c0[PR], pr_c1[PR], pr_s0[PR], pr_sl[PR], pr_off[PR]; int32_t pr_idx[PR];
     __device__ K* keys() { return reinterpret_cast<K*>(store); }
     __device__ uint64_t* vals() { return reinterpret_cast<uint64_t*>(store + (size_t)QCAP * sizeof(K)); }
     __device__ unsigned long long* hkeys() { return reinterpret_cast<unsigned long long*>(store); }            // hashed mode
@@ -763,6 +763,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     STAMP(2);
     // ---- 8 coalesced sweeps over the tile ----
     uint32_t acc = 0;
+    int pr_n = 0; uint32_t pr_total = 0;                              // pileup: parked reads / their pairs (wave-uniform)
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
     constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? JoinSmem<K, MODE>::SLOTS : JoinSmem<K, MODE>::QCAP;
 #ifndef XCK_FLUSH_END_ONLY
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
 #endif
     // set mode: the de-duplicated fill of a 1024-read tile is a few hundred keys, so flush once, at the end
     // (better de-duplication, half the cursor atomics); saturation still spills correctly through emit_global()
-    constexpr int FLUSH_EVERY = JoinSmem<K, MODE>::USE_SET ? (JoinSmem<K, MODE>::HAS_VAL ? XCK_BAF_FLUSH_EVERY : TILE_ITEMS)
+    constexpr int FLUSH_EVERY = JoinSmem<K, MODE>::SPLIT ? TILE_ITEMS : JoinSmem<K, MODE>::USE_SET ? (JoinSmem<K, MODE>::HAS_VAL ? XCK_BAF_FLUSH_EVERY : TILE_ITEMS)
                               : ((CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)));
     if (DENSE) {
         // ---- region-major evaluation: every thread keeps its 4 reads in registers; the loop over the tile's
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
             int32_t k_lo = 0; uint32_t c = 0, n_gap = 0;
             const int32_t w_lo = r.pos >> WS;
-            if (r.ok && w_lo < d.n_swin) {
+            if (r.ok && w_lo < d.n_swin && !(XCK_EXP & 32)) {
                 const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
                 k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
                 if constexpr (JoinSmem<K, MODE>::SPLIT) {
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                     // costs one 16-byte record instead of 20 hits.
                     const uint64_t ordv = (d.ordinal_base + (uint64_t)i) << ALLELE_BITS;
                     auto gap = [&](int32_t ka, int32_t kb) {
-                        for (int32_t ks = ka; ks < kb; ks += 32)
+                        if (!(XCK_EXP & 64)) for (int32_t ks = ka; ks < kb; ks += 32)
                             emit_nobase<K, MODE>(a, sm, a.kl.make((uint32_t)ks, (uint32_t)r.cell, r.umi), ordv | (uint64_t)(min(kb - ks, 32) - 1));
                         n_gap += (uint32_t)(kb - ka);
                     };
@@ -853,35 +854,44 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                 } else
                 c = (uint32_t)(lower_snp<K, MODE>(a, d, sm, k_lo, r.endpos) - k_lo);
             }
-            // wave-level: each wave parks its 64 reads in its own LDS segment and deals its pairs out over its 64
-            // lanes - no block barrier (a wave's LDS operations execute in order)
+            // wave-level: only the reads that HAVE pairs are parked (compacted) in the wave's own 64-slot LDS segment; the
+            // pairs are dealt out over the 64 lanes when the segment fills up or the tile ends - one CIGAR walk + base
+            // fetch per lane per round at high lane utilisation, no block barrier (a wave's LDS operations execute in order)
             uint32_t inc = c;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t_ = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t_; }
-            const uint32_t total = __shfl(inc, 63, 64);
-            if (total) {
-                const int wb = tid & ~63;                                   // first slot of this wave's segment
-                sm.pr_pos[tid] = r.pos; sm.pr_end[tid] = r.endpos; sm.pr_c0[tid] = r.c0; sm.pr_c1[tid] = r.c1; sm.pr_cell[tid] = r.cell; sm.pr_umi[tid] = r.umi;
-                sm.pr_klo[tid] = k_lo; sm.pr_s0[tid] = cur.s0; sm.pr_sl[tid] = cur.s1 - cur.s0; sm.pr_off[tid] = inc - c;
+            const uint32_t total = (XCK_EXP & 64) ? 0u : __shfl(inc, 63, 64);
+            const unsigned long long has = __ballot(c > 0 && !(XCK_EXP & 64));
+            const int n_new = __popcll(has);
+            const int wb = tid & ~63;                                       // first slot of this wave's segment
+            auto drain = [&]() {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t pi = lane; pi < total; pi += 64) {
-                    int lo = 0, hi = 63;                                    // the read this pair belongs to: last u with pr_off[u] <= pi
-#pragma unroll
-                    for (int st = 0; st < 6; st++) { const int mid = (lo + hi + 1) >> 1; if (sm.pr_off[wb + mid] <= pi) lo = mid; else hi = mid - 1; }
+                for (uint32_t pi = lane; pi < pr_total; pi += 64) {
+                    int lo = 0, hi = pr_n - 1;                              // the read this pair belongs to: last u with pr_off[u] <= pi
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sm.pr_off[wb + mid] <= pi) lo = mid; else hi = mid - 1; }
                     const int u = wb + lo;
                     int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
                     int al;
                     if constexpr (JoinSmem<K, MODE>::SPLIT) al = nth_aligned_snp<K, MODE>(a, d, sm, u, pi - sm.pr_off[u], k);
-                    else al = allele_at_slot<K, MODE>(a, d, sm, u, tile0 + j * JOIN_BLOCK + u, snp_p0<K, MODE>(a, sm, k));
+                    else al = allele_at_slot<K, MODE>(a, d, sm, u, sm.pr_idx[u], snp_p0<K, MODE>(a, sm, k));
                     const K key = a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]);
-                    const uint64_t val = ((d.ordinal_base + (uint64_t)(tile0 + j * JOIN_BLOCK + u)) << ALLELE_BITS) | (uint64_t)(al + 1);
+                    const uint64_t val = ((d.ordinal_base + (uint64_t)sm.pr_idx[u]) << ALLELE_BITS) | (uint64_t)(al + 1);
                     if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val & ~(uint64_t)((1u << ALLELE_BITS) - 1));   // a record of one SNP
                     else emit<K, MODE>(a, sm, key, val);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();                            // the segment is overwritten by the wave's next sweep
+                __builtin_amdgcn_wave_barrier();                            // the segment is free again
+                pr_n = 0; pr_total = 0;
+            };
+            if (pr_n + n_new > 64) drain();
+            if (c > 0 && !(XCK_EXP & 64)) {
+                const int u = wb + pr_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+                sm.pr_pos[u] = r.pos; sm.pr_end[u] = r.endpos; sm.pr_c0[u] = r.c0; sm.pr_c1[u] = r.c1; sm.pr_cell[u] = r.cell; sm.pr_umi[u] = r.umi;
+                sm.pr_klo[u] = k_lo; sm.pr_s0[u] = cur.s0; sm.pr_sl[u] = cur.s1 - cur.s0; sm.pr_off[u] = pr_total + inc - c; sm.pr_idx[u] = i;
             }
+            pr_n += n_new; pr_total += total;
+            if (j + 1 == TILE_ITEMS && pr_n) drain();
             acc += c + n_gap;
         } else if (r.ok) {
             uor |= r.umi;
