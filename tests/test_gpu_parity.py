@@ -182,3 +182,79 @@ def test_device_resident_batches_more_than_one_fused_launch():
             exp = O.run_oracle(cfg, [b for b, _ in hb])
             util.assert_coo_equal(got, exp, mats)
         eng.close()
+
+
+def _dense_pileup_case(seed, n_reads, n_cells, n_umis, snp_step=37, span=120000, max_batch=5000):
+    """Hand-rolled reads over ONE region with a SNP every `snp_step` bp: long N gaps (hundreds of SNPs per gap: many
+    32-SNP gap records), D gaps, insertions / clips, reads without sequence, unmapped-flag reads with a CIGAR, and few
+    (cell, UMI) pairs, so that 'the first read of a (SNP, cell, UMI) wins - even without a base' decides most keys."""
+    rng = np.random.default_rng(seed)
+    names = ["1"]
+    regions = [("1", 1, span, "g0"), ("1", 2000, 50000, "g1"), ("1", 60000, 61000, "g2")]
+    snps = [("1", p, "ACGT"[(p // snp_step) % 4], "ACGT"[(p // snp_step + 1 + (p % 3)) % 4], p % 2, 1 - p % 2)
+            for p in range(10, span - 10, snp_step)]
+    M, I, D, N, S = 0, 1, 2, 3, 4
+    recs = []
+    for _ in range(n_reads):
+        pos = int(rng.integers(0, span - 30000))
+        kind = rng.integers(0, 10)
+        if kind < 3:
+            cig = [(M, 91)]
+        elif kind < 6:
+            a = int(rng.integers(10, 80)); cig = [(M, a), (N, int(rng.integers(50, 25000))), (M, 91 - a)]
+        elif kind == 6:
+            a = int(rng.integers(10, 60)); cig = [(M, a), (D, int(rng.integers(1, 300))), (M, 91 - a)]
+        elif kind == 7:
+            a = int(rng.integers(10, 60)); cig = [(S, 5), (M, a), (I, 3), (M, 20), (N, int(rng.integers(100, 3000))), (M, 63 - a)]
+        elif kind == 8:
+            a = int(rng.integers(5, 40)); cig = [(M, a), (N, 2000), (M, 20), (N, 1500), (M, 71 - a)]
+        else:
+            cig = [(M, 40), (N, 9000), (M, 51)]
+        qlen = sum(l for op, l in cig if op in (M, I, S))
+        noseq = rng.random() < 0.04
+        flag = 0
+        if rng.random() < 0.03:
+            flag |= 4                                      # unmapped flag with a CIGAR: reference span collapses to 1
+        if rng.random() < 0.3:
+            flag |= 16
+        nib = (1 << rng.integers(0, 4, qlen)).astype(np.uint8)
+        nib[rng.random(qlen) < 0.01] = 15
+        if qlen % 2:
+            nib = np.append(nib, 0)
+        seq = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8) if not noseq else np.zeros(0, np.uint8)
+        cell = int(rng.integers(-1, n_cells))
+        umi = np.uint64((1 << 24) | int(rng.integers(0, n_umis)))
+        recs.append((pos, cig, seq, flag, cell, umi))
+    recs.sort(key=lambda r: r[0])
+    batches = []
+    for s in range(0, len(recs), max_batch):
+        part = recs[s:s + max_batch]
+        cig_off = np.zeros(len(part) + 1, np.uint32); seq_off = np.zeros(len(part) + 1, np.uint32)
+        cw, sq = [], []
+        for j, (pos, cig, seq, flag, cell, umi) in enumerate(part):
+            cw += [(l << 4) | op for op, l in cig]; sq.append(seq)
+            cig_off[j + 1] = len(cw); seq_off[j + 1] = seq_off[j] + len(seq)
+        d = dict(contig=0, ordinal_base=s, pos=np.array([r[0] for r in part], np.int32), flag=np.array([r[3] for r in part], np.uint16),
+                 mapq=np.full(len(part), 60, np.uint8), cell=np.array([r[4] for r in part], np.int32),
+                 umi=np.array([r[5] for r in part], np.uint64), cig_off=cig_off, cigar=np.array(cw, np.uint32),
+                 seq_off=seq_off, seq=np.concatenate(sq) if sq else np.zeros(0, np.uint8))
+        batches.append(util.batch_from_dict(d))
+    return regions, snps, names, batches
+
+
+@pytest.mark.parametrize("flags", [0, capi.XCK_F_FORCE_KEY128])
+@pytest.mark.parametrize("opts", [dict(excl_flag=0), dict(), dict(no_dup_hap=False, min_count=2, min_maf=0.05)])
+def test_pileup_gap_records_and_claims(flags, opts):
+    """Split pileup path (gap records, Bloom filter, claims) against the oracle where gaps cover hundreds of SNPs and
+    (cell, UMI) pairs are reused by many reads; the 128-bit path (single sorted stream) must agree too."""
+    regions, snps, names, batches = _dense_pileup_case(seed=5, n_reads=30000, n_cells=6, n_umis=40)
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 6, batches, flags=flags, min_len=10, **opts)
+    assert len(exp["dp"][0]) > 5 and int(exp["dp"][2].sum()) > 20
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+
+
+def test_pileup_gap_records_many_cells():
+    regions, snps, names, batches = _dense_pileup_case(seed=9, n_reads=60000, n_cells=500, n_umis=3000, snp_step=101, max_batch=20000)
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 500, batches, min_len=10)
+    assert len(exp["dp"][0]) > 100
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])

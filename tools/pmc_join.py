@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run k_join on the bench workload (BASELINE configs[2] by default) for ONE configuration, three passes, so that a
 rocprofv3 --pmc run can attribute HBM counters to the LAST k_join dispatch (buffers are sized by then, no replay).
-usage: pmc_join.py {fc|fc_filtered|baf} [reads] [cells] [snps]
+usage: pmc_join.py {fc|fc_filtered|baf|baf_filtered} [reads] [cells] [snps]
 fc_filtered rejects every read (min_mapq above any MAPQ): its byte count is known, which calibrates FETCH_SIZE."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ n_snps = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000
 regions, snps, names = soa.make_tables(33472, n_snps, soa.HG38_LENGTHS, seed=2)
 arrays, batches = soa_torch.gen_reads_device(regions, names, n, cells, seed=100, device=torch.device("cuda", 0))
 print("n_reads", arrays["n_reads"], "n_cig", arrays["n_cig"])
-mode, kw = {"fc": (1, dict(min_mapq=20)), "fc_filtered": (1, dict(min_mapq=256)), "baf": (2, dict(min_mapq=20))}[label]
+mode, kw = {"fc": (1, dict(min_mapq=20)), "fc_filtered": (1, dict(min_mapq=256)), "baf": (2, dict(min_mapq=20)), "baf_filtered": (2, dict(min_mapq=256))}[label]
 eng = Engine(mode, names, regions, cells, snps=snps if mode == 2 else (), device=0, min_len=30, excl_flag=772, **kw)
 for rep in range(3):
     eng.reset()
