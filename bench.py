@@ -246,10 +246,13 @@ def main():
         import oracle as O
         import util
         take, tot = [], 0
-        for c, s, e in sorted(batches, key=lambda b: b[2] - b[1]):   # whole contigs only (their matrix rows are complete), smallest first
+        per_contig = {}
+        for c, s, e in batches:                        # a long contig may come as several batches
+            per_contig.setdefault(c, []).append((c, s, e))
+        for c in sorted(per_contig, key=lambda c: sum(e - s for _, s, e in per_contig[c])):   # whole contigs only (their matrix rows are complete), smallest first
             if tot >= args.cpu_sample:
                 break
-            take.append((c, s, e)); tot += e - s
+            take += per_contig[c]; tot += sum(e - s for _, s, e in per_contig[c])
         hb = [util.batch_from_dict(soa_torch.host_batch_dict(arrays, c, s, e, True)) for c, s, e in take]
         tc = 0.0
         sample_contigs = {names[c] for c, _, _ in take}

@@ -96,9 +96,11 @@ def gen_reads_device(regions, names, n_reads, n_cells, seed, device, umi_len=12,
     cigar[base] = w0.to(torch.int32)
     m2 = ncig >= 2; cigar[base[m2] + 1] = w1[m2].to(torch.int32)
     m3 = ncig >= 3; cigar[base[m3] + 2] = w2[m3].to(torch.int32)
+    # offsets are kept as absolute int64; device_batch() turns a slice into the u32 offsets of the C-ABI, relative to the
+    # slice's own first CIGAR word / sequence byte (one batch may not exceed 4 GiB of either, see max_batch below)
     arrays = dict(pos=pos.to(torch.int32).contiguous(), flag=flag.contiguous(), mapq=mapq.contiguous(),
-                  cell=cell.contiguous(), umi=umi.contiguous(), cig_off=cig_off.to(torch.int32).contiguous(),
-                  cigar=cigar, n_cig=n_cig, n_reads=n, read_len=L)
+                  cell=cell.contiguous(), umi=umi.contiguous(), cig_off=cig_off.contiguous(),
+                  cigar=cigar, n_cig=n_cig, n_reads=n, read_len=L, _rel={})
     if with_seq:
         nb = (L + 1) // 2
         seq = torch.empty(n * nb, dtype=torch.uint8, device=device)
@@ -110,19 +112,22 @@ def gen_reads_device(regions, names, n_reads, n_cells, seed, device, umi_len=12,
             lo = torch.bitwise_left_shift(torch.ones_like(b), b & 3)
             seq[s:e] = (hi << 4) | lo
         arrays["seq"] = seq
-        arrays["seq_off"] = (torch.arange(n + 1, dtype=torch.int64, device=device) * nb).to(torch.int32)
+        arrays["seq_off"] = torch.arange(n + 1, dtype=torch.int64, device=device) * nb
     bounds = torch.nonzero(contig[1:] != contig[:-1]).flatten() + 1
     starts = [0] + bounds.tolist()
     ends = bounds.tolist() + [n]
     cids = contig[torch.tensor(starts, device=device)].tolist()
-    batches = [(int(c), int(s), int(e)) for c, s, e in zip(cids, starts, ends)]
+    max_batch = max(1, (7 << 29) // max((L + 1) // 2, 12))      # 3.5 GiB of packed bases / 12-byte CIGAR budget per batch
+    batches = []
+    for c, s, e in zip(cids, starts, ends):
+        for s2 in range(int(s), int(e), max_batch):               # a contig's reads may be split: batches stay coordinate sorted
+            batches.append((int(c), s2, min(int(e), s2 + max_batch)))
     arrays["bam_index"] = bam_index
     return arrays, batches
 
 
 def device_batch(capi, arrays, contig, s, e, with_seq):
-    """capi.Batch whose pointers are DEVICE addresses of the slice [s, e) (for
-    xck_push_batch_device).  cig_off / seq_off keep absolute offsets into the whole arrays."""
+    """capi.Batch whose pointers are DEVICE addresses of the slice [s, e) (for xck_push_batch_device)."""
     import ctypes as C
     b = capi.Batch()
     b.contig = contig
@@ -131,16 +136,28 @@ def device_batch(capi, arrays, contig, s, e, with_seq):
 
     def ptr(t, off, ctype):
         return C.cast(t.data_ptr() + off * t.element_size(), C.POINTER(ctype))
+
+    def rel(name):                                           # u32 offsets relative to the slice (cached: the tensors must outlive the batch)
+        key = (name, s, e)
+        if key not in arrays["_rel"]:
+            o = arrays[name][s:e + 1]
+            base = int(o[0].item())
+            if int(o[-1].item()) - base >= (1 << 32):
+                raise ValueError("batch [%d, %d) exceeds the 4 GiB u32 offset range of xck_batch.%s" % (s, e, name))
+            arrays["_rel"][key] = ((o - base).to(torch.int32).contiguous(), base)      # values < 2^32: same bits as uint32
+        return arrays["_rel"][key]
     b.pos = ptr(arrays["pos"], s, C.c_int32)
     b.flag = ptr(arrays["flag"], s, C.c_uint16)
     b.mapq = ptr(arrays["mapq"], s, C.c_uint8)
     b.cell = ptr(arrays["cell"], s, C.c_int32)
     b.umi = ptr(arrays["umi"], s, C.c_uint64)
-    b.cig_off = ptr(arrays["cig_off"], s, C.c_uint32)
-    b.cigar = ptr(arrays["cigar"], 0, C.c_uint32)
+    co, cbase = rel("cig_off")
+    b.cig_off = ptr(co, 0, C.c_uint32)
+    b.cigar = ptr(arrays["cigar"], cbase, C.c_uint32)
     if with_seq:
-        b.seq_off = ptr(arrays["seq_off"], s, C.c_uint32)
-        b.seq = ptr(arrays["seq"], 0, C.c_uint8)
+        so, sbase = rel("seq_off")
+        b.seq_off = ptr(so, 0, C.c_uint32)
+        b.seq = ptr(arrays["seq"], sbase, C.c_uint8)
     return b
 
 
@@ -151,11 +168,11 @@ def host_batch_dict(arrays, contig, s, e, with_seq):
         d[k] = arrays[k][s:e].cpu().numpy()
     d["flag"] = arrays["flag"][s:e].cpu().numpy().view(np.uint16)
     d["umi"] = arrays["umi"][s:e].cpu().numpy().view(np.uint64)
-    co = arrays["cig_off"][s:e + 1].cpu().numpy().view(np.uint32).astype(np.int64)
+    co = arrays["cig_off"][s:e + 1].cpu().numpy().astype(np.int64)
     d["cigar"] = arrays["cigar"][int(co[0]):int(co[-1])].cpu().numpy().view(np.uint32)
     d["cig_off"] = (co - co[0]).astype(np.uint32)
     if with_seq:
-        so = arrays["seq_off"][s:e + 1].cpu().numpy().view(np.uint32).astype(np.int64)   # offsets are uint32 bit patterns
+        so = arrays["seq_off"][s:e + 1].cpu().numpy().astype(np.int64)
         d["seq"] = arrays["seq"][int(so[0]):int(so[-1])].cpu().numpy()
         d["seq_off"] = (so - so[0]).astype(np.uint32)
     return d
