@@ -54,12 +54,20 @@ class Engine(object):
         cidx = {n: i for i, n in enumerate(self.contig_names)}
         regions = list(regions)
         snps = list(snps)
+        # column-wise fills (a per-row structured assignment costs ~1.5 us: 1.5 s for 1 M SNPs)
         self._reg = np.zeros(len(regions), dtype=capi.REGION_DTYPE)
-        for i, r in enumerate(regions):
-            self._reg[i] = (cidx[r[0]], r[1], r[2])
+        if regions:
+            self._reg["contig"] = [cidx[r[0]] for r in regions]
+            self._reg["start"] = [r[1] for r in regions]
+            self._reg["end"] = [r[2] for r in regions]
         self._snp = np.zeros(len(snps), dtype=capi.SNP_DTYPE)
-        for i, s in enumerate(snps):
-            self._snp[i] = (cidx[s[0]], s[1], ord(s[2]), ord(s[3]), s[4], s[5])
+        if snps:
+            self._snp["contig"] = [cidx[s[0]] for s in snps]
+            self._snp["pos"] = [s[1] for s in snps]
+            self._snp["ref"] = [ord(s[2]) for s in snps]
+            self._snp["alt"] = [ord(s[3]) for s in snps]
+            self._snp["ref_hap"] = [s[4] for s in snps]
+            self._snp["alt_hap"] = [s[5] for s in snps]
         cfg = capi.Config()
         cfg.struct_size = C.sizeof(capi.Config)
         cfg.mode = mode

@@ -116,6 +116,9 @@ def load_region_from_txt(fn, sep="\t", verbose=False):
     return out
 
 
+_BASES = frozenset("ACGTN")
+
+
 def _snp_from_fields(chrom, pos, ref, alt, a1, a2):
     ref, alt = ref.upper(), alt.upper()
     if len(ref) != 1 or ref not in "ACGTN":
@@ -141,6 +144,11 @@ def load_snp_from_tsv(fn, verbose=False):
             if len(parts) < 6:
                 if verbose:
                     sys.stderr.write("[W::%s] too few columns of line %d.\n" % (func, nl))
+                continue
+            # inlined common case of _snp_from_fields (a million-SNP panel is a million calls)
+            ref, alt, a1, a2 = parts[2], parts[3], parts[4], parts[5]
+            if ref in _BASES and alt in _BASES and ((a1 == "0" and a2 == "1") or (a1 == "1" and a2 == "0")):
+                snps.append((format_chrom(parts[0]), int(parts[1]), ref, alt, int(a1), int(a2)))
                 continue
             s = _snp_from_fields(parts[0], parts[1], parts[2], parts[3], parts[4], parts[5])
             if isinstance(s, str):
