@@ -184,7 +184,7 @@ def test_device_resident_batches_more_than_one_fused_launch():
         eng.close()
 
 
-def _dense_pileup_case(seed, n_reads, n_cells, n_umis, snp_step=37, span=120000, max_batch=5000):
+def _dense_pileup_case(seed, n_reads, n_cells, n_umis, snp_step=37, span=120000, max_batch=5000, gap_max=25000):
     """Hand-rolled reads over ONE region with a SNP every `snp_step` bp: long N gaps (hundreds of SNPs per gap: many
     32-SNP gap records), D gaps, insertions / clips, reads without sequence, unmapped-flag reads with a CIGAR, and few
     (cell, UMI) pairs, so that 'the first read of a (SNP, cell, UMI) wins - even without a base' decides most keys."""
@@ -201,7 +201,7 @@ def _dense_pileup_case(seed, n_reads, n_cells, n_umis, snp_step=37, span=120000,
         if kind < 3:
             cig = [(M, 91)]
         elif kind < 6:
-            a = int(rng.integers(10, 80)); cig = [(M, a), (N, int(rng.integers(50, 25000))), (M, 91 - a)]
+            a = int(rng.integers(10, 80)); cig = [(M, a), (N, int(rng.integers(50, gap_max))), (M, 91 - a)]
         elif kind == 6:
             a = int(rng.integers(10, 60)); cig = [(M, a), (D, int(rng.integers(1, 300))), (M, 91 - a)]
         elif kind == 7:
@@ -209,7 +209,7 @@ def _dense_pileup_case(seed, n_reads, n_cells, n_umis, snp_step=37, span=120000,
         elif kind == 8:
             a = int(rng.integers(5, 40)); cig = [(M, a), (N, 2000), (M, 20), (N, 1500), (M, 71 - a)]
         else:
-            cig = [(M, 40), (N, 9000), (M, 51)]
+            cig = [(M, 40), (N, min(9000, gap_max)), (M, 51)]
         qlen = sum(l for op, l in cig if op in (M, I, S))
         noseq = rng.random() < 0.04
         flag = 0
@@ -257,4 +257,16 @@ def test_pileup_gap_records_many_cells():
     regions, snps, names, batches = _dense_pileup_case(seed=9, n_reads=60000, n_cells=500, n_umis=3000, snp_step=101, max_batch=20000)
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 500, batches, min_len=10)
     assert len(exp["dp"][0]) > 100
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+
+
+def test_pileup_overflow_replay_both_streams(monkeypatch):
+    """A SNP every 3 bp: ~30 hits with a base and tens of gap records per read overrun the first capacity guess
+    (1.25 keys per read) of BOTH pileup streams: overflow flag, growth of all four buffers, cursor rewind, replay."""
+    monkeypatch.setenv("XCK_HIT_CAP0", "1024"); monkeypatch.setenv("XCK_HIT_SLACK", "0")    # read by the library at xck_create / first use
+    regions, snps, names, batches = _dense_pileup_case(seed=21, n_reads=200000, n_cells=50, n_umis=5000, snp_step=3,
+                                                       span=60000, max_batch=200000, gap_max=900)
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 50, batches, min_len=10)
+    assert st["n_hits_unique"] > 2 * 16 * (200000 * 5 // 4 // 16)          # more than the first guess can hold
+    assert st["n_join_launches"] > len(batches)                          # at least one launch was replayed
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])

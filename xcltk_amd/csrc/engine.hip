@@ -1539,6 +1539,8 @@ static int res_reserve(EngineImpl* im, int m, size_t nnz) {
     return 0;
 }
 
+// per-shard head room added to every capacity guess (XCK_HIT_SLACK: test knob that makes the overflow / replay path easy to reach)
+static inline size_t hit_slack() { const char* e = getenv("XCK_HIT_SLACK"); return e ? (size_t)std::max(0ll, atoll(e)) : 65536; }
 static inline bool split_mode(const EngineImpl* im) { return XCK_BAF_SPLIT && !XCK_BAF_MAP && im->mode == XCK_MODE_BAF && im->key_bits == 64; }
 
 static int ensure_hits(EngineImpl* im, size_t need) {           // need = elements per shard
@@ -1657,7 +1659,7 @@ static int launch_queue(EngineImpl* im, int slot_idx) {
       for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, std::max(im->cur[sh], im->ncur[sh]));
       // first guess: 1.25 keys per queued read (after the LDS de-duplication a 10x run leaves ~0.8); a launch that needs
       // more sets the overflow flag and is replayed into grown buffers, and the capacity is kept for the next pass
-      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / 4 / NSHARD + 65536); if (rc) return rc; }
+      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / 4 / NSHARD + hit_slack()); if (rc) return rc; }
     im->inflight.swap(im->queue); im->queue.clear();
     im->inflight_reads = im->queued_reads; im->queued_reads = 0;
     im->inflight_slot = slot_idx;
@@ -2104,7 +2106,7 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     HIP_TRY(hipHostMalloc((void**)&im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
     memset(im->h_ctl, 0, CTL_WORDS * sizeof(unsigned long long));
     HIP_TRY(hipHostGetDevicePointer((void**)&im->d_hctl, im->h_ctl, 0));
-    rc = ensure_hits(im, (size_t)1 << 20); if (rc) return rc;
+    rc = ensure_hits(im, getenv("XCK_HIT_CAP0") ? (size_t)std::max(64ll, atoll(getenv("XCK_HIT_CAP0"))) : (size_t)1 << 20); if (rc) return rc;   // (test knob)
     return 0;
 }
 
