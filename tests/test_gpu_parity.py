@@ -270,3 +270,41 @@ def test_pileup_overflow_replay_both_streams(monkeypatch):
     assert st["n_hits_unique"] > 2 * 16 * (200000 * 5 // 4 // 16)          # more than the first guess can hold
     assert st["n_join_launches"] > len(batches)                          # at least one launch was replayed
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+
+
+def test_degenerate_tables_and_lifecycle(small):
+    """Empty region / SNP tables, finish() without any push, reset() and reuse of a handle, regions that pysam's fetch
+    rejects (start < 1, start - 1 > end), SNPs outside every region, a contig without targets."""
+    regions, snps, names, batches = small
+    # no reads at all
+    for mode, tabs in ((capi.XCK_MODE_BASEFC, ()), (capi.XCK_MODE_BAF, snps)):
+        from xcltk_amd.engine import Engine
+        eng = Engine(mode, names, regions, 200, snps=tabs)
+        try:
+            out = eng.finish()
+            assert all(len(v[0]) == 0 for v in out.values())
+            eng.reset()
+            for b, _ in batches[:2]:
+                eng.push(b)
+            first = {k: [a.copy() for a in v] for k, v in eng.finish().items()}
+            eng.reset()                                       # same handle, same input again: identical result
+            for b, _ in batches[:2]:
+                eng.push(b)
+            again = eng.finish()
+            for k in first:
+                assert all(np.array_equal(x, y) for x, y in zip(first[k], again[k]))
+        finally:
+            eng.close()
+    # odd tables: empty SNP list; regions outside fetch's domain; SNPs on a contig / at positions no region covers
+    odd_regions = [("1", 0, 5000, "starts_at_0"), ("1", 9000, 100, "inverted"), ("2", 1, 10, "tiny")] + list(regions[:50])
+    odd_snps = [("2", 5, "A", "C", 0, 1), ("1", 248000000, "G", "T", 1, 0)] + list(snps[:2000])
+    odd_snps.sort(key=lambda s: (names.index(s[0]), s[1]))
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, odd_regions, [], 200, batches)
+    util.assert_coo_equal(got, exp, ["count"])
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, odd_regions, odd_snps, 200, batches)
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, odd_regions, [], 200, batches)
+    assert all(len(got[k][0]) == 0 for k in ("ad", "dp", "oth"))
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, [], [], 200, batches)
+    assert len(got["count"][0]) == 0
