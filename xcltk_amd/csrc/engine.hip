@@ -129,7 +129,7 @@ static_assert(sizeof(JoinArgs<unsigned __int128>) <= 4000, "kernel arguments mus
 // blockIdx % NSHARD; every shard owns its own cursor word (128 B apart -> different channels) and
 // its own slice [shard*cap, (shard+1)*cap) of the hit buffer; finish() packs the slices.
 constexpr int NSHARD = 16;
-constexpr int CTL_OVERFLOW = 1, CTL_SCRATCH = 3, CTL_SHARD0 = 16, CTL_STRIDE = 16;
+constexpr int CTL_OVERFLOW = 1, CTL_GIANT = 2, CTL_SCRATCH = 3, CTL_SHARD0 = 16, CTL_STRIDE = 16;
 constexpr int XSHARD = 32;                 // k_expand: sharded totals / cursors (one shared word serialises at ~90 atomics/us)
 constexpr int CTL_X0 = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
 constexpr int CTL_WORDS = CTL_X0 + XSHARD * CTL_STRIDE;
@@ -1030,6 +1030,114 @@ __global__ __launch_bounds__(FD_BLOCK) void k_fold_emit(const K* __restrict__ k,
     }
 }
 
+// Same fold for keys that are sorted by (row, cell) ONLY (the UMI bits were left out of the radix sort: 4 passes instead
+// of 7).  Inside a run the UMIs are in arbitrary order, so "distinct" is decided by an LDS hash set: the tile first
+// inserts the part of its leading run that lies in earlier tiles (its lead-in, at most FU_LEAD keys), then its own keys -
+// a key is counted by the one thread whose compare-and-swap claims the slot.  A key therefore counts in the tile that
+// holds its first occurrence and nowhere else.  A run with a longer lead-in raises *giant and the host redoes the fold on
+// fully sorted keys.  64-bit keys only.
+constexpr int FU_LEAD = 4096, FU_SLOTS = 8192;                           // <= 2048 + 4096 keys in 8192 slots (64 KB, dynamic LDS)
+static_assert(FU_LEAD == 16 * FD_BLOCK && FD_TILE == 8 * FD_BLOCK, "lead-in search / sweep layout");
+__global__ __launch_bounds__(FD_BLOCK) void k_fold_emit_unsorted(const unsigned long long* __restrict__ k, long long n, KeyLayout<unsigned long long> kl,
+                                                                 const unsigned long long* __restrict__ off,
+                                                                 int32_t* __restrict__ row, int32_t* __restrict__ col, int32_t* __restrict__ val,
+                                                                 unsigned long long* __restrict__ giant) {
+    typedef unsigned long long K;
+    extern __shared__ K set[];                                            // FU_SLOTS slots (a tile with a short lead-in uses half)
+    __shared__ uint16_t s_hx[FD_TILE + 1], s_he[FD_TILE];                 // per head: distinct keys before it / its element
+    __shared__ uint32_t s_wh[FD_BLOCK / 64], s_wd[FD_BLOCK / 64];
+    __shared__ long long s_lead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * FD_TILE;
+    const int n_loc = (int)min((long long)FD_TILE, n - base);
+    // ---- lead-in of the first run: keys of earlier tiles with the (row, cell) of the tile's first key (a suffix of
+    //      what precedes the tile).  256 coarse probes 16 keys apart, then 16 fine ones: two L2 round trips.
+    const K rc0 = kl.rc(k[base]);
+    const long long w0 = max(0ll, base - FU_LEAD);
+    long long lead0 = base;
+    if (base > 0 && kl.rc(k[base - 1]) == rc0) {                          // block-uniform
+        if (tid == 0) s_lead = base - 1;
+        __syncthreads();
+        const long long g = base - 1 - 16ll * tid;
+        if (g >= w0 && kl.rc(k[g]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g);
+        __syncthreads();
+        const long long c = s_lead;                                       // smallest coarse match: the run starts in (c - 16, c]
+        __syncthreads();
+        if (tid < 16) { const long long g2 = c - tid; if (g2 >= w0 && kl.rc(k[g2]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g2); }
+        __syncthreads();
+        lead0 = s_lead;
+        if (tid == 0 && lead0 == w0 && w0 > 0 && kl.rc(k[w0 - 1]) == rc0) *giant = 1ull;   // the run starts before the window
+    }
+    const int slots = ((int)(base - lead0) + n_loc <= 3072) ? FU_SLOTS / 2 : FU_SLOTS;      // block-uniform; load factor <= 0.75
+    const uint32_t smask = (uint32_t)slots - 1;
+    for (int t = tid; t < slots; t += FD_BLOCK) set[t] = ~0ull;
+    __syncthreads();
+    auto probe_on = [&](K key, uint32_t slot) -> bool {                  // continue after a first probe that hit another key
+        for (;;) {
+            slot = (slot + 1) & smask;
+            const K prev = atomicCAS(&set[slot], ~0ull, key);
+            if (prev == ~0ull) return true;
+            if (prev == key) return false;
+        }
+    };
+    for (long long g = lead0 + tid; g < base; g += FD_BLOCK) {
+        const K key = k[g]; const uint32_t sl = set_slot<FU_SLOTS>(key) & smask;
+        const K prev = atomicCAS(&set[sl], ~0ull, key);
+        if (prev != ~0ull && prev != key) (void)probe_on(key, sl);
+    }
+    __syncthreads();
+    // ---- own keys: wave w owns elements [512 w, 512 w + 512) in 8 coalesced sweeps of 64; element order = (wave, sweep, lane)
+    K me[FD_ITEMS], got[FD_ITEMS]; uint32_t sl[FD_ITEMS]; bool hd[FD_ITEMS];
+    const int e_w = wave * (FD_TILE / (FD_BLOCK / 64));
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        const int e = e_w + q * 64 + lane;
+        me[q] = ~0ull; hd[q] = false; sl[q] = 0; got[q] = 0;
+        if (e < n_loc) {
+            me[q] = k[base + e];
+            hd[q] = base + e == 0 || kl.rc(me[q]) != kl.rc(k[base + e - 1]);
+            sl[q] = set_slot<FU_SLOTS>(me[q]) & smask;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++)                                    // eight independent LDS atomics in flight per lane
+        if (e_w + q * 64 + lane < n_loc) got[q] = atomicCAS(&set[sl[q]], ~0ull, me[q]);
+    unsigned long long hb[FD_ITEMS], db[FD_ITEMS];
+    uint32_t th = 0, td = 0;
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        bool dist = false;
+        if (e_w + q * 64 + lane < n_loc) dist = got[q] == ~0ull ? true : (got[q] == me[q] ? false : probe_on(me[q], sl[q]));   // first occurrence of this (row, cell, UMI)
+        hb[q] = __ballot(hd[q]); db[q] = __ballot(dist);
+        th += (uint32_t)__popcll(hb[q]); td += (uint32_t)__popcll(db[q]);
+    }
+    if (lane == 0) { s_wh[wave] = th; s_wd[wave] = td; }
+    __syncthreads();
+    uint32_t r = 0, xd = 0, n_heads = 0, n_dist = 0;
+#pragma unroll
+    for (int w = 0; w < FD_BLOCK / 64; w++) { if (w < wave) { r += s_wh[w]; xd += s_wd[w]; } n_heads += s_wh[w]; n_dist += s_wd[w]; }
+    const unsigned long long lt = (1ull << lane) - 1;
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        if (hd[q]) { const uint32_t rr = r + (uint32_t)__popcll(hb[q] & lt); s_hx[rr] = (uint16_t)(xd + (uint32_t)__popcll(db[q] & lt)); s_he[rr] = (uint16_t)(e_w + q * 64 + lane); }
+        r += (uint32_t)__popcll(hb[q]); xd += (uint32_t)__popcll(db[q]);
+    }
+    if (tid == 0) s_hx[n_heads] = (uint16_t)n_dist;
+    __syncthreads();
+    const unsigned long long out = off[blockIdx.x];
+    for (uint32_t i = tid; i < n_heads; i += FD_BLOCK) {
+        const K key = k[base + s_he[i]];
+        const int32_t cnt = (int32_t)s_hx[i + 1] - (int32_t)s_hx[i];
+        const unsigned long long d = out + i;
+        row[d] = (int32_t)kl.row(key); col[d] = (int32_t)kl.cell(key);
+        if (i + 1 == n_heads) atomicAdd(&val[d], cnt); else val[d] = cnt;  // the last run may continue in later tiles
+    }
+    if (tid == 0) {
+        const uint32_t lead = n_heads ? s_hx[0] : n_dist;
+        if (lead && out > 0) atomicAdd(&val[out - 1], (int32_t)lead);
+    }
+}
+
 __device__ __forceinline__ int nib_bucket(int nib) { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4; }
 
 // BAF step 1: per (snp, cell, umi) run keep the value with the smallest ordinal (first read in
@@ -1751,9 +1859,9 @@ static size_t sort_tmp_bytes(size_t n, int top) {
     return tb + 256;
 }
 template <class K, class V>
-static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout, V* vin, V* vout, size_t n, int top) {
+static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout, V* vin, V* vout, size_t n, int top, int begin = 0) {
     hipError_t er;
-    if constexpr (std::is_same<V, rocprim::empty_type>::value) er = rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, 0u, (unsigned)top, im->s_comp);
+    if constexpr (std::is_same<V, rocprim::empty_type>::value) er = rocprim::radix_sort_keys(tmp, tmp_bytes, kin, kout, n, (unsigned)begin, (unsigned)top, im->s_comp);
     else er = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, (unsigned)top, im->s_comp);
     HIP_TRY(er);
     return 0;
@@ -1829,8 +1937,9 @@ static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total) {
 }
 
 // basefc: sorted keys -> COO (row, col, count of distinct keys) without a dense intermediate
+constexpr int FOLD_GIANT = 1;              // fold_coo(): a (row, cell) run too long for the hash fold - redo on fully sorted keys
 template <class K>
-static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayout<K> kl, int m) {
+static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayout<K> kl, int m, bool umi_sorted = true) {
     size_t nb = (n + FD_TILE - 1) / FD_TILE;
     uint32_t* d_blk = ws.get<uint32_t>(nb); unsigned long long* d_off = ws.get<unsigned long long>(nb);
     if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (fold)"; return XCK_E_NOMEM; }
@@ -1846,6 +1955,23 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
     int32_t* d_o = ws.get<int32_t>(total * 3);
     if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
     HIP_TRY(hipMemsetAsync(d_o + 2 * total, 0, total * sizeof(int32_t), im->s_comp));       // k_fold_emit accumulates run pieces into val[]
+    if constexpr (sizeof(K) == 8) {
+        if (!umi_sorted) {
+            HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_GIANT, 0, sizeof(unsigned long long), im->s_comp));
+            KeyLayout<unsigned long long> kl8; kl8.ubits = kl.ubits; kl8.cbits = kl.cbits;
+            static bool lds_set = false;
+            if (!lds_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_fold_emit_unsorted, hipFuncAttributeMaxDynamicSharedMemorySize, FU_SLOTS * 8)); lds_set = true; }
+            hipLaunchKernelGGL(k_fold_emit_unsorted, dim3(nb), dim3(FD_BLOCK), FU_SLOTS * 8, im->s_comp, (const unsigned long long*)keys, (long long)n, kl8, d_off,
+                               d_o, d_o + total, d_o + 2 * total, im->d_ctl + CTL_GIANT);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_GIANT), im->d_hctl + CTL_GIANT, 1);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(im->s_comp));
+            if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] hash fold: n=%zu nnz=%zu ubits=%d cbits=%d giant=%llu\n", n, total, kl.ubits, kl.cbits, im->h_ctl[CTL_GIANT]);
+            if (im->h_ctl[CTL_GIANT]) return FOLD_GIANT;
+            return copy_out(im, m, d_o, total);
+        }
+    }
     hipLaunchKernelGGL((k_fold_emit<K>), dim3(nb), dim3(FD_BLOCK), 0, im->s_comp, keys, (long long)n, kl, d_off, d_o, d_o + total, d_o + 2 * total);
     HIP_TRY(hipGetLastError());
     return copy_out(im, m, d_o, total);
@@ -1902,7 +2028,7 @@ static int finish_t(EngineImpl* im) {
     K* keys = (K*)im->d_keys;
     if (im->mode == XCK_MODE_BASEFC) {
         const size_t tmpb = sort_tmp_bytes<K, rocprim::empty_type>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + nb * 12 + n * 12 + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + 2 * (nb * 12 + n * 12) + (1 << 20)))) return rc;
         K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb);
         if ((rc = tm.start())) return rc;
         int used = im->ubits;                                                       // UMI bits actually in use
@@ -1916,8 +2042,19 @@ static int finish_t(EngineImpl* im) {
         } else
         if ((rc = pack_shards(im, alt, (uint64_t*)nullptr))) return rc;             // shard slices -> contiguous
         const int top_fc = kl.ubits + im->cbits + im->rbits;
-        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top_fc))) return rc;
-        if ((rc = fold_coo<K>(im, im->ws1, keys, n, kl, 0))) return rc;
+        // 64-bit keys: the radix sort only orders (row, cell) - 4 passes instead of 7 - and the fold tells the UMIs of a run
+        // apart with an LDS hash set; a run too long for that (FOLD_GIANT) is redone on fully sorted keys
+        static const bool full_sort = getenv("XCK_FULL_SORT") && atoi(getenv("XCK_FULL_SORT"));
+        // (rocPRIM 4.2 returns garbage for begin_bit > 0 with end_bit = 64 - tools/scratch/sortpart.hip - so keys that could not be
+        // squeezed below 63 bits take the classic path)
+        const bool partial = sizeof(K) == 8 && !full_sort && top_fc <= 62;
+        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top_fc, partial ? kl.ubits : 0))) return rc;
+        rc = fold_coo<K>(im, im->ws1, keys, n, kl, 0, !partial);
+        if (rc == FOLD_GIANT) {
+            if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, keys, alt, nullptr, nullptr, n, top_fc, 0))) return rc;
+            rc = fold_coo<K>(im, im->ws1, alt, n, kl, 0, true);
+        }
+        if (rc) return rc;
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
