@@ -310,20 +310,21 @@ def test_degenerate_tables_and_lifecycle(small):
     assert len(got["count"][0]) == 0
 
 
-def test_basefc_giant_runs_fall_back_to_full_sort():
-    """One (region, cell) pair with tens of thousands of distinct UMIs: its run is far longer than the hash fold's
-    lead-in window, so finish() must notice (FOLD_GIANT) and redo the fold on fully sorted keys; a second region / many
-    cells keep ordinary runs around it.  Duplicated UMIs make sure 'distinct' is really what is counted."""
+@pytest.mark.parametrize("n,hot,n_umis,label", [(150000, 0.7, 60000, "giant"), (20000, 0.2, 3000, "lead-in"), (60000, 0.1, 2500, "lead-in-dups")])
+def test_basefc_long_runs_hash_fold_and_fallback(n, hot, n_umis, label):
+    """Long (region, cell) runs for the hash fold (keys sorted by (row, cell) only): 'giant' = one pair with tens of
+    thousands of distinct UMIs, far beyond the fold's lead-in window - finish() must notice (FOLD_GIANT) and redo the fold
+    on fully sorted keys; 'lead-in*' = runs of a few thousand keys that cross tile borders inside the window, with the
+    same UMI on both sides of a border.  A second region / other cells keep ordinary runs around them."""
     rng = np.random.default_rng(3)
     names = ["1"]
     regions = [("1", 1, 200000, "hot"), ("1", 50000, 60000, "inner")]
-    n = 150000
     pos = np.sort(rng.integers(0, 190000, n)).astype(np.int32)
-    cell = np.where(rng.random(n) < 0.7, 0, rng.integers(0, 40, n)).astype(np.int32)
-    umi = ((1 << 24) | rng.integers(0, 60000, n)).astype(np.uint64)                 # ~2.5 reads per UMI in the hot cell
+    cell = np.where(rng.random(n) < hot, 0, rng.integers(0, 40, n)).astype(np.int32)
+    umi = ((1 << 24) | rng.integers(0, n_umis, n)).astype(np.uint64)
     d = dict(contig=0, ordinal_base=0, pos=pos, flag=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8), cell=cell, umi=umi,
              cig_off=np.arange(n + 1, dtype=np.uint32), cigar=np.full(n, (91 << 4) | 0, np.uint32))
     batches = [util.batch_from_dict(d)]
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 40, batches)
-    assert int(exp["count"][2].max()) > 30000
+    assert int(exp["count"][2].max()) > (30000 if label == "giant" else 1500)
     util.assert_coo_equal(got, exp, ["count"])
