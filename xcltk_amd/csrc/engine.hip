@@ -1037,40 +1037,54 @@ __global__ __launch_bounds__(FD_BLOCK) void k_fold_emit(const K* __restrict__ k,
 // holds its first occurrence and nowhere else.  A run with a longer lead-in raises *giant and the host redoes the fold on
 // fully sorted keys.  64-bit keys only.
 constexpr int FU_LEAD = 4096, FU_SLOTS = 8192;                           // <= 2048 + 4096 keys in 8192 slots (64 KB, dynamic LDS)
-static_assert(FU_LEAD == 16 * FD_BLOCK && FD_TILE == 8 * FD_BLOCK, "lead-in search / sweep layout");
-__global__ __launch_bounds__(FD_BLOCK) void k_fold_emit_unsorted(const unsigned long long* __restrict__ k, long long n, KeyLayout<unsigned long long> kl,
+// 1024 threads per tile: the 72 KB of LDS allow two blocks per CU, and with 256-thread blocks the two waves per SIMD could not
+// hide the chains of LDS atomics (4.3 ms for 380 M keys; 3.0 ms with 512 threads, 2.8 ms with 1024)
+constexpr int FU_BLOCK = 1024, FU_ITEMS = FD_TILE / FU_BLOCK, FU_STRIDE = FU_LEAD / FU_BLOCK;
+static_assert(FU_ITEMS * FU_BLOCK == FD_TILE && FU_STRIDE * FU_BLOCK == FU_LEAD && FU_STRIDE <= 64, "lead-in search / sweep layout");
+__global__ __launch_bounds__(FU_BLOCK) void k_fold_emit_unsorted(const unsigned long long* __restrict__ k, long long n, KeyLayout<unsigned long long> kl,
                                                                  const unsigned long long* __restrict__ off,
                                                                  int32_t* __restrict__ row, int32_t* __restrict__ col, int32_t* __restrict__ val,
                                                                  unsigned long long* __restrict__ giant) {
     typedef unsigned long long K;
     extern __shared__ K set[];                                            // FU_SLOTS slots (a tile with a short lead-in uses half)
     __shared__ uint16_t s_hx[FD_TILE + 1], s_he[FD_TILE];                 // per head: distinct keys before it / its element
-    __shared__ uint32_t s_wh[FD_BLOCK / 64], s_wd[FD_BLOCK / 64];
+    __shared__ uint32_t s_wh[FU_BLOCK / 64], s_wd[FU_BLOCK / 64];
     __shared__ long long s_lead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long base = (long long)blockIdx.x * FD_TILE;
     const int n_loc = (int)min((long long)FD_TILE, n - base);
+    // the tile's own keys (and each key's predecessor) are requested first: the loads fly during the lead-in search and
+    // the table set-up.  Wave w owns FD_TILE / 8 consecutive elements in FU_ITEMS coalesced sweeps of 64; element order = (wave, sweep, lane).
+    K me[FU_ITEMS], pv[FU_ITEMS];
+    const int e_w = wave * (FD_TILE / (FU_BLOCK / 64));
+#pragma unroll
+    for (int q = 0; q < FU_ITEMS; q++) {
+        const int e = e_w + q * 64 + lane;
+        me[q] = ~0ull; pv[q] = ~0ull;
+        if (e < n_loc) { me[q] = k[base + e]; if (base + e > 0) pv[q] = k[base + e - 1]; }
+    }
+    const unsigned long long out = off[blockIdx.x];
     // ---- lead-in of the first run: keys of earlier tiles with the (row, cell) of the tile's first key (a suffix of
-    //      what precedes the tile).  256 coarse probes 16 keys apart, then 16 fine ones: two L2 round trips.
+    //      what precedes the tile).  One coarse probe per thread, FU_STRIDE keys apart, then FU_STRIDE fine ones: two L2 round trips.
     const K rc0 = kl.rc(k[base]);
     const long long w0 = max(0ll, base - FU_LEAD);
     long long lead0 = base;
     if (base > 0 && kl.rc(k[base - 1]) == rc0) {                          // block-uniform
         if (tid == 0) s_lead = base - 1;
         __syncthreads();
-        const long long g = base - 1 - 16ll * tid;
+        const long long g = base - 1 - (long long)FU_STRIDE * tid;
         if (g >= w0 && kl.rc(k[g]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g);
         __syncthreads();
-        const long long c = s_lead;                                       // smallest coarse match: the run starts in (c - 16, c]
+        const long long c = s_lead;                                       // smallest coarse match: the run starts in (c - FU_STRIDE, c]
         __syncthreads();
-        if (tid < 16) { const long long g2 = c - tid; if (g2 >= w0 && kl.rc(k[g2]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g2); }
+        if (tid < FU_STRIDE) { const long long g2 = c - tid; if (g2 >= w0 && kl.rc(k[g2]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g2); }
         __syncthreads();
         lead0 = s_lead;
         if (tid == 0 && lead0 == w0 && w0 > 0 && kl.rc(k[w0 - 1]) == rc0) *giant = 1ull;   // the run starts before the window
     }
     const int slots = ((int)(base - lead0) + n_loc <= 3072) ? FU_SLOTS / 2 : FU_SLOTS;      // block-uniform; load factor <= 0.75
     const uint32_t smask = (uint32_t)slots - 1;
-    for (int t = tid; t < slots; t += FD_BLOCK) set[t] = ~0ull;
+    for (int t = tid; t < slots; t += FU_BLOCK) set[t] = ~0ull;
     __syncthreads();
     auto probe_on = [&](K key, uint32_t slot) -> bool {                  // continue after a first probe that hit another key
         for (;;) {
@@ -1080,32 +1094,30 @@ __global__ __launch_bounds__(FD_BLOCK) void k_fold_emit_unsorted(const unsigned 
             if (prev == key) return false;
         }
     };
-    for (long long g = lead0 + tid; g < base; g += FD_BLOCK) {
+    for (long long g = lead0 + tid; g < base; g += FU_BLOCK) {
         const K key = k[g]; const uint32_t sl = set_slot<FU_SLOTS>(key) & smask;
         const K prev = atomicCAS(&set[sl], ~0ull, key);
         if (prev != ~0ull && prev != key) (void)probe_on(key, sl);
     }
     __syncthreads();
-    // ---- own keys: wave w owns elements [512 w, 512 w + 512) in 8 coalesced sweeps of 64; element order = (wave, sweep, lane)
-    K me[FD_ITEMS], got[FD_ITEMS]; uint32_t sl[FD_ITEMS]; bool hd[FD_ITEMS];
-    const int e_w = wave * (FD_TILE / (FD_BLOCK / 64));
+    // ---- own keys
+    K got[FU_ITEMS]; uint32_t sl[FU_ITEMS]; bool hd[FU_ITEMS];
 #pragma unroll
-    for (int q = 0; q < FD_ITEMS; q++) {
+    for (int q = 0; q < FU_ITEMS; q++) {
         const int e = e_w + q * 64 + lane;
-        me[q] = ~0ull; hd[q] = false; sl[q] = 0; got[q] = 0;
+        hd[q] = false; sl[q] = 0; got[q] = 0;
         if (e < n_loc) {
-            me[q] = k[base + e];
-            hd[q] = base + e == 0 || kl.rc(me[q]) != kl.rc(k[base + e - 1]);
+            hd[q] = base + e == 0 || kl.rc(me[q]) != kl.rc(pv[q]);
             sl[q] = set_slot<FU_SLOTS>(me[q]) & smask;
         }
     }
 #pragma unroll
-    for (int q = 0; q < FD_ITEMS; q++)                                    // eight independent LDS atomics in flight per lane
+    for (int q = 0; q < FU_ITEMS; q++)                                    // independent LDS atomics in flight per lane
         if (e_w + q * 64 + lane < n_loc) got[q] = atomicCAS(&set[sl[q]], ~0ull, me[q]);
-    unsigned long long hb[FD_ITEMS], db[FD_ITEMS];
+    unsigned long long hb[FU_ITEMS], db[FU_ITEMS];
     uint32_t th = 0, td = 0;
 #pragma unroll
-    for (int q = 0; q < FD_ITEMS; q++) {
+    for (int q = 0; q < FU_ITEMS; q++) {
         bool dist = false;
         if (e_w + q * 64 + lane < n_loc) dist = got[q] == ~0ull ? true : (got[q] == me[q] ? false : probe_on(me[q], sl[q]));   // first occurrence of this (row, cell, UMI)
         hb[q] = __ballot(hd[q]); db[q] = __ballot(dist);
@@ -1115,17 +1127,16 @@ __global__ __launch_bounds__(FD_BLOCK) void k_fold_emit_unsorted(const unsigned 
     __syncthreads();
     uint32_t r = 0, xd = 0, n_heads = 0, n_dist = 0;
 #pragma unroll
-    for (int w = 0; w < FD_BLOCK / 64; w++) { if (w < wave) { r += s_wh[w]; xd += s_wd[w]; } n_heads += s_wh[w]; n_dist += s_wd[w]; }
+    for (int w = 0; w < FU_BLOCK / 64; w++) { if (w < wave) { r += s_wh[w]; xd += s_wd[w]; } n_heads += s_wh[w]; n_dist += s_wd[w]; }
     const unsigned long long lt = (1ull << lane) - 1;
 #pragma unroll
-    for (int q = 0; q < FD_ITEMS; q++) {
+    for (int q = 0; q < FU_ITEMS; q++) {
         if (hd[q]) { const uint32_t rr = r + (uint32_t)__popcll(hb[q] & lt); s_hx[rr] = (uint16_t)(xd + (uint32_t)__popcll(db[q] & lt)); s_he[rr] = (uint16_t)(e_w + q * 64 + lane); }
         r += (uint32_t)__popcll(hb[q]); xd += (uint32_t)__popcll(db[q]);
     }
     if (tid == 0) s_hx[n_heads] = (uint16_t)n_dist;
     __syncthreads();
-    const unsigned long long out = off[blockIdx.x];
-    for (uint32_t i = tid; i < n_heads; i += FD_BLOCK) {
+    for (uint32_t i = tid; i < n_heads; i += FU_BLOCK) {
         const K key = k[base + s_he[i]];
         const int32_t cnt = (int32_t)s_hx[i + 1] - (int32_t)s_hx[i];
         const unsigned long long d = out + i;
@@ -1961,7 +1972,7 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
             KeyLayout<unsigned long long> kl8; kl8.ubits = kl.ubits; kl8.cbits = kl.cbits;
             static bool lds_set = false;
             if (!lds_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_fold_emit_unsorted, hipFuncAttributeMaxDynamicSharedMemorySize, FU_SLOTS * 8)); lds_set = true; }
-            hipLaunchKernelGGL(k_fold_emit_unsorted, dim3(nb), dim3(FD_BLOCK), FU_SLOTS * 8, im->s_comp, (const unsigned long long*)keys, (long long)n, kl8, d_off,
+            hipLaunchKernelGGL(k_fold_emit_unsorted, dim3(nb), dim3(FU_BLOCK), FU_SLOTS * 8, im->s_comp, (const unsigned long long*)keys, (long long)n, kl8, d_off,
                                d_o, d_o + total, d_o + 2 * total, im->d_ctl + CTL_GIANT);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_GIANT), im->d_hctl + CTL_GIANT, 1);
