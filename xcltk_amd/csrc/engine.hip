@@ -42,6 +42,9 @@ typedef unsigned __int128 u128;
 #ifndef XCK_PREFETCH_ALL
 #define XCK_PREFETCH_ALL 1   // all TILE_ITEMS reads of a thread are loaded in the prologue (one HBM round trip per tile)
 #endif
+#ifndef XCK_LAZY_BOUNDS
+#define XCK_LAZY_BOUNDS 1
+#endif
 #ifndef XCK_DENSE
 #define XCK_DENSE 0           // region-major evaluation (4 reads in registers): measured equal-to-slower, 100 VGPRs cost a wave of occupancy
 #endif
@@ -153,8 +156,13 @@ __device__ __forceinline__ void frac_bounds(ReadInfo& r, double f) {
     r.m_rej = (int32_t)ceil(p * (1.0 - 0x1p-50));
     r.m_acc = (int32_t)floor(p * (1.0 + 0x1p-50)) + 1;
 }
-__device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r, double f) {
+__device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double f) {
     if (XCK_EXP & 2) return false;
+#if XCK_LAZY_BOUNDS
+    ReadInfo r = r0; frac_bounds(r, f);                               // only (read, region) pairs with a partial overlap get here
+#else
+    const ReadInfo& r = r0;
+#endif
     if (m < r.m_rej) return true;
     if (m >= r.m_acc) return false;
     return (double)m / (double)r.n_al < f;
@@ -315,7 +323,9 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchD
     r.endpos = r.pos + rlen;
     r.n_al = n_al;
     r.ok = n_al >= a.f.min_len;
+#if !XCK_LAZY_BOUNDS
     if (MODE == XCK_MODE_BASEFC && a.f.frac_mode) frac_bounds(r, a.f.min_inc_frac);
+#endif
     return r;
 }
 
