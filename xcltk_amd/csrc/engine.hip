@@ -1251,19 +1251,27 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
 }
 template <class K>
 __global__ void k_tally(const K* __restrict__ k, const uint8_t* __restrict__ al, long long n, KeyLayout<K> kl, uint32_t* __restrict__ tally) {
-    // keys are sorted by SNP: a wave usually sits inside ONE SNP's run, and the five counters of a deep SNP would
-    // take thousands of same-address atomics - count with ballots and let one lane add
+    // keys are sorted by SNP, so the lanes of a wave form a few segments of equal SNP: the first lane of a segment adds the
+    // segment's five bucket counts (ballots), instead of one atomic per key on the counters of a deep SNP
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t code = i < n ? al[i] : 0u;
     const uint32_t row = i < n ? kl.row(k[i]) : 0xffffffffu;
     const int bucket = code ? nib_bucket(int(code) - 1) : -1;
-    const uint32_t row0 = __shfl(row, 0, 64);
-    if (__all(row == row0 || i >= n)) {
-        for (int b = 0; b < 5; b++) {
-            const unsigned long long m = __ballot(bucket == b);
-            if (m && (threadIdx.x & 63) == 0) atomicAdd(&tally[(size_t)row0 * 5 + b], (uint32_t)__popcll(m));
+    const uint32_t row_prev = __shfl_up(row, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || row != row_prev);
+    unsigned long long bm[5];
+#pragma unroll
+    for (int b = 0; b < 5; b++) bm[b] = __ballot(bucket == b);
+    if ((heads >> lane) & 1ull) {                                         // segment = [lane, next head)
+        const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+        const int end = later ? __builtin_ctzll(later) : 64;
+        const unsigned long long seg = (end == 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << lane) - 1);
+        if (row != 0xffffffffu) {
+#pragma unroll
+            for (int b = 0; b < 5; b++) { const int c = __popcll(bm[b] & seg); if (c) atomicAdd(&tally[(size_t)row * 5 + b], (uint32_t)c); }
         }
-    } else if (code) atomicAdd(&tally[(size_t)row * 5 + bucket], 1u);
+    }
 }
 
 struct SnpFilter { int32_t min_count; double min_maf; };
