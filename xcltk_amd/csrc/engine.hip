@@ -36,18 +36,6 @@ typedef unsigned __int128 u128;
 #ifndef XCK_EXP
 #define XCK_EXP 0          // timing experiments only (wrong results): 1 no emit, 2 no fp64 divide, 4 no CIGAR re-walk, 8 no flush, 16 no join, 32 pileup: no SNP work, 64 pileup: count only
 #endif
-#ifndef XCK_HASH_MUL64
-#define XCK_HASH_MUL64 0
-#endif
-#ifndef XCK_PREFETCH_ALL
-#define XCK_PREFETCH_ALL 1   // all TILE_ITEMS reads of a thread are loaded in the prologue (one HBM round trip per tile)
-#endif
-#ifndef XCK_LAZY_BOUNDS
-#define XCK_LAZY_BOUNDS 1
-#endif
-#ifndef XCK_DENSE
-#define XCK_DENSE 0           // region-major evaluation (4 reads in registers): measured equal-to-slower, 100 VGPRs cost a wave of occupancy
-#endif
 constexpr int WS = XCK_WS;             // window shift of the interval index (2^WS bp windows)
 constexpr int JOIN_BLOCK = 256;
 
@@ -110,7 +98,7 @@ struct TileMeta {
     uint32_t c_lo, cg_n;                  // CIGAR words of the tile: [c_lo, c_lo + cg_n) are staged
     int32_t  w0, nw, e0, n_ent;           // basefc: staged windows [w0, w0+nw), their entries [e0, e0+n_ent)
     int32_t  k0, nk;                      // pileup: staged SNPs [k0, k0+nk)
-    int32_t  b, r0, r1, n0;               // batch index, first / one-past-last read of the tile, entries of window w0
+    int32_t  b, r0, r1, pad;              // batch index, first / one-past-last read of the tile
 };
 
 template <class K> struct JoinArgs {
@@ -158,11 +146,7 @@ __device__ __forceinline__ void frac_bounds(ReadInfo& r, double f) {
 }
 __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double f) {
     if (XCK_EXP & 2) return false;
-#if XCK_LAZY_BOUNDS
     ReadInfo r = r0; frac_bounds(r, f);                               // only (read, region) pairs with a partial overlap get here
-#else
-    const ReadInfo& r = r0;
-#endif
     if (m < r.m_rej) return true;
     if (m >= r.m_acc) return false;
     return (double)m / (double)r.n_al < f;
@@ -181,23 +165,8 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double
 #ifndef XCK_STAMPS
 #define XCK_STAMPS 0
 #endif
-#ifndef XCK_UNROLL_PROBE
-#define XCK_UNROLL_PROBE 1
-#endif
-#ifndef XCK_UNROLL_TILE
-#define XCK_UNROLL_TILE 1
-#endif
 #ifndef XCK_TILE_ITEMS
 #define XCK_TILE_ITEMS 4
-#endif
-#ifndef XCK_BAF_FLUSH_EVERY
-#define XCK_BAF_FLUSH_EVERY XCK_TILE_ITEMS   // sweeps between two flushes of the pileup map
-#endif
-#ifndef XCK_BAF_BALANCED
-#define XCK_BAF_BALANCED 1        // pileup: (read, SNP) pairs of a sweep are spread evenly over the block's threads
-#endif
-#ifndef XCK_BAF_SEQ_PREFETCH
-#define XCK_BAF_SEQ_PREFETCH 1   // 1: seq_off is streamed with every read; 0: looked up per (read, SNP) pair (measured slower)
 #endif
 #ifndef XCK_BAF_SPLIT
 #define XCK_BAF_SPLIT 1           // pileup, 64-bit keys: hits without a base go to a second stream that is never sorted
@@ -207,15 +176,6 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double
 #endif
 #ifndef XCK_BAF_BQUEUE_BYTES
 #define XCK_BAF_BQUEUE_BYTES 4096   // split mode: queue of the hits with a base (~1 in 10), flushed at the tile end
-#endif
-#ifndef XCK_BAF_MAP
-#define XCK_BAF_MAP 0             // 1: pileup hits go through the LDS key -> min(value) map instead of the queue
-#endif
-#ifndef XCK_BAF_QUEUE_BYTES
-#define XCK_BAF_QUEUE_BYTES 6144
-#endif
-#ifndef XCK_MAP_SLOTS
-#define XCK_MAP_SLOTS 1024
 #endif
 #ifndef XCK_HS_BYTES
 #define XCK_HS_BYTES 16384
@@ -230,21 +190,22 @@ constexpr int TILE_ITEMS = XCK_TILE_ITEMS;
 constexpr int TILE = JOIN_BLOCK * TILE_ITEMS;
 constexpr int HS_BYTES = XCK_HS_BYTES;   // LDS set / queue storage per block
 constexpr int HS_SLOTS = HS_BYTES / 8;   // slots of the 64-bit key set
-constexpr int MAP_SLOTS = XCK_MAP_SLOTS; // slots of the pileup key -> min(value) map (16 B each)
 constexpr int CG_CAP = XCK_CG_CAP;       // staged CIGAR words
 constexpr int ST_CAP = XCK_ST_CAP;       // staged regions / SNPs
 constexpr int ST_WIN = 64;               // staged index windows
 
 template <class K, int MODE> struct JoinSmem {
-    // 64-bit keys go through an LDS hash table: basefc a SET of keys (duplicate (region, cell, UMI) dropped), pileup a
-    // MAP key -> min(value) ("first read in fetch order wins", baf/fc/mcount.py:118-119: the value's high bits are the
-    // read ordinal).  The PCR / UMI duplicates that sit next to each other in a sorted BAM never reach HBM.
-    // 128-bit keys use a plain queue.
-    static constexpr bool USE_SET = sizeof(K) == 8 && (MODE == XCK_MODE_BASEFC || XCK_BAF_MAP);
+    // basefc, 64-bit keys: accepted keys go through an LDS hash SET (a duplicate (region, cell, UMI) is dropped): the PCR /
+    // UMI duplicates that sit next to each other in a sorted BAM never reach HBM.  Everything else uses plain queues.
+    static constexpr bool USE_SET = sizeof(K) == 8 && MODE == XCK_MODE_BASEFC;
     static constexpr bool HAS_VAL = MODE == XCK_MODE_BAF;
-    static constexpr int  SLOTS = HAS_VAL ? MAP_SLOTS : HS_SLOTS;
-    static constexpr bool SPLIT_ = MODE == XCK_MODE_BAF && sizeof(K) == 8 && XCK_BAF_SPLIT && !XCK_BAF_MAP;
-    static constexpr int  STORE_BYTES = USE_SET ? SLOTS * (HAS_VAL ? 16 : 8) : (HAS_VAL ? (SPLIT_ ? XCK_BAF_BQUEUE_BYTES : XCK_BAF_QUEUE_BYTES) : HS_BYTES);
+    static constexpr int  SLOTS = HS_SLOTS;
+    // pileup split mode (64-bit keys): a hit whose read shows NO base at the SNP (the SNP sits in an N / D gap - the
+    // bulk of the hits of spliced reads) only matters if a read of the same (SNP, cell, UMI) WITH a base comes later in
+    // fetch order (baf/fc/mcount.py:118-119: the earlier read holds the key).  Those hits go to their own queue / HBM
+    // stream, which finish() never sorts: it is only looked up against the (small) sorted stream of hits with a base.
+    static constexpr bool SPLIT = MODE == XCK_MODE_BAF && sizeof(K) == 8 && XCK_BAF_SPLIT;
+    static constexpr int  STORE_BYTES = USE_SET ? SLOTS * 8 : (HAS_VAL ? (SPLIT ? XCK_BAF_BQUEUE_BYTES : 6144) : HS_BYTES);
     static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (HAS_VAL ? 8 : 0));
     alignas(16) unsigned char store[STORE_BYTES];
     uint32_t cig[CG_CAP];
@@ -253,29 +214,22 @@ template <class K, int MODE> struct JoinSmem {
     uint32_t cg_lo, cg_n;                // staged CIGAR range [cg_lo, cg_lo + cg_n)
     int32_t  w0, nw;                     // staged windows [w0, w0 + nw)          (basefc)
     int32_t  k0, nk;                     // staged SNPs    [k0, k0 + nk)          (pileup)
-    uint32_t count;                      // entries currently in the set / queue
-    uint32_t nuniq;                      // regions in the tile's duplicate-free list (dense basefc path)
+    uint32_t count;                      // entries currently in the queue
     uint32_t wuor[2 * (JOIN_BLOCK / 64)];  // per-wave OR of the UMI codes
     uint32_t wcnt[JOIN_BLOCK / 64];
     unsigned long long base;
-    // pileup split mode (64-bit keys): a hit whose read shows NO base at the SNP (the SNP sits in an N / D gap - the
-    // bulk of the hits of spliced reads) only matters if a read of the same (SNP, cell, UMI) WITH a base comes later in
-    // fetch order (baf/fc/mcount.py:118-119: the earlier read holds the key).  Those hits go to their own queue / HBM
-    // stream, which finish() never sorts: it is only looked up against the (small) sorted stream of hits with a base.
-    static constexpr bool SPLIT = MODE == XCK_MODE_BAF && sizeof(K) == 8 && XCK_BAF_SPLIT && !XCK_BAF_MAP;
     static constexpr int  NQCAP = SPLIT ? XCK_BAF_NQUEUE_BYTES / 16 : 1;
     uint64_t nq_key[NQCAP], nq_val[NQCAP];
     uint32_t ncount;
     unsigned long long nbase;
-    // pileup, balanced (read, SNP) pairs: the sweep's reads parked in LDS so that any thread can work on any pair
-    static constexpr int PR = (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) ? JOIN_BLOCK : 1;
+    // pileup: the reads of a wave that have (read, SNP) pairs, parked so that any lane can work on any pair
+    static constexpr int PR = MODE == XCK_MODE_BAF ? JOIN_BLOCK : 1;
     uint64_t pr_umi[PR];
     int32_t  pr_pos[PR], pr_end[PR], pr_cell[PR], pr_klo[PR];
     uint32_t pr_c0[PR], pr_c1[PR], pr_s0[PR], pr_sl[PR], pr_off[PR]; int32_t pr_idx[PR];
     __device__ K* keys() { return reinterpret_cast<K*>(store); }
     __device__ uint64_t* vals() { return reinterpret_cast<uint64_t*>(store + (size_t)QCAP * sizeof(K)); }
-    __device__ unsigned long long* hkeys() { return reinterpret_cast<unsigned long long*>(store); }            // hashed mode
-    __device__ unsigned long long* hvals() { return reinterpret_cast<unsigned long long*>(store) + SLOTS; }
+    __device__ unsigned long long* hkeys() { return reinterpret_cast<unsigned long long*>(store); }            // set mode
 };
 
 template <class K, int MODE>
@@ -323,9 +277,6 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchD
     r.endpos = r.pos + rlen;
     r.n_al = n_al;
     r.ok = n_al >= a.f.min_len;
-#if !XCK_LAZY_BOUNDS
-    if (MODE == XCK_MODE_BASEFC && a.f.frac_mode) frac_bounds(r, a.f.min_inc_frac);
-#endif
     return r;
 }
 
@@ -347,26 +298,6 @@ __device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const Batc
     return m;
 }
 
-// UCount.push_read + get_query_bases: BAM nibble of the query base at reference p0, or -1
-template <class K, int MODE>
-__device__ __forceinline__ int allele_at(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const ReadInfo& r, int i, int32_t p0) {
-    int32_t rp = r.pos, q = 0;
-    for (uint32_t c = r.c0; c < r.c1; c++) {
-        uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
-        if (op_aligned(op)) {
-            if (p0 >= rp && p0 < rp + l) {
-                int32_t qi = q + (p0 - rp);
-                uint32_t s0 = as_global(d.seq_off)[i], s1 = as_global(d.seq_off)[i + 1];
-                if ((uint32_t)(qi >> 1) >= s1 - s0) return -1;
-                uint32_t by = as_global(d.seq)[s0 + (qi >> 1)];
-                return (qi & 1) ? int(by & 15u) : int(by >> 4);
-            }
-            rp += l; q += l;
-        } else if (op == 1u || op == 4u) q += l;
-        else if (op_ref(op)) rp += l;
-    }
-    return -1;
-}
 
 // append straight to HBM (slow path: LDS set/queue saturated)
 template <class K, int MODE>
@@ -380,14 +311,10 @@ __device__ __forceinline__ void emit_global(const JoinArgs<K>& a, K key, uint64_
 // slot of a 64-bit key: full-rate VALU only (a 64-bit multiply is four quarter-rate v_mul ops on CDNA)
 template <int SLOTS>
 __device__ __forceinline__ uint32_t set_slot(unsigned long long kk) {
-#if XCK_HASH_MUL64
-    return (uint32_t)((kk * 0x9E3779B97F4A7C15ull) >> 40) & (SLOTS - 1);
-#else
     const uint32_t lo = (uint32_t)kk, hi = (uint32_t)(kk >> 32);
     uint32_t x = lo ^ ((hi << 9) | (hi >> 23));
     x ^= x >> 15;
     return (__umul24(x, 0x9E3779u) >> 12) & (SLOTS - 1);
-#endif
 }
 
 template <class K, int MODE>
@@ -398,15 +325,9 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
         unsigned long long* set = sm.hkeys();
         const unsigned long long kk = (unsigned long long)key;
         uint32_t slot = set_slot<SLOTS>(kk);
-#if !XCK_UNROLL_PROBE
-#pragma unroll 1
-#endif
         for (int probe = 0; probe < 24; probe++) {
             unsigned long long prev = atomicCAS(&set[slot], ~0ull, kk);
-            if (prev == ~0ull || prev == kk) {                       // new key, or a duplicate (same region|SNP, cell, UMI)
-                if (JoinSmem<K, MODE>::HAS_VAL) atomicMin(&sm.hvals()[slot], (unsigned long long)val);   // smallest ordinal wins
-                return;                                              // (no shared counter: flush points are static)
-            }
+            if (prev == ~0ull || prev == kk) return;                 // new key, or a duplicate (same region, cell, UMI); no shared counter: flush points are static
             slot = (slot + 1) & (SLOTS - 1);
         }
         emit_global<K, MODE>(a, key, val);
@@ -491,7 +412,6 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
                 uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (fits) a.keys[dst + pre] = (K)v;
                 set[s] = ~0ull;
-                if (JoinSmem<K, MODE>::HAS_VAL) { if (fits) a.vals[dst + pre] = sm.hvals()[s]; sm.hvals()[s] = ~0ull; }
             }
             dst += __popcll(m);
         }
@@ -537,7 +457,6 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
             int32_t s0, e0, row;
             if (staged) { s0 = sm.st_a[k]; e0 = sm.st_b[k]; row = sm.st_c[k]; }
             else { s0 = as_global(a.win_s0)[k]; e0 = as_global(a.win_e0)[k]; row = as_global(a.win_row)[k]; }
-            row &= 0x7fffffff;
             if (w != max(w_lo, s0 >> WS)) continue;                 // report each (read, region) pair once
             if (!(r.pos < e0 && r.endpos > s0)) continue;           // htslib fetch overlap
             int32_t m = included_len(a, d, sm, r, s0, e0);
@@ -553,30 +472,6 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
     return n_acc;
 }
 
-// per-read join over the GLOBAL tables for windows >= w_from; regions whose first window is below w_from belong
-// to the tile's staged duplicate-free list and are skipped here (w_from = 0: the plain per-read join)
-template <class K, int MODE>
-__device__ __forceinline__ uint32_t join_regions_global(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r, int32_t w_from) {
-    uint32_t n_acc = 0;
-    const int32_t w_lo = r.pos >> WS;
-    if (w_lo >= d.n_win) return 0;
-    const int32_t w_hi = min((r.endpos - 1) >> WS, d.n_win - 1);
-    for (int32_t w = max(w_lo, w_from); w <= w_hi; w++) {
-        const int32_t k0 = as_global(d.win_off)[w], k1 = as_global(d.win_off)[w + 1];
-        for (int32_t k = k0; k < k1; k++) {
-            const int32_t s0 = as_global(a.win_s0)[k], e0 = as_global(a.win_e0)[k];
-            const int32_t fw = s0 >> WS;
-            if (fw < w_from || w != max(w_lo, fw)) continue;
-            if (!(r.pos < e0 && r.endpos > s0)) continue;
-            const int32_t m = included_len(a, d, sm, r, s0, e0);
-            if (a.f.frac_mode) { if (r.n_al <= 0) continue; if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue; }
-            else if (m < a.f.min_inc_len) continue;
-            emit<K, MODE>(a, sm, a.kl.make((uint32_t)(as_global(a.win_row)[k] & 0x7fffffff), (uint32_t)r.cell, r.umi), 0);
-            n_acc++;
-        }
-    }
-    return n_acc;
-}
 
 // position of SNP k (staged slice first)
 template <class K, int MODE>
@@ -607,10 +502,8 @@ __device__ __forceinline__ int32_t lower_snp(const JoinArgs<K>& a, const BatchDe
 }
 // UCount.push_read + get_query_bases for a read parked in LDS slot u: BAM nibble of the query base at reference p0, or -1
 template <class K, int MODE>
-__device__ __forceinline__ int allele_at_slot(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int u, int i, int32_t p0) {
-    uint32_t s0, sl;
-    if (XCK_BAF_SEQ_PREFETCH) { s0 = sm.pr_s0[u]; sl = sm.pr_sl[u]; }
-    else { s0 = as_global(d.seq_off)[i]; sl = as_global(d.seq_off)[i + 1] - s0; }     // in flight during the CIGAR walk
+__device__ __forceinline__ int allele_at_slot(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int u, int32_t p0) {
+    const uint32_t s0 = sm.pr_s0[u], sl = sm.pr_sl[u];
     int32_t rp = sm.pr_pos[u], q = 0;
     const uint32_t c1 = sm.pr_c1[u];
     for (uint32_t c = sm.pr_c0[u]; c < c1; c++) {
@@ -655,26 +548,6 @@ __device__ __forceinline__ int nth_aligned_snp(const JoinArgs<K>& a, const Batch
     return -1;                                                           // not reached for jn < the read's pair count
 }
 
-template <class K, int MODE>
-__device__ __forceinline__ uint32_t join_snps(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r, int i) {
-    uint32_t n_acc = 0;
-    int32_t w_lo = r.pos >> WS;
-    if (w_lo >= d.n_swin) return 0;
-    int32_t k = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
-    auto p0_of = [&](int32_t kk) { uint32_t d = (uint32_t)(kk - sm.k0); return d < (uint32_t)sm.nk ? sm.st_a[d] : as_global(a.snp_p0)[kk]; };
-    while (k < d.snp_end && p0_of(k) < r.pos) k++;
-    for (; k < d.snp_end; k++) {
-        int32_t p0 = p0_of(k);
-        if (p0 >= r.endpos) break;
-        int al = allele_at(a, d, sm, r, i, p0);
-        const K key = a.kl.make((uint32_t)k, (uint32_t)r.cell, r.umi);
-        const uint64_t val = ((d.ordinal_base + (uint64_t)i) << ALLELE_BITS) | (uint64_t)(al + 1);
-        if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val);
-        else emit<K, MODE>(a, sm, key, val);
-        n_acc++;
-    }
-    return n_acc;
-}
 
 // one thread per tile: locate the batch, read the tile's extent, size the LDS staging
 template <int MODE>
@@ -685,7 +558,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (bt.desc[mid].tile0 <= t) lo = mid; else hi = mid - 1; }
     const BatchDesc& d = bt.desc[lo];
     TileMeta m;
-    m.b = lo; m.r0 = (t - d.tile0) * TILE; m.r1 = min(m.r0 + TILE, d.n); m.n0 = 0;
+    m.b = lo; m.r0 = (t - d.tile0) * TILE; m.r1 = min(m.r0 + TILE, d.n); m.pad = 0;
     const uint32_t c_lo = as_global(d.cig_off)[m.r0], c_hi = as_global(d.cig_off)[m.r1];
     const int32_t p_first = max(as_global(d.pos)[m.r0], 0), p_last = max(as_global(d.pos)[m.r1 - 1], 0);
     m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
@@ -697,7 +570,6 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
             int a_ = 0, z_ = nw_max;                              // largest nw with entries <= ST_CAP (offsets are monotone)
             while (a_ < z_) { int mid = (a_ + z_ + 1) >> 1; if (as_global(d.win_off)[m.w0 + mid] - e0 <= ST_CAP) a_ = mid; else z_ = mid - 1; }
             m.nw = a_; m.e0 = e0; m.n_ent = as_global(d.win_off)[m.w0 + a_] - e0;
-            m.n0 = a_ > 0 ? as_global(d.win_off)[m.w0 + 1] - e0 : 0;
         }
     } else {
         if (m.w0 < d.n_swin) { m.k0 = as_global(d.snp_win)[m.w0]; m.nk = min(d.snp_end - m.k0, ST_CAP); m.nw = min(d.n_swin - m.w0, ST_WIN); }
@@ -718,24 +590,20 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     // ---- prologue: one record from k_tile_meta, then ONE round of independent loads ----
     const XCK_GLOBAL TileMeta* mp = as_global(a.meta) + blockIdx.x;
     const uint32_t c_lo = mp->c_lo, cg_n = mp->cg_n;
-    const int32_t w0 = mp->w0, nw = mp->nw, e0 = mp->e0, n_ent = mp->n_ent, k0 = mp->k0, nk = mp->nk, n0 = mp->n0;
-    constexpr bool DENSE = XCK_DENSE && MODE == XCK_MODE_BASEFC && JoinSmem<K, MODE>::USE_SET;
+    const int32_t w0 = mp->w0, nw = mp->nw, e0 = mp->e0, n_ent = mp->n_ent, k0 = mp->k0, nk = mp->nk;
     const int b = __builtin_amdgcn_readfirstlane(mp->b);
     const int tile0 = __builtin_amdgcn_readfirstlane(mp->r0);
     const BatchDesc& d = a.bt.desc[b];                                // kernarg: scalar loads through the constant cache
     unsigned long long uor = 0;
     STAMP(0);
-    RawRead nxt; RawRead W[TILE_ITEMS];
-    if (DENSE || XCK_PREFETCH_ALL) {
+    RawRead W[TILE_ITEMS];
 #pragma unroll
-        for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read<MODE == XCK_MODE_BAF && XCK_BAF_BALANCED && XCK_BAF_SEQ_PREFETCH>(d, tile0 + j * JOIN_BLOCK + tid);   // the whole tile's loads fly during the staging
-    } else nxt = fetch_read<MODE == XCK_MODE_BAF && XCK_BAF_BALANCED && XCK_BAF_SEQ_PREFETCH>(d, tile0 + tid);                           // first sweep's loads overlap the staging
+    for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read<MODE == XCK_MODE_BAF>(d, tile0 + j * JOIN_BLOCK + tid);   // the whole tile's loads fly during the staging
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
-        unsigned long long* set = sm.hkeys();                         // keys, then (pileup) values: all ones = empty / +inf
-        for (int s = tid; s < JoinSmem<K, MODE>::SLOTS * (JoinSmem<K, MODE>::HAS_VAL ? 2 : 1); s += JOIN_BLOCK) set[s] = ~0ull;
+        unsigned long long* set = sm.hkeys();                         // all ones = empty
+        for (int s = tid; s < JoinSmem<K, MODE>::SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; sm.nuniq = 0; }
-    if (DENSE) __syncthreads();                                      // nuniq must be 0 before the appends below
+    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; }
     // Every global load of the prologue is issued BEFORE the first LDS store: written as load/store loops the
     // compiler waits (s_waitcnt vmcnt(0)) inside each iteration, which serialised ~7 HBM round trips per tile.
     static_assert(ST_CAP <= JOIN_BLOCK && ST_WIN + 1 <= JOIN_BLOCK, "staging assumes one element per thread");
@@ -747,7 +615,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     if (MODE == XCK_MODE_BASEFC) {
         if (nw > 0) {
             if (tid < n_ent) { g_a = as_global(a.win_s0)[e0 + tid]; g_b = as_global(a.win_e0)[e0 + tid]; g_c = as_global(a.win_row)[e0 + tid]; }
-            if (!DENSE && tid <= nw) g_w = as_global(d.win_off)[w0 + tid] - e0;
+            if (tid <= nw) g_w = as_global(d.win_off)[w0 + tid] - e0;
         }
     } else {
         if (tid < nk) g_a = as_global(a.snp_p0)[k0 + tid];
@@ -756,11 +624,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
 #pragma unroll
     for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; if (c < cg_n) sm.cig[c] = cw[q]; }
     if (MODE == XCK_MODE_BASEFC) {
-        if (nw > 0 && DENSE) {
-            // duplicate-free region list of the tile: an entry counts in window w0, or in the first window of its region
-            if (tid < n_ent && (tid < n0 || g_c < 0)) { const uint32_t u = atomicAdd(&sm.nuniq, 1u);
-                sm.st_a[u] = g_a; sm.st_b[u] = g_b; sm.st_c[u] = g_c & 0x7fffffff; }
-        } else if (nw > 0) {
+        if (nw > 0) {
             if (tid <= nw) sm.st_w[tid] = g_w;
             if (tid < n_ent) { sm.st_a[tid] = g_a; sm.st_b[tid] = g_b; sm.st_c[tid] = g_c; }
         }
@@ -776,60 +640,16 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     int pr_n = 0; uint32_t pr_total = 0;                              // pileup: parked reads / their pairs (wave-uniform)
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
     constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? JoinSmem<K, MODE>::SLOTS : JoinSmem<K, MODE>::QCAP;
-#ifndef XCK_FLUSH_END_ONLY
-#define XCK_FLUSH_END_ONLY 1
-#endif
     // set mode: the de-duplicated fill of a 1024-read tile is a few hundred keys, so flush once, at the end
     // (better de-duplication, half the cursor atomics); saturation still spills correctly through emit_global()
-    constexpr int FLUSH_EVERY = JoinSmem<K, MODE>::SPLIT ? TILE_ITEMS : JoinSmem<K, MODE>::USE_SET ? (JoinSmem<K, MODE>::HAS_VAL ? XCK_BAF_FLUSH_EVERY : TILE_ITEMS)
+    constexpr int FLUSH_EVERY = (JoinSmem<K, MODE>::SPLIT || JoinSmem<K, MODE>::USE_SET) ? TILE_ITEMS
                               : ((CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)));
-    if (DENSE) {
-        // ---- region-major evaluation: every thread keeps its 4 reads in registers; the loop over the tile's
-        //      duplicate-free region list is UNIFORM (same trip count in every lane, broadcast LDS reads), so the
-        //      divergent per-read window / candidate loops disappear from the common path
-        ReadInfo R[TILE_ITEMS]; bool in_list[TILE_ITEMS];
-        const int32_t w_end = nw > 0 ? w0 + nw : 0;                   // first window that is NOT covered by the list
 #pragma unroll
-        for (int j = 0; j < TILE_ITEMS; j++) {
-            R[j] = load_read<K, MODE>(a, d, sm, W[j]);
-            if (R[j].ok) uor |= R[j].umi;
-            in_list[j] = R[j].ok && nw > 0 && (R[j].pos >> WS) >= w0;  // reads before the staged range (unsorted input) go global
-        }
-        const int32_t nu = (XCK_EXP & 16) ? 0 : (int32_t)sm.nuniq;
-        for (int32_t k = 0; k < nu; k++) {
-            const int32_t s0 = sm.st_a[k], e0r = sm.st_b[k], row = sm.st_c[k];
-#pragma unroll
-            for (int j = 0; j < TILE_ITEMS; j++) {
-                const ReadInfo& r = R[j];
-                if (!in_list[j] || !(r.pos < e0r && r.endpos > s0)) continue;
-                const int32_t m = included_len(a, d, sm, r, s0, e0r);
-                if (a.f.frac_mode) { if (r.n_al <= 0) continue; if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue; }
-                else if (m < a.f.min_inc_len) continue;
-                emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
-                acc++;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TILE_ITEMS; j++) {                         // what the list does not cover (rare)
-            const ReadInfo& r = R[j];
-            if (!r.ok) continue;
-            if (!in_list[j]) acc += join_regions_global<K, MODE>(a, d, sm, r, 0);
-            else if (((r.endpos - 1) >> WS) >= w_end) acc += join_regions_global<K, MODE>(a, d, sm, r, w_end);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        flush<K, MODE>(a, sm);
-    } else
-#if XCK_UNROLL_TILE
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
     for (int j = 0; j < TILE_ITEMS; j++) {
         const int i = tile0 + j * JOIN_BLOCK + tid;
-        const RawRead cur = XCK_PREFETCH_ALL ? W[j] : nxt;
-        if (!XCK_PREFETCH_ALL && j + 1 < TILE_ITEMS) nxt = fetch_read<MODE == XCK_MODE_BAF && XCK_BAF_BALANCED && XCK_BAF_SEQ_PREFETCH>(d, i + JOIN_BLOCK);      // next sweep's loads fly during this sweep's work
+        const RawRead cur = W[j];
         ReadInfo r = load_read<K, MODE>(a, d, sm, cur);
-        if constexpr (MODE == XCK_MODE_BAF && XCK_BAF_BALANCED) {
+        if constexpr (MODE == XCK_MODE_BAF) {
             // A spliced read spans thousands of bases and tens of SNPs, most reads none: looping per read leaves the
             // wave waiting for its longest read.  So: every read only COUNTS its SNPs, the counts are scanned, and the
             // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
@@ -884,7 +704,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                     int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
                     int al;
                     if constexpr (JoinSmem<K, MODE>::SPLIT) al = nth_aligned_snp<K, MODE>(a, d, sm, u, pi - sm.pr_off[u], k);
-                    else al = allele_at_slot<K, MODE>(a, d, sm, u, sm.pr_idx[u], snp_p0<K, MODE>(a, sm, k));
+                    else al = allele_at_slot<K, MODE>(a, d, sm, u, snp_p0<K, MODE>(a, sm, k));
                     const K key = a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]);
                     const uint64_t val = ((d.ordinal_base + (uint64_t)sm.pr_idx[u]) << ALLELE_BITS) | (uint64_t)(al + 1);
                     if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val & ~(uint64_t)((1u << ALLELE_BITS) - 1));   // a record of one SNP
@@ -905,8 +725,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             acc += c + n_gap;
         } else if (r.ok) {
             uor |= r.umi;
-            if (MODE == XCK_MODE_BASEFC) acc += join_regions<K, MODE>(a, d, sm, r);
-            else acc += join_snps<K, MODE>(a, d, sm, r, i);
+            acc += join_regions<K, MODE>(a, d, sm, r);
         }
         // Flush points are fixed at compile time, never decided from sm.count: a count-based decision read
         // after the barrier races with the next sweep's inserts (threads could disagree and split at the
@@ -1632,10 +1451,6 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
     {   // window-list entries carry their region inline (one load level less in the join)
         std::vector<int32_t> ws0(win_list.size()), we0(win_list.size()), wrow(win_list.size());
         for (size_t k = 0; k < win_list.size(); k++) { int32_t g = win_list[k]; ws0[k] = reg_s0[g]; we0[k] = reg_e0[g]; wrow[k] = reg_row[g]; }
-        // top bit of the row: this entry sits in the FIRST window of its region (lets a tile build a duplicate-free list)
-        for (int c = 0; c < nc; c++) { const ContigTab& t = im->ctab[c];
-            for (int32_t w = 0; w < t.n_win; w++) for (int32_t k = win_off[t.win_base + w]; k < win_off[t.win_base + w + 1]; k++)
-                if ((ws0[k] >> WS) == w) wrow[k] |= (int32_t)0x80000000; }
         if ((rc = dev_upload(im, &im->d_win_s0, ws0))) return rc;
         if ((rc = dev_upload(im, &im->d_win_e0, we0))) return rc;
         if ((rc = dev_upload(im, &im->d_win_row, wrow))) return rc;
@@ -1678,7 +1493,7 @@ static int res_reserve(EngineImpl* im, int m, size_t nnz) {
 
 // per-shard head room added to every capacity guess (XCK_HIT_SLACK: test knob that makes the overflow / replay path easy to reach)
 static inline size_t hit_slack() { const char* e = getenv("XCK_HIT_SLACK"); return e ? (size_t)std::max(0ll, atoll(e)) : 65536; }
-static inline bool split_mode(const EngineImpl* im) { return XCK_BAF_SPLIT && !XCK_BAF_MAP && im->mode == XCK_MODE_BAF && im->key_bits == 64; }
+static inline bool split_mode(const EngineImpl* im) { return XCK_BAF_SPLIT && im->mode == XCK_MODE_BAF && im->key_bits == 64; }
 
 static int ensure_hits(EngineImpl* im, size_t need) {           // need = elements per shard
     if (need <= im->hit_cap) return 0;
