@@ -6,14 +6,17 @@
 // with ONE streaming pass over coordinate-sorted record batches:
 //
 //   k_tile_meta : one thread per 1024-read tile: extent, staged index windows (48-byte record).
-//   k_join      : one block per tile; CIGAR run, window CSR and regions / SNPs staged in LDS; read x region
-//                 interval join + CIGAR-walk include test, or read x SNP join + query base at the SNP;
-//                 accepted keys de-duplicated in an LDS hash set; fragments appended through sharded cursors.
-//   finish      : radix sort of the keys (rocPRIM), then hand-written segmented reductions:
-//                 k_fold_heads/k_fold_emit (distinct-UMI counts per (row, cell) straight into COO);
-//                 k_first_read ("first read wins" per (snp, cell, umi)) + per-SNP allele tallies,
-//                 k_expand (per-SNP filters, SNP -> region fan-out), k_hap_counts (haplotype set algebra),
-//                 k_cp_* (ordered compaction); copy-out on the copy stream (xck_finish_async).
+//   k_join      : one block per tile; CIGAR run, window CSR and regions / SNPs staged in LDS.
+//                 basefc: read x region interval join + CIGAR-walk include test, accepted keys de-duplicated in an LDS
+//                 hash set.  pileup: read x SNP join with the (read, SNP) pairs dealt evenly over each wave's lanes; hits
+//                 with a base and "gap records" (SNPs inside N / D gaps) leave in two streams.
+//                 Fragments are appended through sharded cursors.
+//   finish      : basefc: radix sort (rocPRIM) over the (row, cell) bits, k_fold_heads / k_fold_emit_unsorted (distinct
+//                 UMIs of a run told apart by an LDS hash set) straight into COO; classic path: full sort + k_fold_emit.
+//                 pileup: sort of the hits with a base, k_first_base (first read per key, Bloom filter), k_claim (gap
+//                 records that hold a key earlier in fetch order), k_tally, k_expand (per-SNP filters, SNP -> region
+//                 fan-out), k_hap_counts (haplotype set algebra), k_cp_* (ordered compaction); 128-bit keys: k_first_read.
+//                 Copy-out on the copy stream (xck_finish_async).
 //
 // Integer / byte work only - HBM-bound, no MFMA.  See DESIGN.md for layouts, byte counts and measurements.
 #include <algorithm>
@@ -152,7 +155,7 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double
     return (double)m / (double)r.n_al < f;
 }
 
-// ---- join kernel: one 256-thread block per tile of 2048 consecutive reads ---------------------
+// ---- join kernel: one 256-thread block per tile of 1024 consecutive reads ---------------------
 // Reads are coordinate sorted, so a tile touches a handful of index windows, regions / SNPs and
 // one contiguous run of CIGAR words: all of that is staged in LDS once per tile (with a global
 // fallback for anything outside the staged range - the staging is a cache, never a correctness
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     STAMP(1);
     __syncthreads();
     STAMP(2);
-    // ---- 8 coalesced sweeps over the tile ----
+    // ---- TILE_ITEMS coalesced sweeps over the tile (the reads were requested in the prologue) ----
     uint32_t acc = 0;
     int pr_n = 0; uint32_t pr_total = 0;                              // pileup: parked reads / their pairs (wave-uniform)
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
