@@ -2,7 +2,13 @@
 #include <hip/hip_runtime_api.h>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <memory>
+#include <string>
 #include <thread>
+#include <vector>
 #include "xck_internal.h"
 
 using namespace xck;
@@ -128,25 +134,53 @@ int xck_get_stats(const xck_engine* ce, xck_stats* out) {
 
 // merge_mtx() header + body, rdr/fc/utils.py:54-93 (byte-identical text)
 int xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map, int32_t n_rows_out, int32_t n_cols) {
+    // Text identical to merge_mtx (rdr/fc/utils.py:54-93).  A 500 M-read run writes ~10^8 lines: the entries are formatted by
+    // a few threads, a wave of 1 M-entry chunks at a time, and the chunks are written in order.
     if (!path || !m || !row_map) return XCK_E_ARG;
     FILE* fp = fopen(path, "wb");
     if (!fp) { set_thread_error(std::string("cannot open ") + path); return XCK_E_IO; }
-    static const size_t BUF = 1 << 22;
-    std::string buf; buf.reserve(BUF + 64);
-    int64_t nnz = 0;
-    for (int64_t i = 0; i < m->nnz; i++) if (row_map[m->row[i]] > 0) nnz++;
+    const int64_t n = m->nnz;
+    const int64_t CH = 1 << 20;
+    const int64_t n_chunks = (n + CH - 1) / CH;
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
+    if (const char* e = getenv("XCK_WRITE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    if ((int64_t)nt > n_chunks) nt = (unsigned)std::max<int64_t>(n_chunks, 1);
+    auto for_chunks = [&](int64_t c0, int64_t c1, const std::function<void(int64_t)>& fn) {
+        if (nt <= 1 || c1 - c0 <= 1) { for (int64_t c = c0; c < c1; c++) fn(c); return; }
+        std::atomic<int64_t> next(c0);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { for (int64_t c; (c = next.fetch_add(1)) < c1;) fn(c); });
+        for (auto& x : th) x.join();
+    };
+    std::vector<int64_t> kept((size_t)n_chunks, 0);
+    for_chunks(0, n_chunks, [&](int64_t c) { int64_t k = 0; const int64_t e = std::min(n, (c + 1) * CH);
+        for (int64_t i = c * CH; i < e; i++) if (row_map[m->row[i]] > 0) k++; kept[(size_t)c] = k; });
+    int64_t nnz = 0; for (int64_t k : kept) nnz += k;
     char line[96];
     int k = snprintf(line, sizeof line, "%%%%MatrixMarket matrix coordinate integer general\n%%%%\n%d\t%d\t%lld\n", n_rows_out, n_cols, (long long)nnz);
-    buf.append(line, (size_t)k);
-    auto put_int = [&](int64_t v) { char t[24]; int n = 0; if (v == 0) t[n++] = '0'; bool neg = v < 0; if (neg) v = -v;
-        while (v) { t[n++] = char('0' + v % 10); v /= 10; } if (neg) buf.push_back('-'); while (n) buf.push_back(t[--n]); };
-    for (int64_t i = 0; i < m->nnz; i++) {
-        int32_t r = row_map[m->row[i]];
-        if (r <= 0) continue;
-        put_int(r); buf.push_back('\t'); put_int((int64_t)m->col[i] + 1); buf.push_back('\t'); put_int(m->val[i]); buf.push_back('\n');
-        if (buf.size() >= BUF) { if (fwrite(buf.data(), 1, buf.size(), fp) != buf.size()) { fclose(fp); return XCK_E_IO; } buf.clear(); }
+    if (fwrite(line, 1, (size_t)k, fp) != (size_t)k) { fclose(fp); return XCK_E_IO; }
+    auto put_int = [](char*& p, int64_t v) { char t[24]; int q = 0; if (v == 0) t[q++] = '0'; const bool neg = v < 0; if (neg) v = -v;
+        while (v) { t[q++] = char('0' + v % 10); v /= 10; } if (neg) *p++ = '-'; while (q) *p++ = t[--q]; };
+    const int64_t WAVE = std::max<int64_t>(nt * 2, 1);
+    std::vector<std::unique_ptr<char[]>> bufs((size_t)WAVE);           // uninitialised, allocated on first use, reused by every wave
+    std::vector<size_t> used((size_t)WAVE, 0);
+    for (int64_t w0 = 0; w0 < n_chunks; w0 += WAVE) {
+        const int64_t w1 = std::min(n_chunks, w0 + WAVE);
+        for_chunks(w0, w1, [&](int64_t c) {
+            std::unique_ptr<char[]>& b = bufs[(size_t)(c - w0)];
+            if (!b) b.reset(new char[(size_t)CH * 36]);                // 3 ints of <= 11 characters + 3 separators per line
+            char* p = b.get();
+            const int64_t e = std::min(n, (c + 1) * CH);
+            for (int64_t i = c * CH; i < e; i++) {
+                const int32_t r = row_map[m->row[i]];
+                if (r <= 0) continue;
+                put_int(p, r); *p++ = '\t'; put_int(p, (int64_t)m->col[i] + 1); *p++ = '\t'; put_int(p, m->val[i]); *p++ = '\n';
+            }
+            used[(size_t)(c - w0)] = (size_t)(p - b.get());
+        });
+        for (int64_t c = w0; c < w1; c++)
+            if (used[(size_t)(c - w0)] && fwrite(bufs[(size_t)(c - w0)].get(), 1, used[(size_t)(c - w0)], fp) != used[(size_t)(c - w0)]) { fclose(fp); return XCK_E_IO; }
     }
-    if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), fp) != buf.size()) { fclose(fp); return XCK_E_IO; }
     if (fclose(fp) != 0) return XCK_E_IO;
     return XCK_OK;
 }
