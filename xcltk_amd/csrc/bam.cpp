@@ -32,28 +32,90 @@ static thread_local std::string t_err;
 void set_thread_error(const std::string& s) { t_err = s; }
 const char* get_thread_error() { return t_err.c_str(); }
 
-uint64_t hash_bytes(const char* s, size_t n) {
-    uint64_t h = 0xcbf29ce484222325ull;
-    for (size_t i = 0; i < n; i++) { h ^= (uint8_t)s[i]; h *= 0x100000001b3ull; }
+uint64_t hash_bytes(const char* s, size_t n) {                       // 8 bytes per step (read names are 20-40 characters)
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    while (n >= 8) { uint64_t w; memcpy(&w, s, 8); h = (h ^ w) * 0xbf58476d1ce4e5b9ull; h ^= h >> 32; s += 8; n -= 8; }
+    if (n) { uint64_t w = 0; memcpy(&w, s, n); h = (h ^ w) * 0x94d049bb133111ebull; }
     h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
     return h;
 }
 
+void InternTable::Shard::grow() {
+    const size_t ncap = slots.empty() ? 1024 : slots.size() * 2;
+    std::vector<Slot> ns(ncap, Slot{0, 0, 0, 0, 0});
+    for (const Slot& sl : slots) if (sl.epoch == epoch) {
+        size_t i = (size_t)(sl.h >> 6) & (ncap - 1);
+        while (ns[i].epoch == epoch) i = (i + 1) & (ncap - 1);
+        ns[i] = sl;
+    }
+    slots.swap(ns);
+}
+
 uint64_t InternTable::intern(const char* s, size_t n) {
-    uint64_t h = hash_bytes(s, n);
+    const uint64_t h = hash_bytes(s, n);
     Shard& sh = shards_[h & (NSHARD - 1)];
     std::lock_guard<std::mutex> lk(sh.mu);
-    auto it = sh.map.find(std::string(s, n));
-    if (it != sh.map.end()) return it->second;
-    uint64_t id = ((uint64_t)sh.map.size() << 6) | (h & (NSHARD - 1));
-    sh.map.emplace(std::string(s, n), id);
-    return id;
+    if ((size_t)(sh.count + 1) * 2 > sh.slots.size()) sh.grow();
+    const size_t mask = sh.slots.size() - 1;
+    size_t i = (size_t)(h >> 6) & mask;
+    for (;;) {
+        Slot& sl = sh.slots[i];
+        if (sl.epoch != sh.epoch) {
+            sl.h = h; sl.off = (uint32_t)sh.arena.size(); sl.len1 = (uint32_t)n + 1; sl.idx = sh.count++; sl.epoch = sh.epoch;
+            sh.arena.insert(sh.arena.end(), s, s + n);
+            return ((uint64_t)sl.idx << 6) | (h & (NSHARD - 1));
+        }
+        if (sl.h == h && sl.len1 == (uint32_t)n + 1 && memcmp(sh.arena.data() + sl.off, s, n) == 0) return ((uint64_t)sl.idx << 6) | (h & (NSHARD - 1));
+        i = (i + 1) & mask;
+    }
 }
-uint64_t InternTable::size() const { uint64_t n = 0; for (auto& s : shards_) n += s.map.size(); return n; }
-void InternTable::clear() { for (auto& s : shards_) { std::lock_guard<std::mutex> lk(s.mu); s.map.clear(); } }
+uint64_t InternTable::hash(const char* s, size_t n) { return hash_bytes(s, n); }
 
-uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, bool* overflow) {
-    if (n == 0) return XCK_UMI_NONE;
+// UMI-less mode interns every read name: per string the shared table costs a lock and two cache misses (the table of a
+// 2 M-read BAM is ~100 MB).  A parse task therefore collects its names and hands them over here, sorted by shard: one
+// lock per shard, and the probes of a shard (1/64 of the table) hit the cache.
+void InternTable::intern_batch(std::vector<Item>& items, bool* overflow) {
+    std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return (a.h & (NSHARD - 1)) < (b.h & (NSHARD - 1)); });
+    size_t i = 0;
+    while (i < items.size()) {
+        const unsigned shard = (unsigned)(items[i].h & (NSHARD - 1));
+        Shard& sh = shards_[shard];
+        std::lock_guard<std::mutex> lk(sh.mu);
+        for (; i < items.size() && (items[i].h & (NSHARD - 1)) == shard; i++) {
+            const Item& it = items[i];
+            if ((size_t)(sh.count + 1) * 2 > sh.slots.size()) sh.grow();
+            const size_t mask = sh.slots.size() - 1;
+            if (i + 4 < items.size()) __builtin_prefetch(&sh.slots[(size_t)(items[i + 4].h >> 6) & mask]);
+            size_t k = (size_t)(it.h >> 6) & mask;
+            uint64_t id;
+            for (;;) {
+                Slot& sl = sh.slots[k];
+                if (sl.epoch != sh.epoch) {
+                    sl.h = it.h; sl.off = (uint32_t)sh.arena.size(); sl.len1 = it.n + 1; sl.idx = sh.count++; sl.epoch = sh.epoch;
+                    sh.arena.insert(sh.arena.end(), it.s, it.s + it.n);
+                    id = ((uint64_t)sl.idx << 6) | shard; break;
+                }
+                if (sl.h == it.h && sl.len1 == it.n + 1 && memcmp(sh.arena.data() + sl.off, it.s, it.n) == 0) { id = ((uint64_t)sl.idx << 6) | shard; break; }
+                k = (k + 1) & mask;
+            }
+            const uint64_t lim = it.umi_bits >= 64 ? (1ull << 63) - 1 : (1ull << (it.umi_bits - 1)) - 1;
+            if (id >= lim) { if (overflow) *overflow = true; *it.out = XCK_UMI_NONE; }
+            else *it.out = (1ull << (it.umi_bits - 1)) | id;
+        }
+    }
+}
+uint64_t InternTable::size() const { uint64_t n = 0; for (auto& s : shards_) n += s.count; return n; }
+void InternTable::clear() {
+    for (auto& s : shards_) {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.arena.clear(); s.count = 0;
+        if (++s.epoch == 0) { std::fill(s.slots.begin(), s.slots.end(), Slot{0, 0, 0, 0, 0}); s.epoch = 1; }   // slots of older epochs read as empty
+    }
+}
+
+// the part of encode_key() that needs no table: empty string -> NONE, short ACGT string -> 2-bit code
+static bool encode_key_direct(const char* s, size_t n, int umi_bits, uint64_t* out) {
+    if (n == 0) { *out = XCK_UMI_NONE; return true; }
     if (2 * (int)n + 1 <= umi_bits - 1) {
         uint64_t v = 1; bool ok = true;
         for (size_t i = 0; i < n; i++) {
@@ -62,8 +124,14 @@ uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, boo
             if (c > 3) { ok = false; break; }
             v = (v << 2) | c;
         }
-        if (ok) return v;
+        if (ok) { *out = v; return true; }
     }
+    return false;
+}
+
+uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, bool* overflow) {
+    uint64_t direct;
+    if (encode_key_direct(s, n, umi_bits, &direct)) return direct;
     uint64_t id = tab.intern(s, n);
     uint64_t lim = umi_bits >= 64 ? (1ull << 63) - 1 : (1ull << (umi_bits - 1)) - 1;
     if (id >= lim) { if (overflow) *overflow = true; return XCK_UMI_NONE; }
@@ -461,6 +529,9 @@ static inline const uint8_t* aux_skip(const uint8_t* p, const uint8_t* e) {     
 static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, int64_t r1, std::atomic<int>* flags) {
     const DecodeCfg& dc = e->dec;
     HostSoA& s = b->soa;
+    // UMI-less mode: every read name goes through the intern table - collected here, interned in one batch at the end
+    std::vector<InternTable::Item> names;
+    if (!dc.use_umi) names.reserve((size_t)(r1 - r0));
     for (int64_t r = r0; r < r1; r++) {
         int64_t o = b->rec_out[r];
         if (o < 0) continue;
@@ -506,10 +577,12 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
                     key = encode_key(t.data(), t.size(), dc.umi_bits, e->intern, &ovf);
                 }
             }
-        } else key = encode_key(qname, qlen, dc.umi_bits, e->intern, &ovf);
+        } else if (encode_key_direct(qname, qlen, dc.umi_bits, &key)) { /* empty or 2-bit codable name */ }
+        else { names.push_back(InternTable::Item{InternTable::hash(qname, qlen), qname, (uint32_t)qlen, 0, &s.umi[o], dc.umi_bits}); key = XCK_UMI_NONE; }
         if (ovf) flags->fetch_or(2);
         s.umi[o] = key;
     }
+    if (!names.empty()) { bool ovf = false; e->intern.intern_batch(names, &ovf); if (ovf) flags->fetch_or(2); }
 }
 
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error

@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
     const int64_t n_reads = atoll(argv[5]); const uint64_t seed = strtoull(argv[6], nullptr, 10);
     int n_thr = argc > 7 ? atoi(argv[7]) : (int)std::thread::hardware_concurrency(); if (n_thr <= 0) n_thr = 4;
     const int level = argc > 8 ? atoi(argv[8]) : 6;
+    const bool no_tags = getenv("XCK_SYNTH_NOTAGS") && atoi(getenv("XCK_SYNTH_NOTAGS"));
     std::vector<std::string> cname; std::vector<int32_t> clen;
     { std::ifstream f(argv[2]); std::string a; int64_t l; while (f >> a >> l) { cname.push_back(a); clen.push_back((int32_t)l); } }
     std::vector<Gene> genes;
@@ -135,9 +136,11 @@ int main(int argc, char** argv) {
                 for (int j = 0; j < (L + 1) / 2; j++) { uint32_t x = (uint32_t)r.next(); rec.push_back((char)(((1u << (x & 3)) << 4) | (1u << ((x >> 2) & 3)))); }
                 for (int j = 0; j < L; j++) { static const char q4[4] = {11, 25, 37, 37}; rec.push_back(q4[r.below(4)]); }
                 rec.append("NHC", 3); rec.push_back(1);
+                if (!no_tags) {                                       // XCK_SYNTH_NOTAGS=1: well-based (SMART-seq) style BAM without CB / UB
                 if (cell >= 0) { rec.append("CBZ", 3); rec += bcs[cell]; rec.push_back('\0'); }
                 else if (outside) { rec.append("CBZ", 3); for (int j = 0; j < 16; j++) rec.push_back("ACGT"[m.below(4)]); rec.append("-9", 2); rec.push_back('\0'); }
                 if (has_ub) { rec.append("UBZ", 3); rec.append(umi, 13); }
+                }
                 uint32_t bs = (uint32_t)rec.size();
                 if (payload.size() + 4 + bs > 0xff00 && !payload.empty()) { bgzf_block(payload.data(), payload.size(), level, o); payload.clear(); }
                 payload.append((const char*)&bs, 4); payload += rec;
