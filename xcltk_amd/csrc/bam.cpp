@@ -346,6 +346,16 @@ struct SeqReader {
     }
 };
 
+// A multi-BAM run (one file per cell, hundreds of files) opens and closes a reader per file.  The big buffers of a reader -
+// pinned SoA arrays (hipHostMalloc pins page by page), the two inflate buffers, the record index, the thread pool - cost
+// ~30 ms to set up, twice the decode time of a 500 k-read file: closed readers park them here for the next open.
+struct BamScratch {
+    HostSoA soa; std::vector<uint8_t> ubuf[2]; std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;
+    Pool* pool = nullptr; int n_threads = 0;
+};
+static std::mutex g_scratch_mu;
+static std::vector<BamScratch*> g_scratch;                            // at most 4 parked sets; kept until the process ends
+
 extern "C" {
 
 int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen) {
@@ -380,7 +390,15 @@ int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size
     else { b->next_coff = r.blk_coff; b->first_skip = (uint32_t)(r.pos - r.blk_start); }
     if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 4; }
     b->n_threads = n_threads;
-    b->pool = new Pool(n_threads);
+    { BamScratch* sc = nullptr;
+      { std::lock_guard<std::mutex> lk(g_scratch_mu); if (!g_scratch.empty()) { sc = g_scratch.back(); g_scratch.pop_back(); } }
+      if (sc) {
+          b->soa = sc->soa; b->ch[0].ubuf.swap(sc->ubuf[0]); b->ch[1].ubuf.swap(sc->ubuf[1]);
+          b->recs.swap(sc->recs); b->rec_contig.swap(sc->rec_contig); b->rec_out.swap(sc->rec_out);
+          if (sc->pool && sc->n_threads == n_threads) b->pool = sc->pool; else delete sc->pool;
+          delete sc;
+      } }
+    if (!b->pool) b->pool = new Pool(n_threads);
     if (const char* cb = getenv("XCK_CHUNK_BYTES")) { long long v = atoll(cb); if (v >= 1024) b->chunk_target = (size_t)v; }   // tests: force many chunks
     *out = b;
     return XCK_OK;
@@ -389,8 +407,13 @@ int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size
 void xck_bam_close(xck_bam* b) {
     if (!b) return;
     for (auto& c : b->ch) c.tg.wait();
-    delete b->pool;
-    soa_free(b->soa);
+    { BamScratch* sc = new BamScratch();
+      sc->soa = b->soa; b->soa = HostSoA(); sc->ubuf[0].swap(b->ch[0].ubuf); sc->ubuf[1].swap(b->ch[1].ubuf);
+      sc->recs.swap(b->recs); sc->rec_contig.swap(b->rec_contig); sc->rec_out.swap(b->rec_out);
+      sc->pool = b->pool; sc->n_threads = b->n_threads; b->pool = nullptr;
+      std::lock_guard<std::mutex> lk(g_scratch_mu);
+      if (g_scratch.size() < 4) g_scratch.push_back(sc);
+      else { delete sc->pool; soa_free(sc->soa); delete sc; } }
     if (b->map) munmap((void*)b->map, b->fsize);
     if (b->fd >= 0) close(b->fd);
     delete b;
