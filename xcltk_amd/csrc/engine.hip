@@ -40,6 +40,10 @@ typedef unsigned __int128 u128;
 #define XCK_EXP 0          // timing experiments only (wrong results): 1 no emit, 2 no fp64 divide, 4 no CIGAR re-walk, 8 no flush, 16 no join, 32 pileup: no SNP work, 64 pileup: count only
 #endif
 constexpr int WS = XCK_WS;             // window shift of the interval index (2^WS bp windows)
+#ifndef XCK_WS_SNP
+#define XCK_WS_SNP 10           // 1 kb: the first probe lands within a SNP or two of the read (32 kb windows needed a binary search per read)
+#endif
+constexpr int WSS = XCK_WS_SNP;        // window shift of the SNP index (window -> first SNP)
 constexpr int JOIN_BLOCK = 256;
 
 #define HIP_TRY(expr)                                                                      \
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     const uint32_t c_lo = as_global(d.cig_off)[m.r0], c_hi = as_global(d.cig_off)[m.r1];
     const int32_t p_first = max(as_global(d.pos)[m.r0], 0), p_last = max(as_global(d.pos)[m.r1 - 1], 0);
     m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
-    m.w0 = p_first >> WS; m.nw = 0; m.e0 = 0; m.n_ent = 0; m.k0 = 0; m.nk = 0;
+    m.w0 = p_first >> (MODE == XCK_MODE_BASEFC ? WS : WSS); m.nw = 0; m.e0 = 0; m.n_ent = 0; m.k0 = 0; m.nk = 0;
     if (MODE == XCK_MODE_BASEFC) {
         if (m.w0 < d.n_win && p_last >= p_first) {
             int nw_max = min(min((p_last >> WS) + 1, d.n_win - 1) - m.w0 + 1, ST_WIN);
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             // wave waiting for its longest read.  So: every read only COUNTS its SNPs, the counts are scanned, and the
             // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
             int32_t k_lo = 0; uint32_t c = 0, n_gap = 0;
-            const int32_t w_lo = r.pos >> WS;
+            const int32_t w_lo = r.pos >> WSS;
             if (r.ok && w_lo < d.n_swin && !(XCK_EXP & 32)) {
                 const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
                 k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
@@ -1434,9 +1438,9 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
                 snp_info.push_back(nib_of(x.ref) | (nib_of(x.alt) << 4) | ((uint32_t)(x.ref_hap & 1) << 8) | ((uint32_t)(x.alt_hap & 1) << 9));
             }
             int32_t max_p = v.empty() ? 0 : cfg->snps[v.back()].pos;
-            t.n_swin = v.empty() ? 0 : (max_p >> WS) + 1;
+            t.n_swin = v.empty() ? 0 : (max_p >> WSS) + 1;
             t.swin_base = (int32_t)snp_win.size();
-            { int32_t k = 0; for (int32_t w = 0; w < t.n_swin; w++) { while (k < t.n_snp && snp_p0[t.snp_base + k] < (w << WS)) k++; snp_win.push_back(t.snp_base + k); } }
+            { int32_t k = 0; for (int32_t w = 0; w < t.n_swin; w++) { while (k < t.n_snp && snp_p0[t.snp_base + k] < (w << WSS)) k++; snp_win.push_back(t.snp_base + k); } }
             // SNP -> regions: start <= pos <= end_incl; rows ascending so keys stay deterministic
             std::vector<std::vector<int32_t>> hits(t.n_snp);
             for (int32_t g : reg_c[c]) {
