@@ -880,7 +880,10 @@ static_assert(FU_ITEMS * FU_BLOCK == FD_TILE && FU_STRIDE * FU_BLOCK == FU_LEAD 
 __global__ __launch_bounds__(FU_BLOCK) void k_fold_emit_unsorted(const unsigned long long* __restrict__ k, long long n, KeyLayout<unsigned long long> kl,
                                                                  const unsigned long long* __restrict__ off,
                                                                  int32_t* __restrict__ row, int32_t* __restrict__ col, int32_t* __restrict__ val,
-                                                                 unsigned long long* __restrict__ giant) {
+                                                                 unsigned long long* __restrict__ giant, int sub_shift) {
+    // sub_shift = lowest key bit the radix sort covered (<= kl.ubits): the sort's whole digits usually reach a few bits into
+    // the UMI field, so a (row, cell) run is a sequence of sub-runs by UMI prefix - and only the sub-run of the tile's first
+    // key can have keys (hence duplicates) in earlier tiles.  That is what the lead-in covers.
     typedef unsigned long long K;
     extern __shared__ K set[];                                            // FU_SLOTS slots (a tile with a short lead-in uses half)
     __shared__ uint16_t s_hx[FD_TILE + 1], s_he[FD_TILE];                 // per head: distinct keys before it / its element
@@ -902,21 +905,21 @@ __global__ __launch_bounds__(FU_BLOCK) void k_fold_emit_unsorted(const unsigned 
     const unsigned long long out = off[blockIdx.x];
     // ---- lead-in of the first run: keys of earlier tiles with the (row, cell) of the tile's first key (a suffix of
     //      what precedes the tile).  One coarse probe per thread, FU_STRIDE keys apart, then FU_STRIDE fine ones: two L2 round trips.
-    const K rc0 = kl.rc(k[base]);
+    const K rc0 = k[base] >> sub_shift;
     const long long w0 = max(0ll, base - FU_LEAD);
     long long lead0 = base;
-    if (base > 0 && kl.rc(k[base - 1]) == rc0) {                          // block-uniform
+    if (base > 0 && (k[base - 1] >> sub_shift) == rc0) {                      // block-uniform
         if (tid == 0) s_lead = base - 1;
         __syncthreads();
         const long long g = base - 1 - (long long)FU_STRIDE * tid;
-        if (g >= w0 && kl.rc(k[g]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g);
+        if (g >= w0 && (k[g] >> sub_shift) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g);
         __syncthreads();
         const long long c = s_lead;                                       // smallest coarse match: the run starts in (c - FU_STRIDE, c]
         __syncthreads();
-        if (tid < FU_STRIDE) { const long long g2 = c - tid; if (g2 >= w0 && kl.rc(k[g2]) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g2); }
+        if (tid < FU_STRIDE) { const long long g2 = c - tid; if (g2 >= w0 && (k[g2] >> sub_shift) == rc0) atomicMin((unsigned long long*)&s_lead, (unsigned long long)g2); }
         __syncthreads();
         lead0 = s_lead;
-        if (tid == 0 && lead0 == w0 && w0 > 0 && kl.rc(k[w0 - 1]) == rc0) *giant = 1ull;   // the run starts before the window
+        if (tid == 0 && lead0 == w0 && w0 > 0 && (k[w0 - 1] >> sub_shift) == rc0) *giant = 1ull;   // the sub-run starts before the window
     }
     const int slots = ((int)(base - lead0) + n_loc <= 3072) ? FU_SLOTS / 2 : FU_SLOTS;      // block-uniform; load factor <= 0.75
     const uint32_t smask = (uint32_t)slots - 1;
@@ -1335,6 +1338,7 @@ struct EngineImpl {
     unsigned long long cur[NSHARD] = {0};      // host view of the shard cursors after the last completed launch
     unsigned long long cur_before[NSHARD] = {0}, acc_before[NSHARD] = {0};
     unsigned long long cursor = 0;             // sum of cur[]; hit_cap is the capacity of ONE shard
+    int fold_extra_digits = 0;                 // basefc hash fold: extra radix digits that earlier finishes needed (giant runs)
     // fused launch queue
     std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
     std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
@@ -1790,7 +1794,7 @@ static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total) {
 // basefc: sorted keys -> COO (row, col, count of distinct keys) without a dense intermediate
 constexpr int FOLD_GIANT = 1;              // fold_coo(): a (row, cell) run too long for the hash fold - redo on fully sorted keys
 template <class K>
-static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayout<K> kl, int m, bool umi_sorted = true) {
+static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayout<K> kl, int m, int sorted_from = 0) {   // sorted_from: lowest key bit the sort covered
     size_t nb = (n + FD_TILE - 1) / FD_TILE;
     uint32_t* d_blk = ws.get<uint32_t>(nb); unsigned long long* d_off = ws.get<unsigned long long>(nb);
     if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (fold)"; return XCK_E_NOMEM; }
@@ -1807,13 +1811,13 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
     if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
     HIP_TRY(hipMemsetAsync(d_o + 2 * total, 0, total * sizeof(int32_t), im->s_comp));       // k_fold_emit accumulates run pieces into val[]
     if constexpr (sizeof(K) == 8) {
-        if (!umi_sorted) {
+        if (sorted_from > 0) {
             HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_GIANT, 0, sizeof(unsigned long long), im->s_comp));
             KeyLayout<unsigned long long> kl8; kl8.ubits = kl.ubits; kl8.cbits = kl.cbits;
             static bool lds_set = false;
             if (!lds_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_fold_emit_unsorted, hipFuncAttributeMaxDynamicSharedMemorySize, FU_SLOTS * 8)); lds_set = true; }
             hipLaunchKernelGGL(k_fold_emit_unsorted, dim3(nb), dim3(FU_BLOCK), FU_SLOTS * 8, im->s_comp, (const unsigned long long*)keys, (long long)n, kl8, d_off,
-                               d_o, d_o + total, d_o + 2 * total, im->d_ctl + CTL_GIANT);
+                               d_o, d_o + total, d_o + 2 * total, im->d_ctl + CTL_GIANT, sorted_from);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_GIANT), im->d_hctl + CTL_GIANT, 1);
             HIP_TRY(hipGetLastError());
@@ -1879,7 +1883,7 @@ static int finish_t(EngineImpl* im) {
     K* keys = (K*)im->d_keys;
     if (im->mode == XCK_MODE_BASEFC) {
         const size_t tmpb = sort_tmp_bytes<K, rocprim::empty_type>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + 2 * (nb * 12 + n * 12) + (1 << 20)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + nb * 12 + n * 12 + (1 << 20)))) return rc;
         K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb);
         if ((rc = tm.start())) return rc;
         int used = im->ubits;                                                       // UMI bits actually in use
@@ -1899,11 +1903,22 @@ static int finish_t(EngineImpl* im) {
         // (rocPRIM 4.2 returns garbage for begin_bit > 0 with end_bit = 64 - tools/scratch/sortpart.hip - so keys that could not be
         // squeezed below 63 bits take the classic path)
         const bool partial = sizeof(K) == 8 && !full_sort && top_fc <= 62;
-        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, alt, keys, nullptr, nullptr, n, top_fc, partial ? kl.ubits : 0))) return rc;
-        rc = fold_coo<K>(im, im->ws1, keys, n, kl, 0, !partial);
-        if (rc == FOLD_GIANT) {
-            if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, keys, alt, nullptr, nullptr, n, top_fc, 0))) return rc;
-            rc = fold_coo<K>(im, im->ws1, alt, n, kl, 0, true);
+        // whole 8-bit digits from the top: the (row, cell) bits plus whatever UMI bits the last digit reaches for free.  A run
+        // that is still too long for the fold's lead-in window (FOLD_GIANT: one gene holding a large share of a cell's reads)
+        // is split further - one more digit per attempt, remembered for the next finish() of this handle.
+        auto begin_for = [&](int extra) { const int passes = (top_fc - kl.ubits + 7) / 8 + extra; return std::max(0, top_fc - 8 * passes); };
+        int begin = partial ? begin_for(im->fold_extra_digits) : 0;
+        K* src = alt; K* dst = keys;
+        if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, src, dst, nullptr, nullptr, n, top_fc, begin))) return rc;
+        const size_t ws_mark = im->ws1.off;                              // a discarded attempt gives its workspace back
+        rc = fold_coo<K>(im, im->ws1, dst, n, kl, 0, begin);
+        while (rc == FOLD_GIANT) {
+            im->ws1.off = ws_mark;
+            im->fold_extra_digits++;
+            begin = begin_for(im->fold_extra_digits);
+            std::swap(src, dst);                                          // any order of the same keys is a valid sort input
+            if ((rc = sort_run<K, rocprim::empty_type>(im, tmp, tmpb, src, dst, nullptr, nullptr, n, top_fc, begin))) return rc;
+            rc = fold_coo<K>(im, im->ws1, dst, n, kl, 0, begin);      // begin == 0: fully sorted, classic fold, cannot be giant
         }
         if (rc) return rc;
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
