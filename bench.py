@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--serial", action="store_true", help="no overlap between the basefc and pileup engines")
     ap.add_argument("--depth", type=int, default=2, help="basefc engines used in rotation: the copy-out of pass i drains while pass i+1 computes (1 = overlap with the pileup pass only)")
+    ap.add_argument("--contig-subset", default="", help="N=1 only: draw the reads from these contig indices only (comma separated), i.e. the shard one rank of a larger run would own")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -76,7 +77,7 @@ def main():
     # contiguous contig ranges per rank: rank-order concatenation of the blocks is already (row, col) order
     shard = linear_partition(soa.HG38_LENGTHS, world)[rank]
     arrays, batches = soa_torch.gen_reads_device(regions, names, args.reads, args.cells, seed=100 + rank,
-                                                device=device, contig_subset=shard if world > 1 else None)
+                                                device=device, contig_subset=shard if world > 1 else ([int(x) for x in args.contig_subset.split(",")] if args.contig_subset else None))
     torch.cuda.synchronize()
     n_reads = arrays["n_reads"]
     data_checksum = [int(arrays["pos"].to(torch.int64).sum().item()), int((arrays["umi"] & 0xFFFFFF).sum().item()),
