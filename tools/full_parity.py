@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Engine vs oracle on the full bench workload (default 50 M reads): bit-exact COO comparison."""
+"""Engine vs oracle on a full bench-shaped workload (default 50 M reads): bit-exact comparison of EVERY non-zero.
+usage: full_parity.py [reads] [modes 1,2] [cells] [snps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -10,9 +11,10 @@ from xcltk_amd.engine import Engine
 from xcltk_amd.synth import soa, soa_torch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
-cells = 5000
+cells = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
+n_snps = int(sys.argv[4]) if len(sys.argv) > 4 else 100000
 dev = torch.device("cuda", 0)
-regions, snps, names = soa.make_tables(33472, 100000, soa.HG38_LENGTHS, seed=2)
+regions, snps, names = soa.make_tables(33472, n_snps, soa.HG38_LENGTHS, seed=2)
 arrays, batches = soa_torch.gen_reads_device(regions, names, n, cells, seed=100, device=dev)
 print("data checksum", int(arrays["pos"].to(torch.int64).sum().item()), int((arrays["umi"] & 0xFFFFFF).sum().item()), int(arrays["cell"].to(torch.int64).sum().item()), flush=True)
 filt = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
