@@ -139,6 +139,7 @@ __host__ __device__ inline int ctl_ncursor(int shard) { return CTL_SHARD0 + shar
 __host__ __device__ inline int ctl_accepted(int shard) { return CTL_SHARD0 + (NSHARD + shard) * CTL_STRIDE; }
 
 struct ReadInfo { int32_t pos, endpos, n_al; uint32_t c0, c1; int32_t cell; uint64_t umi; bool ok;
+                  bool span_is_cigar;        // endpos - pos is the CIGAR's reference length (false: unmapped flag / no CIGAR: 1)
                   int32_t m_rej, m_acc; };   // fraction mode: m < m_rej fails, m >= m_acc passes, between: divide
 
 // `m / float(n) < min_include` (rdr/fc/core.py:160-165) is an IEEE double comparison of a ROUNDED quotient.  The
@@ -259,7 +260,7 @@ __device__ __forceinline__ RawRead fetch_read(const BatchDesc& d, int i) {
 // filter + CIGAR summary of a read (endpos = htslib bam_endpos, n_al = len(read.positions))
 template <class K, int MODE>
 __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const RawRead& w) {
-    ReadInfo r; r.ok = false; r.pos = 0; r.endpos = 0; r.n_al = 0; r.c0 = r.c1 = 0; r.cell = -1; r.umi = 0; r.m_rej = 0; r.m_acc = 0;
+    ReadInfo r; r.ok = false; r.span_is_cigar = false; r.pos = 0; r.endpos = 0; r.n_al = 0; r.c0 = r.c1 = 0; r.cell = -1; r.umi = 0; r.m_rej = 0; r.m_acc = 0;
     if (!w.valid) return r;
     uint32_t flag = w.flag;
     int32_t mapq = w.mapq;
@@ -279,8 +280,10 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchD
         if (op_ref(op)) rlen += l;
         if (op_aligned(op)) n_al += l;
     }
-    if ((flag & BAM_FUNMAP) || r.c1 == r.c0) rlen = 1;
-    if (rlen == 0) rlen = 1;
+    // htslib bam_endpos(): an unmapped-flagged read, or one without reference-consuming CIGAR, spans one base for fetch();
+    // read.positions (the include test) still follows the CIGAR
+    r.span_is_cigar = !((flag & BAM_FUNMAP) || r.c1 == r.c0 || rlen == 0);
+    if (!r.span_is_cigar) rlen = 1;
     r.endpos = r.pos + rlen;
     r.n_al = n_al;
     r.ok = n_al >= a.f.min_len;
@@ -290,9 +293,11 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchD
 // __get_include_len(): aligned bases with s0 <= p < e0
 template <class K, int MODE>
 __device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const ReadInfo& r, int32_t s0, int32_t e0) {
-    if ((XCK_EXP & 4) || (r.pos >= s0 && r.endpos <= e0)) return r.n_al;
+    // both shortcuts need endpos to be the CIGAR's own end (an unmapped-flagged read with a CIGAR is fetched by its first base
+    // only, yet its aligned positions are counted over the whole CIGAR)
+    if ((XCK_EXP & 4) || (r.span_is_cigar && r.pos >= s0 && r.endpos <= e0)) return r.n_al;
     // no D / N in the CIGAR (reference span == aligned length): the aligned bases are one block, no walk needed
-    if (r.endpos - r.pos == r.n_al) return max(min(r.endpos, e0) - max(r.pos, s0), 0);
+    if (r.span_is_cigar && r.endpos - r.pos == r.n_al) return max(min(r.endpos, e0) - max(r.pos, s0), 0);
     int32_t p = r.pos, m = 0;
     for (uint32_t c = r.c0; c < r.c1; c++) {
         uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
