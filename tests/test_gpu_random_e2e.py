@@ -20,7 +20,10 @@ def _cmp_dirs(a, b):
         assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
 
 
-@pytest.mark.parametrize("seed", list(range(1, 9)))
+_SEEDS = list(range(1, 9)) if not os.environ.get("XCK_E2E_SEEDS") else list(range(1, 1 + int(os.environ["XCK_E2E_SEEDS"])))   # bigger one-off sweeps
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_10x_dataset_and_options(seed, tmp_path):
     from xcltk_amd.baf.fc.main import afc_wrapper
     from xcltk_amd.rdr.fc.main import fc_wrapper
