@@ -34,6 +34,14 @@ def make_case(seed):
         snps = snps[:60000]
     n_cells = int(rng.choice([1, 3, 40, 700]))
     n_umis = int(rng.choice([5, 200, 50000]))
+    # key codes as the host decoder would produce them: 2-bit coded UMIs of one length, and (for some cases) interned ids,
+    # which carry the top bit of the UMI field - those keys cannot be squeezed and take the classic sort / fold
+    from xcltk_amd.engine import Engine
+    probe = Engine(capi.XCK_MODE_BAF, names, regions, n_cells, snps=snps, decode_only=True)
+    umi_bits = probe.umi_bits
+    probe.close()
+    umi_len = int(rng.choice([4, 12, min(16, (umi_bits - 2) // 2)]))
+    interned_frac = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
     n_reads = int(rng.choice([300, 5000, 40000]))
     gap_max = int(rng.choice([100, 3000, 30000]))
     L = int(rng.choice([30, 91, 150]))
@@ -61,7 +69,12 @@ def make_case(seed):
         flag = int(rng.choice([0, 16, 256, 1024, 4, 1, 3, 2048], p=[.55, .25, .04, .04, .03, .03, .03, .03]))
         mapq = int(rng.choice([255, 60, 20, 19, 0], p=[.5, .3, .08, .06, .06]))
         cell = int(rng.integers(-1, n_cells))
-        umi = np.uint64(capi.XCK_UMI_NONE) if rng.random() < 0.03 else np.uint64((1 << 24) | int(rng.integers(0, n_umis)))
+        if rng.random() < 0.03:
+            umi = np.uint64(capi.XCK_UMI_NONE)
+        elif rng.random() < interned_frac:
+            umi = np.uint64((1 << (umi_bits - 1)) | int(rng.integers(0, n_umis)))
+        else:
+            umi = np.uint64((1 << (2 * umi_len)) | (int(rng.integers(0, n_umis)) % (1 << (2 * umi_len))))
         recs.append((ci, pos, cig, seq, flag, mapq, cell, umi))
     recs.sort(key=lambda r: (r[0], r[1]))
     batches, ordinal = [], 0

@@ -328,3 +328,25 @@ def test_basefc_long_runs_hash_fold_and_fallback(n, hot, n_umis, label):
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 40, batches)
     assert int(exp["count"][2].max()) > (30000 if label == "giant" else 1500)
     util.assert_coo_equal(got, exp, ["count"])
+
+
+def test_unmapped_flag_with_cigar_include_test():
+    """A read with the UNMAP flag but a CIGAR is fetched by its first base only (bam_endpos = pos + 1), while
+    read.positions - and with it the include fraction - follows the whole CIGAR (rdr/fc/core.py:32-43).  With
+    --exclFLAG 0 such reads reach the include test: 91M starting 30 bases before a region's end has m/n = 31/91."""
+    names = ["1"]
+    regions = [("1", 101, 150, "ends_at_150"), ("1", 101, 400, "covers_all"), ("1", 121, 121, "one_base")]
+    pos = np.array([119, 119, 119, 50, 140], np.int32)              # 0-based
+    flag = np.array([4, 0, 4 | 16, 4, 4], np.uint16)
+    n = len(pos)
+    d = dict(contig=0, ordinal_base=0, pos=pos, flag=flag, mapq=np.full(n, 60, np.uint8), cell=np.zeros(n, np.int32),
+             umi=((1 << 24) | np.arange(n)).astype(np.uint64), cig_off=np.arange(n + 1, dtype=np.uint32), cigar=np.full(n, (91 << 4) | 0, np.uint32))
+    batches = [util.batch_from_dict(d)]
+    for inc in (0.5, 0.9, 0.3, 0, 31, 32):
+        got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, batches, excl_flag=0, min_include=inc)
+        util.assert_coo_equal(got, exp, ["count"])
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, batches, excl_flag=0, min_include=0.5)
+    assert exp["count"][0].tolist() == [1] and exp["count"][2].tolist() == [4]   # 31/91 fails 0.5 in region 0 for mapped and unmapped alike; region 1 holds 4 whole reads
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, batches, excl_flag=0, min_include=0.3)
+    assert exp["count"][0].tolist() == [0, 1] and exp["count"][2].tolist() == [3, 4]
+    util.assert_coo_equal(got, exp, ["count"])
