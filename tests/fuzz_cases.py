@@ -8,7 +8,7 @@ from xcltk_amd import capi
 M, I, D, N, S, H, P, EQ, X = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
-def make_case(seed):
+def make_case(seed, odd_regions=True, many_cells=True, long=True, neg_pos=True):
     rng = np.random.default_rng(seed)
     n_contigs = int(rng.integers(1, 4))
     names = [str(i + 1) for i in range(n_contigs)]
@@ -21,6 +21,8 @@ def make_case(seed):
         regions.append((c, s, min(span, s + int(rng.integers(1, ln + 1))), "g%d" % g))
     if rng.random() < 0.3:
         regions.append(regions[0][:3] + ("dup",))                       # identical interval twice
+    if (rng.random() < 0.2) and odd_regions:
+        regions += [(names[0], 0, 500, "starts_at_0"), (names[0], 900, 100, "inverted"), (names[-1], span - 3, span + 5000, "past_the_end")]
     snp_step = int(rng.choice([3, 11, 37, 200, 3000]))
     snps = []
     for c in names:
@@ -32,7 +34,9 @@ def make_case(seed):
                     snps.append((c, p, "ACGT"[a], "ACGT"[r], 1 - h, h))  # duplicate position
     if len(snps) > 60000:
         snps = snps[:60000]
-    n_cells = int(rng.choice([1, 3, 40, 700]))
+    n_cells = int(rng.choice([1, 3, 40, 700, 70000], p=[.24, .24, .24, .24, .04]))
+    if not many_cells and n_cells > 700:
+        n_cells = 700
     n_umis = int(rng.choice([5, 200, 50000]))
     # key codes as the host decoder would produce them: 2-bit coded UMIs of one length, and (for some cases) interned ids,
     # which carry the top bit of the UMI field - those keys cannot be squeezed and take the classic sort / fold
@@ -45,6 +49,7 @@ def make_case(seed):
     n_reads = int(rng.choice([300, 5000, 40000]))
     gap_max = int(rng.choice([100, 3000, 30000]))
     L = int(rng.choice([30, 91, 150]))
+    long_reads = (rng.random() < 0.15) and long                                    # hundreds of CIGAR ops per read: beyond the per-tile LDS staging
     recs = []
     for _ in range(n_reads):
         ci = int(rng.integers(0, n_contigs))
@@ -59,6 +64,13 @@ def make_case(seed):
         elif k == 9: cig = [(H, 5), (M, a), (N, int(rng.integers(1, gap_max))), (M, 5), (N, int(rng.integers(1, gap_max))), (M, L), (S, 2)]
         elif k == 10: cig = [(S, L)] if rng.random() < 0.3 else [(M, 1)]
         else: cig = []                                                   # no CIGAR at all
+        if long_reads and rng.random() < 0.5:
+            cig = []
+            for _ in range(int(rng.integers(20, 300))):
+                cig.append((int(rng.choice([M, M, M, EQ, X])), int(rng.integers(1, 40))))
+                cig.append((int(rng.choice([I, D, N, S if not cig else I])), int(rng.integers(1, 30))))
+        if (rng.random() < 0.01) and neg_pos:
+            pos = -1
         cig = [(op, l) for op, l in cig if l > 0]
         qlen = sum(l for op, l in cig if op in (M, I, S, EQ, X))
         noseq = rng.random() < 0.05 or not cig

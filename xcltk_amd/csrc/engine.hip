@@ -272,7 +272,7 @@ __device__ __forceinline__ ReadInfo load_read(const JoinArgs<K>& a, const BatchD
     ok = ok && !(a.f.excl_flag && (flag & a.f.excl_flag));
     ok = ok && !(a.f.incl_flag && !(flag & a.f.incl_flag));
     ok = ok && !(a.f.no_orphan && (flag & BAM_FPAIRED) && !(flag & BAM_FPROPER_PAIR));
-    ok = ok && r.cell >= 0 && r.umi != XCK_UMI_NONE && r.pos >= 0;
+    ok = ok && r.cell >= 0 && r.umi != XCK_UMI_NONE;                  // (a negative pos is kept: fetch() only asks pos < stop && endpos > start)
     if (!ok) return r;
     int32_t rlen = 0, n_al = 0;
     for (uint32_t c = r.c0; c < r.c1; c++) {
@@ -457,7 +457,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r) {
     uint32_t n_acc = 0;
-    int32_t w_lo = r.pos >> WS;
+    int32_t w_lo = max(r.pos, 0) >> WS;                               // a record may start before the contig (pos -1 with a CIGAR)
     if (w_lo >= d.n_win) return 0;
     int32_t w_hi = min((r.endpos - 1) >> WS, d.n_win - 1);
     for (int32_t w = w_lo; w <= w_hi; w++) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             // wave waiting for its longest read.  So: every read only COUNTS its SNPs, the counts are scanned, and the
             // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
             int32_t k_lo = 0; uint32_t c = 0, n_gap = 0;
-            const int32_t w_lo = r.pos >> WSS;
+            const int32_t w_lo = max(r.pos, 0) >> WSS;
             if (r.ok && w_lo < d.n_swin && !(XCK_EXP & 32)) {
                 const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
                 k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
