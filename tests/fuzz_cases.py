@@ -49,7 +49,9 @@ def make_case(seed, odd_regions=True, many_cells=True, long=True, neg_pos=True):
     n_reads = int(rng.choice([300, 5000, 40000]))
     gap_max = int(rng.choice([100, 3000, 30000]))
     L = int(rng.choice([30, 91, 150]))
-    long_reads = (rng.random() < 0.15) and long                                    # hundreds of CIGAR ops per read: beyond the per-tile LDS staging
+    long_reads = (rng.random() < 0.15) and long
+    if long_reads:
+        n_reads = min(n_reads, 3000)                                    # the oracle walks every CIGAR per region / SNP                                    # hundreds of CIGAR ops per read: beyond the per-tile LDS staging
     recs = []
     for _ in range(n_reads):
         ci = int(rng.integers(0, n_contigs))
