@@ -355,3 +355,31 @@ def test_fraction_bounds():
             assert np.array_equal(fast[ok], exact[ok])
             # and the bounds alone are never wrong where they decide
             assert np.all(exact[ok & (m < m_rej)]) and not np.any(exact[ok & (m >= m_acc)])
+
+
+def test_write_mtx_threads_give_identical_files(tmp_path, monkeypatch):
+    """xck_write_mtx formats 1 M-entry chunks on several threads: same bytes as the single-threaded path, header counts
+    only the rows that survive row_map (merge_mtx format, rdr/fc/utils.py:54-93)."""
+    import ctypes as C
+    lib = capi.load()
+    rng = np.random.default_rng(4)
+    n = 2_300_000                                              # three chunks, the last one partial
+    row = np.sort(rng.integers(0, 5000, n)).astype(np.int32); col = rng.integers(0, 300, n).astype(np.int32)
+    val = rng.integers(1, 100000, n).astype(np.int32)
+    coo = capi.Coo(); coo.nnz = n
+    coo.row = row.ctypes.data_as(C.POINTER(C.c_int32)); coo.col = col.ctypes.data_as(C.POINTER(C.c_int32)); coo.val = val.ctypes.data_as(C.POINTER(C.c_int32))
+    rm = np.zeros(5000, np.int32); keep = rng.random(5000) < 0.8; rm[keep] = np.arange(1, int(keep.sum()) + 1)
+    outs = []
+    for nt in ("1", "5"):
+        monkeypatch.setenv("XCK_WRITE_THREADS", nt)
+        fn = str(tmp_path / ("m%s.mtx" % nt))
+        assert lib.xck_write_mtx(fn.encode(), C.byref(coo), rm.ctypes.data_as(C.POINTER(C.c_int32)), int(rm.max()), 300) == 0
+        outs.append(open(fn, "rb").read())
+    assert outs[0] == outs[1]
+    lines = outs[0].split(b"\n")
+    assert lines[0] == b"%%MatrixMarket matrix coordinate integer general" and lines[1] == b"%%"
+    kept = rm[row] > 0
+    assert lines[2] == b"%d\t300\t%d" % (int(rm.max()), int(kept.sum()))
+    i = int(np.flatnonzero(kept)[0])
+    assert lines[3] == b"%d\t%d\t%d" % (rm[row[i]], col[i] + 1, val[i])
+    assert len(lines) == 3 + int(kept.sum()) + 1 and lines[-1] == b""
