@@ -67,7 +67,7 @@ def test_decode_only_handle_refuses_compute(lib):
 
 
 def _decode_compare(ds, mode, n_threads, env_chunk=None, cell_tag="CB", umi_tag="UB", force128=False):
-    ddir = os.path.join(util.GOLDEN, "datasets", ds)
+    ddir = ds if os.path.isabs(ds) else os.path.join(util.GOLDEN, "datasets", ds)
     regions, snps = util.load_tables(ddir)
     names = O.contig_table(regions, snps)
     import json
@@ -383,3 +383,78 @@ def test_write_mtx_threads_give_identical_files(tmp_path, monkeypatch):
     i = int(np.flatnonzero(kept)[0])
     assert lines[3] == b"%d\t%d\t%d" % (rm[row[i]], col[i] + 1, val[i])
     assert len(lines) == 3 + int(kept.sum()) + 1 and lines[-1] == b""
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XCK_DECODER_FUZZ_SEEDS", "12"))))
+def test_decoder_fuzz_random_bam_layouts(seed, tmp_path):
+    """Random BAMs from the Python writer against the independent reader: records packed across BGZF blocks or not, random
+    compression levels, aux tags of every scalar type before / between / after CB and UB (first occurrence wins), numeric
+    and IUPAC UMIs, barcodes outside the list, empty and very long read names, records without sequence or CIGAR, long
+    CIGARs - decoded with random thread counts and chunk sizes, 10x keys or read-name keys."""
+    import json
+    from xcltk_amd.synth.bamwriter import BamWriter
+    rng = np.random.default_rng(500 + seed)
+    d = tmp_path / ("fz%d" % seed); d.mkdir()
+    refs = [("chr1", 300000), ("2", 200000), ("chrM", 16000)][:int(rng.integers(1, 4))]
+    bcs = sorted({"".join("ACGT"[i] for i in rng.integers(0, 4, 10)) + "-1" for _ in range(int(rng.integers(1, 40)))})
+    well = seed % 3 == 2
+    n_bams = int(rng.integers(1, 4)) if well else int(rng.integers(1, 3))
+    bams = []
+    for bi in range(n_bams):
+        fn = "b%d.bam" % bi
+        w = BamWriter(str(d / fn), refs, align_records=bool(rng.integers(0, 2)), level=int(rng.choice([0, 1, 6, 9])))
+        recs = []
+        for _ in range(int(rng.integers(50, 3000))):
+            tid = int(rng.integers(0, len(refs))); pos = int(rng.integers(0, refs[tid][1] - 200))
+            k = rng.integers(0, 8)
+            L = int(rng.integers(20, 151))
+            if k < 4: cig = "%dM" % L
+            elif k == 4: cig = "%dM%dN%dM" % (L // 2, int(rng.integers(1, 5000)), L - L // 2)
+            elif k == 5: cig = "3S%dM2I%dM1D%dM" % (10, L - 20, 5)
+            elif k == 6: cig = "".join("%dM1I" % int(rng.integers(1, 4)) for _ in range(int(rng.integers(30, 200)))); L = None
+            else: cig = ""
+            if L is None:
+                from xcltk_amd.synth.bamwriter import parse_cigar
+                L = sum(l for op, l in parse_cigar(cig) if op in (0, 1, 4, 7, 8))
+            elif k == 5:
+                L = 3 + 10 + 2 + (L - 20) + 5
+            seq = "" if (rng.random() < 0.05 or not cig) else "".join("ACGTNRY"[i] for i in rng.choice(7, L, p=[.24, .24, .24, .24, .02, .01, .01]))
+            tags = []
+            def junk():
+                t = rng.integers(0, 7)
+                name = "X%s" % "abcdefg"[t]
+                return [(name, int(rng.integers(-100, 100)), "c"), (name, int(rng.integers(0, 60000)), "S"), (name, int(rng.integers(-2**31, 2**31)), "i"),
+                        (name, 1.5, "f"), (name, "q", "A"), (name, "some text", "Z"), (name, int(rng.integers(0, 200)), "C")][t]
+            for _j in range(int(rng.integers(0, 3))): tags.append(junk())
+            if not well:
+                r = rng.random()
+                if r < 0.85: tags.append(("CB", bcs[int(rng.integers(0, len(bcs)))]))
+                elif r < 0.92: tags.append(("CB", "TTTTTTTTTT-9"))
+                if rng.random() < 0.1: tags.append(("CB", bcs[0]))              # second occurrence: ignored
+                for _j in range(int(rng.integers(0, 2))): tags.append(junk())
+                r = rng.random()
+                if r < 0.8: tags.append(("UB", "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.choice([8, 12, 30])))))),
+                elif r < 0.86: tags.append(("UB", "ACGTNACGTN"))
+                elif r < 0.9: tags.append(("UB", int(rng.integers(0, 50)), "i"))
+                elif r < 0.93: tags.append(("UB", ""))
+            for _j in range(int(rng.integers(0, 2))): tags.append(junk())
+            qname = ["", "r%d" % int(rng.integers(0, 400)), "a_very_long_read_name_" * 9 + str(int(rng.integers(0, 50)))][int(rng.choice(3, p=[.02, .9, .08]))]
+            flag = int(rng.choice([0, 16, 99, 147, 4, 256, 1024, 2048]))
+            recs.append((tid, pos, qname, flag, int(rng.choice([0, 3, 20, 60, 255])), cig, seq, tuple(t for t in tags if not isinstance(t, tuple) or len(t) in (2, 3))))
+        recs.sort(key=lambda r: (r[0], r[1]))
+        for r in recs:
+            w.write(r[0], r[1], r[2], r[3], r[4], r[5], r[6], tags=[t[0] if isinstance(t[0], tuple) else t for t in r[7]])
+        w.close()
+        bams.append(fn)
+    (d / "regions.tsv").write_text("chr1\t100\t5000\tg1\n2\t1\t90000\tg2\nM\t1\t16000\tg3\n")
+    (d / "snps.tsv").write_text("chrom\tpos\tref\talt\tref_hap\talt_hap\nchr1\t150\tA\tC\t0\t1\n2\t500\tG\tT\t1\t0\n")
+    info = dict(bams=bams)
+    if well:
+        info["sample_ids"] = ["s%d" % i for i in range(n_bams)]
+    else:
+        info["barcodes"] = "barcodes.tsv"
+        (d / "barcodes.tsv").write_text("".join(b + "\n" for b in bcs))
+    (d / "dataset.json").write_text(json.dumps(info))
+    n = _decode_compare(str(d), int(rng.choice([1, 2])), n_threads=int(rng.integers(1, 7)), env_chunk=int(rng.choice([0, 3000, 20000])) or None,
+                        force128=bool(rng.random() < 0.2))
+    assert n > 0
