@@ -421,10 +421,12 @@ def test_decoder_fuzz_random_bam_layouts(seed, tmp_path):
             seq = "" if (rng.random() < 0.05 or not cig) else "".join("ACGTNRY"[i] for i in rng.choice(7, L, p=[.24, .24, .24, .24, .02, .01, .01]))
             tags = []
             def junk():
-                t = rng.integers(0, 7)
+                t = int(rng.integers(0, 7))
                 name = "X%s" % "abcdefg"[t]
                 return [(name, int(rng.integers(-100, 100)), "c"), (name, int(rng.integers(0, 60000)), "S"), (name, int(rng.integers(-2**31, 2**31)), "i"),
-                        (name, 1.5, "f"), (name, "q", "A"), (name, "some text", "Z"), (name, int(rng.integers(0, 200)), "C")][t]
+                        (name, 1.5, "f"), (name, "q", "A"), (name, "some text", "Z"), (name, int(rng.integers(0, 200)), "C"),
+                        ("YB", ("S", [int(x) for x in rng.integers(0, 60000, int(rng.integers(0, 9)))]), "B"), ("YH", "1AE301", "H"),
+                        ("YF", ("f", [0.5, 2.0]), "B")][int(rng.integers(0, 10))]
             for _j in range(int(rng.integers(0, 3))): tags.append(junk())
             if not well:
                 r = rng.random()

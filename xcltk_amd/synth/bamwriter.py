@@ -73,6 +73,12 @@ def pack_tag(tag, value, typ=None):
         return t + b"Z" + value.encode("ascii") + b"\0"
     if typ == "A":
         return t + b"A" + value.encode("ascii")[:1]
+    if typ == "H":
+        return t + b"H" + value.encode("ascii") + b"\0"
+    if typ == "B":                                            # value = (subtype, [numbers])
+        sub, arr = value
+        f = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+        return t + b"B" + sub.encode("ascii") + struct.pack("<I", len(arr)) + struct.pack("<%d%s" % (len(arr), f), *arr)
     fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}[typ]
     return t + typ.encode("ascii") + struct.pack(fmt, value)
 
