@@ -26,7 +26,7 @@ _SEEDS = list(range(1, 9)) if not os.environ.get("XCK_E2E_SEEDS") else list(rang
 @pytest.mark.parametrize("seed", _SEEDS)
 def test_random_10x_dataset_and_options(seed, tmp_path):
     from xcltk_amd.baf.fc.main import afc_wrapper
-    from xcltk_amd.rdr.fc.main import fc_wrapper
+    from xcltk_amd.rdr.fc.main import fc_main, fc_wrapper
     rng = np.random.default_rng(1000 + seed)
     n_contigs = int(rng.integers(1, 4))
     contigs = tuple(("chr%d" % (i + 1), int(rng.integers(150000, 600000))) for i in range(n_contigs))
@@ -35,7 +35,8 @@ def test_random_10x_dataset_and_options(seed, tmp_path):
                          n_snps=int(rng.integers(50, 600)), n_genes=int(rng.integers(5, 60)), contigs=contigs, seed=seed,
                          bam_contig_prefix=[None, "", "chr"][int(rng.integers(0, 3))], align_records=bool(rng.integers(0, 2)),
                          n_bams=n_bams, paired=bool(rng.integers(0, 2)), umi_len=int(rng.integers(6, 15)),
-                         frac_cb_outside=float(rng.uniform(0, 0.1)), iupac_frac=float(rng.uniform(0, 0.03)))
+                         frac_cb_outside=float(rng.uniform(0, 0.1)), iupac_frac=float(rng.uniform(0, 0.03)),
+                         odd_frac=float(rng.choice([0, 0.05, 0.2])))          # unmapped flag with a CIGAR, CIGAR-less reads
     sam = ",".join(d["bams"])
     umi_tag = ["UB", "UB", "None"][int(rng.integers(0, 3))]
     common = dict(min_mapq=int(rng.choice([0, 2, 20, 30])), min_len=int(rng.choice([0, 30, 60, 91])),
@@ -44,10 +45,20 @@ def test_random_10x_dataset_and_options(seed, tmp_path):
     all_reg = bool(rng.integers(0, 2))
     # ---- basefc
     out = str(tmp_path / "fc"); ref = str(tmp_path / "fc_ref")
-    assert fc_wrapper(sam, d["barcodes"], d["regions"], out, umi_tag=umi_tag, output_all_reg=all_reg,
-                      min_include=min_include, ncores=int(rng.integers(1, 5)), **common) == 0
+    fc_excl = [None, 0, 256][int(rng.integers(0, 3))]
+    ncores = int(rng.integers(1, 5))
+    if fc_excl is None:
+        assert fc_wrapper(sam, d["barcodes"], d["regions"], out, umi_tag=umi_tag, output_all_reg=all_reg,
+                          min_include=min_include, ncores=ncores, **common) == 0
+    else:
+        # like the reference's (rdr/fc/main.py:177-178), fc_wrapper() ignores a non-None excl_flag: only the command line sets it
+        all_reg = True
+        argv = ["xcltk", "basefc", "-s", sam, "-b", d["barcodes"], "-R", d["regions"], "-O", out, "-p", str(ncores), "--UMItag", umi_tag,
+                "--inclFLAG", str(common["incl_flag"]), "--exclFLAG", str(fc_excl), "--minLEN", str(common["min_len"]),
+                "--minMAPQ", str(common["min_mapq"]), "--minINCLUDE", repr(min_include)] + ([] if common["no_orphan"] else ["--countORPHAN"])
+        assert fc_main(argv) == 0
     O.run_files(capi.XCK_MODE_BASEFC, d["bams"], d["regions"], out_dir=ref, barcode_fn=d["barcodes"], umi_tag=umi_tag,
-                output_all_reg=all_reg, min_include=min_include, **common)
+                output_all_reg=all_reg, min_include=min_include, excl_flag=fc_excl, **common)
     _cmp_dirs(out, ref)
     # ---- baf
     excl = [None, 0, 1024, 772][int(rng.integers(0, 4))]

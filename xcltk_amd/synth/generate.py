@@ -137,8 +137,11 @@ def make_10x_dataset(out_dir, n_reads=10000, n_barcodes=1000, n_snps=500, n_gene
                      bam_contig_prefix=None, align_records=True, n_bams=1,
                      frac_missing_cb=0.03, frac_missing_ub=0.03, frac_cb_outside=0.02,
                      iupac_frac=0.002, paired=False, level=6, with_index=True,
-                     lowercase_none=False):
+                     lowercase_none=False, odd_frac=0.0):
     """Droplet-style dataset. Returns dict with paths and the python-side tables.
+
+    odd_frac > 0 marks that share of the reads as oddities a fetch still returns: the unmapped
+    flag on a read that has a CIGAR, a read without a CIGAR, or both (no rng draws when 0).
 
     n_bams > 1 splits molecules across BAMs that share the barcode list
     (multi-BAM barcode mode of the reference, rdr/fc/core.py:153).
@@ -218,6 +221,12 @@ def make_10x_dataset(out_dir, n_reads=10000, n_barcodes=1000, n_snps=500, n_gene
                 flag |= 1024
             if paired:
                 flag |= 1 | (2 if rng.random() < 0.9 else 0) | (64 if rng.random() < 0.5 else 128)
+            if odd_frac > 0 and rng.random() < odd_frac:
+                odd = int(rng.integers(0, 3))
+                if odd != 1:
+                    flag |= 4
+                if odd != 0:
+                    cig_s = "*"
             tags = [("NH", 1, "C")]
             if cb is not None:
                 tags.append(("CB", cb))
@@ -245,7 +254,7 @@ def make_10x_dataset(out_dir, n_reads=10000, n_barcodes=1000, n_snps=500, n_gene
     paths["bams"] = bam_paths
     paths["bam"] = bam_paths[0]
     paths.update(dict(contigs=contigs, genes=genes, snps=snps, barcode_list=barcodes,
-                      n_reads=len(reads)))
+                      n_reads=len(reads), odd_frac=odd_frac))
     return paths
 
 
