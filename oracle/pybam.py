@@ -26,6 +26,7 @@ pinned here by the SAM spec and by round-tripping the real BAM that ships in
 the reference tree (see tests/test_oracle_pybam.py, container-only part).
 """
 
+import bisect
 import gzip
 import struct
 
@@ -36,6 +37,7 @@ _CONSUMES_REF = (True, False, True, True, False, False, False, True, True, False
 _ALIGNED = (True, False, False, False, False, False, False, True, True, False)
 
 BAM_FUNMAP = 4
+_NT16_PAIR = [SEQ_NT16[b >> 4] + SEQ_NT16[b & 0xF] for b in range(256)]
 
 
 class Record(object):
@@ -185,11 +187,7 @@ def read_bam(path):
         nb = (l_seq + 1) // 2
         r.seq_nibbles = d[p:p + nb]
         if l_seq:
-            s = []
-            for i in range(l_seq):
-                b = d[p + (i >> 1)]
-                s.append(SEQ_NT16[(b >> 4) if (i & 1) == 0 else (b & 0xF)])
-            r.query_sequence = "".join(s)
+            r.query_sequence = "".join([_NT16_PAIR[b] for b in r.seq_nibbles])[:l_seq]
         else:
             r.query_sequence = None
         p += nb + l_seq              # skip qualities
@@ -218,8 +216,20 @@ class AlignmentFile(object):
             by_tid = {}
             for r in recs:
                 by_tid.setdefault(r.tid, []).append(r)
-            AlignmentFile._cache[key] = (refs, recs, by_tid)
-        self.refs, self.records, self.by_tid = AlignmentFile._cache[key]
+            # what the .bai gives htslib: per contig the start positions (coordinate-sorted file) and the running
+            # maximum of endpos, so that fetch() can bisect to the first record that can still overlap the window
+            index = {}
+            for tid, rs in by_tid.items():
+                pos = [r.pos for r in rs]
+                if any(pos[i] > pos[i + 1] for i in range(len(pos) - 1)):
+                    continue                                   # not sorted: fetch() scans
+                run, top = [], -1 << 62
+                for r in rs:
+                    top = max(top, r.endpos)
+                    run.append(top)
+                index[tid] = (pos, run)
+            AlignmentFile._cache[key] = (refs, recs, by_tid, index)
+        self.refs, self.records, self.by_tid, self._index = AlignmentFile._cache[key]
         self.references = tuple(n for n, _ in self.refs)
         self.lengths = tuple(l for _, l in self.refs)
         self._tid = {n: i for i, n in enumerate(self.references)}
@@ -244,6 +254,9 @@ class AlignmentFile(object):
         if not 0 <= rstop <= max_pos:
             raise ValueError("stop out of range (%i)" % rstop)
         recs = self.by_tid.get(tid, [])
+        if tid in self._index:
+            pos, run = self._index[tid]
+            recs = recs[bisect.bisect_right(run, rstart):bisect.bisect_left(pos, rstop)]
         return iter([r for r in recs if r.pos < rstop and r.endpos > rstart])
 
     def close(self):

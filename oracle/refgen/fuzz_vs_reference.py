@@ -75,6 +75,11 @@ def one(seed, work):
                          frac_cb_outside=float(rng.uniform(0, 0.1)), iupac_frac=float(rng.uniform(0, 0.03)),
                          odd_frac=float(rng.choice([0, 0.05, 0.2])))
     d_odd = d["odd_frac"]
+    if rng.integers(0, 4) == 0:                                 # fixed-size bins as features (utils/gregion.py)
+        from xcltk_amd.utils import gregion as G
+        bins = G.get_fixsize_reg_from_input_len(dict(contigs), int(rng.choice([1, 5, 20, 100])))
+        d["regions"] = work + "/ds/bins.tsv"
+        G.output_feature_table(bins, d["regions"])
     sam = ",".join(d["bams"])
     umi_tag = ["UB", "UB", "None"][int(rng.integers(0, 3))]
     common = dict(min_mapq=int(rng.choice([0, 2, 20, 30])), min_len=int(rng.choice([0, 30, 60, 91])),

@@ -17,8 +17,9 @@ sys.dont_write_bytecode = True (the tree is read-only) and only its *outputs* ar
 as fixtures under tests/golden/.
 
 usage: run_reference.py <job.json>
-  job = {"kind": "basefc"|"baf", "out_dir": ..., "kwargs": {...}}   (kwargs of fc_wrapper /
-  afc_wrapper, xcltk/rdr/fc/main.py:142 and xcltk/baf/fc/main.py:32)
+  job = {"kind": "basefc"|"baf"|"convert", "out_dir": ..., "kwargs": {...}}   (kwargs of fc_wrapper /
+  afc_wrapper, xcltk/rdr/fc/main.py:142 and xcltk/baf/fc/main.py:32); optional "argv" (basefc command line
+  instead of kwargs) and "prewarm" (BAMs parsed before the timed call)
 """
 import json
 import os
@@ -50,7 +51,15 @@ def main():
     install_standins()
     sys.path.insert(0, REF)
     import logging
+    import time
     logging.disable(logging.CRITICAL)
+    # "prewarm": BAMs to parse into the stand-in's cache before the timed call; the reference's forked workers then
+    # open them for free, like pysam opening an indexed file (used by time_reference.py only)
+    t_load = time.time()
+    for fn in job.get("prewarm", ()):
+        sys.modules["pysam"].AlignmentFile(fn, "r")
+    t_load = time.time() - t_load
+    t_run = time.time()
     if job["kind"] == "basefc":
         from xcltk.rdr.fc.main import fc_wrapper
         # NOTE reference quirk (rdr/fc/main.py:177-178): a non-None excl_flag is never
@@ -64,12 +73,17 @@ def main():
     elif job["kind"] == "baf":
         from xcltk.baf.fc.main import afc_wrapper
         ret = afc_wrapper(**job["kwargs"])
+    elif job["kind"] == "convert":
+        # xcltk/tools/convert.py:15 - returns None, exits non-zero on errors
+        from xcltk.tools.convert import convert_main
+        convert_main(["xcltk", "convert"] + job["argv"])
+        ret = 0
     elif job["kind"] == "fet1":
         # direct per-region call used for the known-answer tests of SURVEY 8c
         raise SystemExit("fet1 jobs are handled by kat.py")
     else:
         raise SystemExit("unknown job kind")
-    sys.stdout.write(json.dumps({"ret": ret}) + "\n")
+    sys.stdout.write(json.dumps({"ret": ret, "standin_load_s": t_load, "elapsed_s": time.time() - t_run}) + "\n")
     return 0 if ret == 0 else 1
 
 

@@ -87,3 +87,27 @@ def test_random_well_mode(seed, tmp_path):
     O.run_files(capi.XCK_MODE_BAF, d["bams"], d["regions"], out_dir=str(tmp_path / "r2"), snp_fn=d["snps_tsv"], **common)
     _cmp_dirs(os.path.join(out, "basefc"), str(tmp_path / "r1"))
     _cmp_dirs(os.path.join(out, "baf"), str(tmp_path / "r2"))
+
+
+@pytest.mark.parametrize("bin_kb,min_include", [(1, 0.9), (10, 0.5), (50, 0), (500, 30)])
+def test_fixed_size_bins_as_features(bin_kb, min_include, tmp_path):
+    """Features = fixed-size bins over the BAM header's contigs (utils/gregion.py): adjacent, non-overlapping
+    regions, the last one reaching past the end of its contig; reads straddling a bin boundary fail the include test in
+    both bins unless min_include is small."""
+    from xcltk_amd.baf.fc.main import afc_wrapper
+    from xcltk_amd.rdr.fc.main import fc_wrapper
+    from xcltk_amd.utils import gregion as G
+    d = make_10x_dataset(str(tmp_path / "ds"), n_reads=6000, n_barcodes=40, n_snps=400, n_genes=30,
+                         contigs=(("chr1", 400000), ("chr2", 250000)), seed=90 + bin_kb, bam_contig_prefix="chr")
+    bins = G.get_fixsize_reg_from_sam_header(["1", "chr2"], bin_kb, d["bam"])          # "1" resolves to chr1
+    assert bins[0].chrom == "chr1" and bins[-1].end >= 250000
+    feat = str(tmp_path / "bins.tsv")
+    G.output_feature_table(bins, feat)
+    out, ref = str(tmp_path / "fc"), str(tmp_path / "fc_ref")
+    assert fc_wrapper(d["bam"], d["barcodes"], feat, out, min_include=min_include, ncores=2) == 0
+    O.run_files(capi.XCK_MODE_BASEFC, d["bams"], feat, out_dir=ref, barcode_fn=d["barcodes"], min_include=min_include)
+    _cmp_dirs(out, ref)
+    out, ref = str(tmp_path / "baf"), str(tmp_path / "baf_ref")
+    assert afc_wrapper(d["bam"], d["barcodes"], feat, d["snps_tsv"], out, ncores=2, output_all_reg=bool(bin_kb & 1)) == 0
+    O.run_files(capi.XCK_MODE_BAF, d["bams"], feat, out_dir=ref, barcode_fn=d["barcodes"], snp_fn=d["snps_tsv"], output_all_reg=bool(bin_kb & 1))
+    _cmp_dirs(out, ref)

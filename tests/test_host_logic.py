@@ -460,3 +460,60 @@ def test_decoder_fuzz_random_bam_layouts(seed, tmp_path):
     n = _decode_compare(str(d), int(rng.choice([1, 2])), n_threads=int(rng.integers(1, 7)), env_chunk=int(rng.choice([0, 3000, 20000])) or None,
                         force128=bool(rng.random() < 0.2))
     assert n > 0
+
+
+# ---------------------------------------------------------------- xcltk convert: bins as features
+_CONVERT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convert")
+
+
+def _convert_cases():
+    import json
+    with open(os.path.join(_CONVERT, "cases.json")) as fp:
+        return [(c["name"], c["argv"]) for c in json.load(fp)["cases"]]
+
+
+@pytest.mark.parametrize("name,argv", _convert_cases())
+def test_convert_matches_reference_outputs(name, argv, tmp_path):
+    """Fixtures = outputs of the reference's `xcltk convert` (oracle/refgen/make_convert_goldens.py)."""
+    from xcltk_amd.xcltk import main
+    out = str(tmp_path / name)
+    av = [a.replace("$BED", os.path.join(_CONVERT, "in.bed")).replace("$TSV", os.path.join(_CONVERT, "in.tsv")) for a in argv]
+    main(["xcltk", "convert"] + av + ["-o", out])
+    assert open(out, "rb").read() == open(os.path.join(_CONVERT, name), "rb").read()
+
+
+def test_convert_errors_and_feature_tables(tmp_path, capsys):
+    from xcltk_amd.tools.convert import convert_main
+    from xcltk_amd.utils import gregion as G
+    for av in (["-B", "0"], ["-B", "50", "-H", "37"], ["-i", str(tmp_path / "missing.bed"), "-I", "bed"], ["-B", "50", "-O", "gff"],
+               ["-i", os.path.join(_CONVERT, "in.bed"), "-I", "vcf"]):
+        with pytest.raises(SystemExit) as e:
+            convert_main(["xcltk", "convert"] + av)
+        assert e.value.code == 1
+    bad = tmp_path / "nonl.tsv"
+    bad.write_text("1\t1\t1000\nMT\t7\t9")                      # no final newline: the reference eats the "9" and fails, so do we
+    with pytest.raises(SystemExit) as e:
+        convert_main(["xcltk", "convert", "-i", str(bad), "-I", "tsv"])
+    assert e.value.code == 1
+    capsys.readouterr()
+    # stdout when no -o
+    convert_main(["xcltk", "convert", "-B", "100000", "-H", "19"])
+    txt = capsys.readouterr().out.split("\n")
+    assert txt[0] == "1\t1\t100000000" and txt[2] == "1\t200000001\t300000000"      # last bin not clipped to 249,250,621
+    assert G.chr2reg("1", 0, 10) is None and G.chr2reg("1", "x", 10) is None and G.get_fixsize_regions(50, "hg38") is None
+    assert [(r.start, r.end) for r in G.chr2reg("c", 25, 10)] == [(1, 10), (11, 20), (21, 30)]
+    assert len(G.chr2reg("c", 30, 10)) == 3
+    # bins over the contigs of a BAM header, with the chr prefix retried either way; four-column feature table loads back
+    case, _, _, _ = util.load_case("c1_basefc_default", str(tmp_path))
+    bam = case["kwargs"]["sam_fn"]
+    refs = capi.bam_references(bam)
+    name0, len0 = refs[0]
+    other = name0[3:] if name0.startswith("chr") else "chr" + name0
+    bins = G.get_fixsize_reg_from_sam_header([other], 100, bam)
+    assert bins[0].chrom == name0 and len(bins) == -(-len0 // 100000) and bins[-1].end >= len0
+    assert G.get_fixsize_reg_from_sam_header(["nope"], 100, bam) is None
+    fn = str(tmp_path / "bins.tsv")
+    G.output_feature_table(bins, fn)
+    from xcltk_amd.fc_common import load_region_from_txt
+    regs = load_region_from_txt(fn)
+    assert len(regs) == len(bins) and regs[0][3] == bins[0].id and regs[1][1] == bins[1].start

@@ -182,6 +182,20 @@ def load(path=None):
     return lib
 
 
+def bam_references(path):
+    """[(name, length)] of a BAM header, read by the engine's own decoder (xck_bam_open; no device needed)."""
+    lib = load()
+    b = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.xck_bam_open(path.encode(), 1, C.byref(b), err, 512)
+    if rc != 0:
+        raise XckLibraryError("xck_bam_open failed (%d): %s" % (rc, err.value.decode()))
+    try:
+        return [(lib.xck_bam_ref_name(b, i).decode(), int(lib.xck_bam_ref_len(b, i))) for i in range(lib.xck_bam_n_refs(b))]
+    finally:
+        lib.xck_bam_close(b)
+
+
 def np_ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 

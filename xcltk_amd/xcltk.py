@@ -1,6 +1,6 @@
 """Command-line dispatcher, same shape as the reference's (xcltk/xcltk.py:16-53) for the two
-commands on the accelerated hot path.  `fixref` and `convert` are VCF / annotation utilities
-outside that path and are not provided."""
+commands on the accelerated hot path, plus `convert` (fixed-size bins as features).  `fixref` is a
+VCF utility outside that path and is not provided."""
 
 import sys
 
@@ -20,6 +20,9 @@ def _usage(fp=sys.stdout):
              "\n"
              "  -- RDR calculation\n"
              "     basefc           Basic feature counting (GPU).\n"
+             "\n"
+             "  -- Tools\n"
+             "     convert          Convert between different formats of genomic features (fixed-size bins).\n"
              "\n"
              "  -- Others\n"
              "     -h, --help       Print this message and exit.\n"
@@ -45,7 +48,10 @@ def main(argv=None):
     if command in ("-V", "--version"):
         sys.stderr.write("%s\n" % VERSION)
         sys.exit(0)
-    if command in ("fixref", "convert"):
+    if command == "convert":
+        from .tools.convert import convert_main
+        return convert_main(argv)
+    if command in ("fixref",):
         sys.stderr.write("Error: command '%s' is outside the accelerated hot path and not provided by %s\n" % (command, ENGINE))
         sys.exit(1)
     sys.stderr.write("Error: wrong command '%s'\n" % command)
