@@ -43,7 +43,28 @@ template <class Cfg> static void run(const char* name, uint64_t* src, uint64_t* 
     hipFree(tmp); hipFree(bad);
 }
 
+template <class Cfg, class V> static void runp(const char* name, uint64_t* src, uint64_t* a, uint64_t* b, V* va, V* vb, size_t n, int top) {
+    size_t tb = 0;
+    rocprim::radix_sort_pairs<Cfg>(nullptr, tb, a, b, va, vb, n, 0u, (unsigned)top, (hipStream_t)0);
+    void* tmp; hipMalloc(&tmp, tb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {
+        hipMemcpy(a, src, n * 8, hipMemcpyDeviceToDevice);
+        hipEventRecord(e0, 0);
+        hipError_t er = rocprim::radix_sort_pairs<Cfg>(tmp, tb, a, b, va, vb, n, 0u, (unsigned)top, (hipStream_t)0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        if (er != hipSuccess) { printf("%s: error %d\n", name, (int)er); return; }
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    printf("%-28s pairs(%zu B values) n=%zu bits [0,%d): %.3f ms\n", name, sizeof(V), n, top, best); fflush(stdout);
+    hipFree(tmp);
+}
 using namespace rocprim;
+template <unsigned HB, unsigned HI, unsigned SB, unsigned SI>
+using pcfg = radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<HB, HI>, kernel_config<SB, SI>, 8, block_radix_rank_algorithm::match>>;
+template <unsigned HB, unsigned HI>
+using hcfg = radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<HB, HI>, kernel_config<1024, 8>, 8, block_radix_rank_algorithm::match>>;
 template <unsigned BS, unsigned IPT, unsigned BITS, block_radix_rank_algorithm A = block_radix_rank_algorithm::match>
 using cfg = radix_sort_config<default_config, default_config, radix_sort_onesweep_config<kernel_config<BS, IPT>, kernel_config<BS, IPT>, BITS, A>>;
 
@@ -53,13 +74,18 @@ int main(int argc, char** argv) {
     uint64_t *src, *a, *b; hipMalloc(&src, n * 8); hipMalloc(&a, n * 8); hipMalloc(&b, n * 8);
     fill<<<(unsigned)((n + 255) / 256), 256>>>(src, n, begin);
     hipDeviceSynchronize();
-    run<default_config>("default", src, a, b, n, begin, begin + 32);
-    run<cfg<1024, 8, 8>>("1024x8 8b", src, a, b, n, begin, begin + 32);
-    run<cfg<1024, 6, 8>>("1024x6 8b", src, a, b, n, begin, begin + 32);
-    run<cfg<1024, 10, 8>>("1024x10 8b", src, a, b, n, begin, begin + 32);
-    run<cfg<1024, 12, 8>>("1024x12 8b", src, a, b, n, begin, begin + 32);
-    run<cfg<1024, 16, 8>>("1024x16 8b", src, a, b, n, begin, begin + 32);
-    run<cfg<768, 10, 8>>("768x10 8b", src, a, b, n, begin, begin + 32);
-    run<cfg<512, 20, 8>>("512x20 8b", src, a, b, n, begin, begin + 32);
+    {
+        size_t m = 72000000; uint64_t* v; hipMalloc(&v, 2 * m * 8);
+        runp<default_config, uint64_t>("default", src, a, b, v, v + m, m, 56);
+        runp<pcfg<512, 32, 1024, 8>, uint64_t>("hist 512x32 sort 1024x8", src, a, b, v, v + m, m, 56);
+        runp<pcfg<512, 32, 512, 12>, uint64_t>("hist 512x32 sort 512x12", src, a, b, v, v + m, m, 56);
+        runp<pcfg<512, 32, 512, 16>, uint64_t>("hist 512x32 sort 512x16", src, a, b, v, v + m, m, 56);
+        runp<pcfg<512, 32, 1024, 6>, uint64_t>("hist 512x32 sort 1024x6", src, a, b, v, v + m, m, 56);
+        size_t m2 = 25000000; uint8_t* w = (uint8_t*)v;
+        runp<default_config, uint8_t>("default", src, a, b, w, w + m2, m2, 56);
+        runp<pcfg<512, 32, 1024, 8>, uint8_t>("hist 512x32 sort 1024x8", src, a, b, w, w + m2, m2, 56);
+        runp<pcfg<512, 32, 512, 16>, uint8_t>("hist 512x32 sort 512x16", src, a, b, w, w + m2, m2, 56);
+        runp<pcfg<512, 32, 512, 12>, uint8_t>("hist 512x32 sort 512x12", src, a, b, w, w + m2, m2, 56);
+    }
     return 0;
 }

@@ -1711,13 +1711,22 @@ struct Timer {
 // One radix sort over key bits [0, top).  (rocPRIM's mid-size merge path is not stable, so the classic
 // "sort the low range, then the high range" trick to skip the all-zero bits between the used UMI bits and
 // the cell field is NOT safe with it - measured on gfx950, tools/scratch/sorttest.hip.)
-// Keys-only sort of 64-bit keys: 1024 threads x 8 keys per block instead of rocPRIM 4.2's tuned default for gfx950
-// (512 x 12): 6.75 ms instead of 7.49 ms for 300 M keys over 32 bits (tools/scratch/sortcfg.hip; 10-bit digits, which
-// would need one pass fewer, are slower: 5.3 ms vs 4.5 ms at 200 M keys).  Everything else keeps the defaults.
+// Keys-only sort of 64-bit keys: sort kernel at 1024 threads x 8 keys and histogram kernel at 512 x 32 instead of rocPRIM
+// 4.2's tuned default for gfx950 (512 x 12 for both): 7.90 ms instead of 9.42 ms for 380 M keys over 32 bits
+// (tools/scratch/sortcfg.hip, profiles/r01_g_sort_configs.log; 10-bit digits, which would need one pass fewer, are
+// slower: 5.3 ms vs 4.5 ms at 200 M keys).  Everything else keeps the defaults.
 template <class K>
 using KeySortConfig = typename std::conditional<sizeof(K) == 8,
     rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                               rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8,
+                               rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 32>, rocprim::kernel_config<1024, 8>, 8,
+                                                                   rocprim::block_radix_rank_algorithm::match>>,
+    rocprim::default_config>::type;
+// pairs with 64-bit keys: 1024 x 6 with 8-byte values (4.29 ms vs 4.56 ms for 72 M pairs over 56 bits), 1024 x 8 with 1-byte values
+// (1.31 ms vs 1.45 ms for 25 M pairs)
+template <class K, class V>
+using PairSortConfig = typename std::conditional<sizeof(K) == 8 && (sizeof(V) == 8 || sizeof(V) == 1),
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                               rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 32>, rocprim::kernel_config<1024, sizeof(V) == 8 ? 6 : 8>, 8,
                                                                    rocprim::block_radix_rank_algorithm::match>>,
     rocprim::default_config>::type;
 
@@ -1725,14 +1734,14 @@ template <class K, class V>
 static size_t sort_tmp_bytes(size_t n, int top) {
     size_t tb = 0; K* k = nullptr; V* v = nullptr;
     if constexpr (std::is_same<V, rocprim::empty_type>::value) (void)rocprim::radix_sort_keys<KeySortConfig<K>>(nullptr, tb, k, k, n, 0u, (unsigned)top, (hipStream_t)0);
-    else (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, n, 0u, (unsigned)top, (hipStream_t)0);
+    else (void)rocprim::radix_sort_pairs<PairSortConfig<K, V>>(nullptr, tb, k, k, v, v, n, 0u, (unsigned)top, (hipStream_t)0);
     return tb + 256;
 }
 template <class K, class V>
 static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout, V* vin, V* vout, size_t n, int top, int begin = 0) {
     hipError_t er;
     if constexpr (std::is_same<V, rocprim::empty_type>::value) er = rocprim::radix_sort_keys<KeySortConfig<K>>(tmp, tmp_bytes, kin, kout, n, (unsigned)begin, (unsigned)top, im->s_comp);
-    else er = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, (unsigned)top, im->s_comp);
+    else er = rocprim::radix_sort_pairs<PairSortConfig<K, V>>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, (unsigned)top, im->s_comp);
     HIP_TRY(er);
     return 0;
 }
