@@ -517,3 +517,32 @@ def test_convert_errors_and_feature_tables(tmp_path, capsys):
     from xcltk_amd.fc_common import load_region_from_txt
     regs = load_region_from_txt(fn)
     assert len(regs) == len(bins) and regs[0][3] == bins[0].id and regs[1][1] == bins[1].start
+
+
+# ---------------------------------------------------------------- untrusted input: the decoder under ASAN + UBSan (host-only build)
+def test_decoder_survives_corrupt_bams_under_sanitizers(tmp_path):
+    """tools/asan: csrc/bam.cpp + csrc/api.cpp built by g++ with -fsanitize=address,undefined (device side stubbed), run
+    over BAMs whose record stream, compressed bytes, length or index were damaged: an error code or a decode, never a
+    bad access (a sanitizer report aborts the harness).  Larger campaigns: tools/asan/mutate_bams.py with more seeds."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asan = os.path.join(root, "tools", "asan")
+    r = subprocess.run(["make", "-C", asan], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 and "sanitize" in r.stdout:
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert r.returncode == 0, r.stdout[-2000:]
+    gold = os.path.join(root, "tests", "golden", "datasets")
+    src = [os.path.join(gold, "special", f) for f in sorted(os.listdir(os.path.join(gold, "special"))) if f.endswith(".bam")][0]
+    multi = [os.path.join(gold, "multibam", f) for f in sorted(os.listdir(os.path.join(gold, "multibam"))) if f.endswith(".bam")][0]
+    mut = os.path.join(asan, "mutate_bams.py")
+    subprocess.check_call([sys.executable, mut, src, str(tmp_path / "a"), "160", "5"])
+    subprocess.check_call([sys.executable, mut, multi, str(tmp_path / "i"), "40", "6", "--bai"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")          # the reader parks its buffers in a process-wide pool on purpose
+    for sub, extra in (("a", {}), ("i", {"XCK_ASAN_INDEX": "1"})):
+        files = sorted(str(p) for p in (tmp_path / sub).glob("*.bam"))
+        r = subprocess.run([os.path.join(asan, "decoder_asan")] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=dict(env, **extra), timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        m = re.search(r"(\d+) files: (\d+) clean decodes, (\d+) rejected", r.stdout)
+        assert m and int(m.group(1)) == len(files) and int(m.group(2)) + int(m.group(3)) == 4 * len(files)
+        if sub == "a":
+            assert int(m.group(3)) > len(files)                      # most damage is detected and reported as an error

@@ -1,0 +1,71 @@
+// Host-only AddressSanitizer / UBSan harness for the BAM decoder (csrc/bam.cpp + csrc/api.cpp): the device side is
+// stubbed out, the handle is a decode-only one.  Every file given on the command line is opened and decoded to the
+// end in both modes (with and without sequences); corrupt input has to end in an error code, never in a bad access.
+//   make -C tools/asan && tools/asan/decoder_asan FILE.bam...
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/xck.h"
+#include "../../xcltk_amd/csrc/xck_internal.h"
+
+namespace xck {   // what engine.hip provides; never reached through a decode-only handle
+int  engine_create(const xck_config*, xck_engine*) { return XCK_E_ARG; }
+void engine_destroy(xck_engine*) {}
+int  engine_push(xck_engine*, const xck_batch*, bool) { return XCK_E_ARG; }
+int  engine_flush(xck_engine*) { return XCK_E_ARG; }
+int  engine_finish(xck_engine*, xck_result*) { return XCK_E_ARG; }
+int  engine_finish_async(xck_engine*) { return XCK_E_ARG; }
+int  engine_result_device(xck_engine*, xck_result*) { return XCK_E_ARG; }
+int  engine_reset(xck_engine*) { return XCK_E_ARG; }
+int  engine_stats(const xck_engine*, xck_stats*) { return XCK_E_ARG; }
+int  engine_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }
+void* pinned_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }       // plain heap: ASAN sees every overrun
+void  pinned_free(void* p) { free(p); }
+}
+
+int main(int argc, char** argv) {
+    std::vector<std::string> bcs;
+    for (int i = 0; i < 64; i++) { char b[32]; snprintf(b, sizeof b, "ACGTACGTACGT%04d-1", i); bcs.push_back(b); }
+    std::vector<const char*> bp; for (auto& s : bcs) bp.push_back(s.c_str());
+    long ok = 0, bad = 0, recs = 0;
+    for (int a = 1; a < argc; a++) {
+        for (int mode : {XCK_MODE_BASEFC, XCK_MODE_BAF}) {
+            for (int threads : {1, 3}) {
+                xck_config cfg; memset(&cfg, 0, sizeof cfg);
+                cfg.struct_size = sizeof cfg; cfg.mode = mode; cfg.n_cells = (int)bp.size(); cfg.barcodes = bp.data();
+                cfg.cell_tag[0] = 'C'; cfg.cell_tag[1] = 'B'; cfg.umi_tag[0] = 'U'; cfg.umi_tag[1] = 'B';
+                cfg.flags = XCK_F_DECODE_ONLY | (threads == 3 ? XCK_F_VERIFY_CRC : 0); cfg.n_threads = threads; cfg.max_batch_reads = 777;
+                cfg.n_snps = mode == XCK_MODE_BAF ? 0 : 0;
+                xck_engine* e = nullptr;
+                if (xck_create(&cfg, &e) != XCK_OK) { fprintf(stderr, "create failed: %s\n", xck_last_error(nullptr)); return 2; }
+                xck_bam* b = nullptr; char err[256] = {0};
+                int rc = xck_bam_open(argv[a], threads, &b, err, sizeof err);
+                if (rc == 0) {
+                    const int nref = xck_bam_n_refs(b);
+                    std::vector<int32_t> t2c(nref > 0 ? nref : 1);
+                    for (int t = 0; t < nref; t++) t2c[t] = t;
+                    xck_ingest_opts o; memset(&o, 0, sizeof o); o.struct_size = sizeof o; o.sample = -1; o.tid_to_contig = t2c.data();
+                    o.use_index = getenv("XCK_ASAN_INDEX") ? 1 : 0;          // PATH.bai is untrusted input as well
+                    if (o.use_index) for (int t = 1; t < nref; t += 2) t2c[t] = -1;
+                    xck_batch bt;
+                    while ((rc = xck_bam_next_batch(e, b, &o, &bt)) > 0) {
+                        recs += bt.n_reads;
+                        // touch everything the batch claims to own
+                        unsigned long long s = 0;
+                        for (int64_t i = 0; i < bt.n_reads; i++) s += (unsigned)bt.pos[i] + bt.flag[i] + bt.mapq[i] + (unsigned)bt.cell[i] + bt.umi[i] + bt.cig_off[i];
+                        if (bt.n_reads) { for (uint32_t c = bt.cig_off[0]; c < bt.cig_off[bt.n_reads]; c++) s += bt.cigar[c];
+                                          if (bt.seq) for (uint32_t q = bt.seq_off[0]; q < bt.seq_off[bt.n_reads]; q++) s += bt.seq[q]; }
+                        if (s == 0x123456789abcull) puts("");
+                    }
+                    xck_bam_close(b);
+                }
+                (rc == 0 ? ok : bad)++;
+                xck_destroy(e);
+            }
+        }
+    }
+    printf("%d files: %ld clean decodes, %ld rejected, %ld records seen\n", argc - 1, ok, bad, recs);
+    return 0;
+}
