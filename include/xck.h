@@ -175,10 +175,13 @@ void xck_destroy(xck_engine* e);
  *   anything else                                   ->  (1 << (bits-1)) | interned id            */
 int  xck_umi_bits(const xck_engine* e);
 /* Copy one batch to the GPU (async, overlapped with kernels of the previous batch) and run
- * the join / pileup kernels on it.  The batch arrays may be reused once the call returns. */
+ * the join / pileup kernels on it.  The batch arrays may be reused once the call returns.
+ * The host arrays are checked first (one linear pass): cig_off / seq_off must not run backwards,
+ * cell[i] < n_cells, contig < n_contigs, no null column - otherwise XCK_E_ARG and nothing is queued. */
 int  xck_push_batch(xck_engine* e, const xck_batch* b);
 /* Same, but the arrays are DEVICE pointers already resident in HBM (benchmarks, pipelines
- * that decode on the GPU side); no copy is made and they must stay valid until xck_flush(). */
+ * that decode on the GPU side); no copy is made and they must stay valid until xck_flush().
+ * The contents cannot be checked from the host: the same invariants are the caller's word. */
 int  xck_push_batch_device(xck_engine* e, const xck_batch* b);
 int  xck_flush(xck_engine* e);                    /* wait for all queued device work */
 /* Fold all hits into the final sparse matrices (radix sort + segmented reduce on the GPU) and copy

@@ -350,3 +350,39 @@ def test_unmapped_flag_with_cigar_include_test():
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, batches, excl_flag=0, min_include=0.3)
     assert exp["count"][0].tolist() == [0, 1] and exp["count"][2].tolist() == [3, 4]
     util.assert_coo_equal(got, exp, ["count"])
+
+
+def test_push_batch_rejects_inconsistent_host_arrays(small):
+    """xck_push_batch checks caller-supplied host arrays before a kernel sees them (api.cpp check_host_batch): offsets that run
+    backwards, a cell index outside the cell table, a contig outside the configured ones; the handle stays usable."""
+    from xcltk_amd.engine import Engine, XckError
+    regions, snps, names, _ = small
+    g = soa.gen_reads(regions, names, 20000, 200, seed=77, max_batch=70000)[0]
+    for mode in (capi.XCK_MODE_BASEFC, capi.XCK_MODE_BAF):
+        eng = Engine(mode, names, regions, 200, snps=snps if mode == capi.XCK_MODE_BAF else ())
+        try:
+            def broken(**kw):
+                d = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+                for k, f in kw.items():
+                    d[k] = f(d[k])
+                return util.batch_from_dict(d)
+
+            def swap(a):
+                a[100], a[101] = a[101] + 5, a[100]
+                return a
+
+            def big_cell(a):
+                a[7] = 200
+                return a
+            cases = [broken(cig_off=swap), broken(cell=big_cell), broken(contig=lambda c: len(names))]
+            if mode == capi.XCK_MODE_BAF:
+                cases.append(broken(seq_off=swap))
+            for b, _ in cases:
+                with pytest.raises(XckError):
+                    eng.push(b)
+            good, _ = util.batch_from_dict(g)
+            eng.push(good)
+            out = eng.finish()
+            assert sum(len(v[0]) for v in out.values()) > 0
+        finally:
+            eng.close()

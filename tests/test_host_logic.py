@@ -527,7 +527,7 @@ def test_decoder_survives_corrupt_bams_under_sanitizers(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     asan = os.path.join(root, "tools", "asan")
     r = subprocess.run(["make", "-C", asan], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0 and "sanitize" in r.stdout:
+    if r.returncode != 0 and ("cannot find -lasan" in r.stdout or "cannot find -lubsan" in r.stdout or "libasan" in r.stdout):
         pytest.skip("no sanitizer runtime for g++ here")
     assert r.returncode == 0, r.stdout[-2000:]
     gold = os.path.join(root, "tests", "golden", "datasets")

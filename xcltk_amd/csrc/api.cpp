@@ -36,6 +36,7 @@ int xck_create(const xck_config* cfg, xck_engine** out) {
     xck_engine* e = new xck_engine();
     e->umi_bits = key_layout(cfg).ubits;
     e->mode = cfg->mode;
+    e->n_cells = cfg->n_cells; e->n_contigs = cfg->n_contigs;
     if (!(cfg->flags & XCK_F_DECODE_ONLY)) {
         const int modes[2] = { cfg->mode == XCK_MODE_BOTH ? XCK_MODE_BASEFC : cfg->mode, XCK_MODE_BAF };
         const int n = cfg->mode == XCK_MODE_BOTH ? 2 : 1;
@@ -76,7 +77,29 @@ void xck_destroy(xck_engine* e) {
 }
 int xck_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }
 
-int xck_push_batch(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; FOR_IMPLS(e, engine_push(e, b, false)); return XCK_OK; }
+// Host arrays handed in through the ABI are checked before any kernel sees them: an offset table that runs backwards or a
+// column index outside the cell table would otherwise become an out-of-bounds access on the device or a row outside the
+// result.  One linear pass over three of the columns; device-resident batches (xck_push_batch_device) are the caller's word.
+static int check_host_batch(xck_engine* e, const xck_batch* b) {
+    if (b->n_reads < 0) { e->err = "batch: negative n_reads"; return XCK_E_ARG; }
+    if (b->contig < 0 || b->n_reads == 0) return XCK_OK;                       // skipped by the engine
+    if (b->contig >= e->n_contigs) { e->err = "batch: contig id outside the configured contigs"; return XCK_E_ARG; }
+    const bool seq = (e->mode & XCK_MODE_BAF) != 0;
+    if (!b->pos || !b->flag || !b->mapq || !b->cell || !b->umi || !b->cig_off || (!b->cigar && b->cig_off[b->n_reads] != b->cig_off[0]) ||
+        (seq && (!b->seq_off || (!b->seq && b->seq_off[b->n_reads] != b->seq_off[0])))) { e->err = "batch: null column"; return XCK_E_ARG; }
+    const int64_t n = b->n_reads;
+    uint32_t bad = 0;
+    for (int64_t i = 0; i < n; i++) bad |= (uint32_t)(b->cig_off[i + 1] < b->cig_off[i]) | (uint32_t)(b->cell[i] >= e->n_cells);
+    if (seq) for (int64_t i = 0; i < n; i++) bad |= (uint32_t)(b->seq_off[i + 1] < b->seq_off[i]);
+    if (bad) { e->err = "batch: offsets run backwards or a cell index is outside the cell table"; return XCK_E_ARG; }
+    return XCK_OK;
+}
+extern "C++" { namespace xck { int push_trusted(xck_engine* e, const xck_batch* b) { FOR_IMPLS(e, engine_push(e, b, false)); return XCK_OK; } } }
+int xck_push_batch(xck_engine* e, const xck_batch* b) {
+    if (!e || !b) return XCK_E_ARG;
+    if (int rc = check_host_batch(e, b)) return rc;
+    return push_trusted(e, b);
+}
 int xck_push_batch_device(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; FOR_IMPLS(e, engine_push(e, b, true)); return XCK_OK; }
 int xck_flush(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_flush(e)); return XCK_OK; }
 int xck_reset(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_reset(e)); return XCK_OK; }

@@ -754,7 +754,7 @@ int xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t*
     xck_batch bt;
     int rc;
     while ((rc = xck_bam_next_batch(e, b, o, &bt)) == 1) {
-        int prc = xck_push_batch(e, &bt);                     // fused handles feed both pipelines
+        int prc = xck::push_trusted(e, &bt);                  // fused handles feed both pipelines
         if (prc) return prc;
     }
     if (n_records) *n_records = b->n_records;

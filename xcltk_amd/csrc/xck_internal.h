@@ -82,6 +82,8 @@ inline KeyBits key_layout(const xck_config* cfg) {
     return k;
 }
 
+// the decoder's own batches are valid by construction and skip the O(n) check of xck_push_batch()
+int push_trusted(xck_engine* e, const xck_batch* b);
 void set_thread_error(const std::string& s);
 const char* get_thread_error();
 
@@ -97,6 +99,7 @@ struct xck_engine {
     int n_impl = 0;
     int mode = 0;
     int umi_bits = 64;
+    int32_t n_cells = 0, n_contigs = 0;  // bounds that caller-supplied batches are checked against (xck_push_batch)
     // host pinned batch staging used by xck_ingest_bam lives in the xck_bam
 };
 
