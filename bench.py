@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--cells", type=int, default=10000)
     ap.add_argument("--snps", type=int, default=1_000_000)
     ap.add_argument("--genes", type=int, default=33472)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = this process's cores, at most 16)")
     ap.add_argument("--serial", action="store_true", help="no overlap between the basefc and pileup engines")
     ap.add_argument("--depth", type=int, default=2, help="basefc engines used in rotation: the copy-out of pass i drains while pass i+1 computes (1 = overlap with the pileup pass only)")
     ap.add_argument("--contig-subset", default="", help="N=1 only: draw the reads from these contig indices only (comma separated), i.e. the shard one rank of a larger run would own")
@@ -239,7 +240,8 @@ def main():
                     stage_ms_per_step={a: round(b, 3) for a, b in k.items()},
                     host_ms_per_step={a: round(b / args.steps * 1e3, 3) for a, b in host.items()})
 
-    # ---- CPU baseline: the oracle (C restatement of the reference's per-region loops), 1 core ----
+    # ---- CPU baseline: the oracle (C restatement of the reference's per-region loops) on the host cores, region chunks per
+    # thread like the reference's worker pool (oracle/xck_oracle.c xo_run_mt) ----
     cpu = None
     if args.cpu_sample > 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -256,6 +258,11 @@ def main():
             take += per_contig[c]; tot += sum(e - s for _, s, e in per_contig[c])
         hb = [util.batch_from_dict(soa_torch.host_batch_dict(arrays, c, s, e, True)) for c, s, e in take]
         tc = 0.0
+        try:
+            n_cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n_cores = os.cpu_count() or 1
+        cpu_threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(n_cores, 16))
         sample_contigs = {names[c] for c, _, _ in take}
         row_in_sample = np.array([r[0] in sample_contigs for r in regions])
         parity = "ok"
@@ -263,7 +270,7 @@ def main():
         for mode, sn, mats in ((capi.XCK_MODE_BASEFC, [], ["count"]), (capi.XCK_MODE_BAF, snps, ["ad", "dp", "oth"])):
             cfg, keep = O.make_config(mode, names, regions, sn, args.cells)
             t1 = time.perf_counter()
-            exp = O.run_oracle(cfg, [b for b, _ in hb])
+            exp = O.run_oracle(cfg, [b for b, _ in hb], n_threads=cpu_threads)
             tc += time.perf_counter() - t1
             for m in mats:                              # the GPU result of the last timed step, restricted to those rows
                 g = res[m]
@@ -272,8 +279,8 @@ def main():
                 n_cmp += int(sel.sum())
                 if not ok:
                     parity = "MISMATCH in %s" % m
-        cpu = dict(value=round(tot / tc, 1), unit="reads/s", cores=1, kind="port",
-                   sample="the %d reads of contig(s) %s of the same workload, basefc + pileup, oracle/xck_oracle.c" % (tot, ",".join(sorted(sample_contigs))),
+        cpu = dict(value=round(tot / tc, 1), unit="reads/s", cores=cpu_threads, kind="port",
+                   sample="the %d reads of contig(s) %s of the same workload, basefc + pileup, oracle/xck_oracle.c (xo_run_mt: region chunks over %d threads)" % (tot, ",".join(sorted(sample_contigs)), cpu_threads),
                    seconds=round(tc, 2), gpu_rows_vs_oracle="%s (%d non-zeros compared bit for bit)" % (parity, n_cmp))
         if parity != "ok":
             sys.exit("bench.py: GPU result differs from the oracle on the sampled contigs: " + parity)

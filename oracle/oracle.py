@@ -53,7 +53,7 @@ _olib = None
 def build_oracle(force=False):
     src = os.path.join(_HERE, "xck_oracle.c")
     if force or not os.path.isfile(ORACLE_LIB) or os.path.getmtime(ORACLE_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", ORACLE_LIB, src, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", ORACLE_LIB, src, "-lm"])
     return ORACLE_LIB
 
 
@@ -65,6 +65,8 @@ def load_oracle():
         lib = C.CDLL(ORACLE_LIB)
         lib.xo_run.restype = C.c_int
         lib.xo_run.argtypes = [C.POINTER(capi.Config), C.POINTER(capi.Batch), C.c_int, C.POINTER(XoResult)]
+        lib.xo_run_mt.restype = C.c_int
+        lib.xo_run_mt.argtypes = [C.POINTER(capi.Config), C.POINTER(capi.Batch), C.c_int, C.POINTER(XoResult), C.c_int]
         lib.xo_free.restype = None
         lib.xo_free.argtypes = [C.POINTER(XoResult)]
         lib.xo_frac_drop.restype = C.c_int
@@ -76,12 +78,14 @@ def load_oracle():
 MATS = ("count", "ad", "dp", "oth")
 
 
-def run_oracle(cfg, batches):
-    """cfg: capi.Config, batches: list of capi.Batch. Returns {name: (row, col, val)}."""
+def run_oracle(cfg, batches, n_threads=1):
+    """cfg: capi.Config, batches: list of capi.Batch. Returns {name: (row, col, val)}.
+    n_threads > 1: region chunks on host threads (xo_run_mt), same output."""
     lib = load_oracle()
     arr = (capi.Batch * max(1, len(batches)))(*batches)
     res = XoResult()
-    rc = lib.xo_run(C.byref(cfg), arr, len(batches), C.byref(res))
+    rc = lib.xo_run_mt(C.byref(cfg), arr, len(batches), C.byref(res), int(n_threads)) if n_threads > 1 else \
+        lib.xo_run(C.byref(cfg), arr, len(batches), C.byref(res))
     if rc != 0:
         raise RuntimeError("oracle failed: %d" % rc)
     out = {}

@@ -212,10 +212,11 @@ static void build_index(const xck_config *cf, const xck_batch *bt, int nb, conti
 #define FETCH_END }}
 
 /* ---------------------------------------------------------------- basefc */
-static void run_basefc(const xck_config *cf, const xck_batch *bt, int nb, contig_idx *ci, xo_result *out) {
+static void run_basefc(const xck_config *cf, const xck_batch *bt, int nb, contig_idx *ci, xo_result *out, int g_lo, int g_hi) {
     int frac_mode = (cf->min_include > 0.0 && cf->min_include < 1.0);
     cu_t *set = NULL; int64_t cap = 0;
-    for (int g = 0; g < cf->n_regions; g++) {
+    (void)nb;
+    for (int g = g_lo; g < g_hi; g++) {
         const xck_region *rg = &cf->regions[g];
         if (rg->contig < 0 || rg->contig >= cf->n_contigs) continue;
         /* reg.start = start, reg.end = end_incl + 1 (rdr/fc/utils.py:42).
@@ -318,17 +319,11 @@ static int cmp_snp_idx(const void *a, const void *b) {
     return *(const int*)a < *(const int*)b ? -1 : 1;
 }
 
-static void run_baf(const xck_config *cf, const xck_batch *bt, int nb, contig_idx *ci, xo_result *out) {
+/* fc_fet1() over the regions [g_lo, g_hi) given every SNP's pileup (plp) and the SNPs ordered by (contig, pos) (sidx) */
+static void baf_regions(const xck_config *cf, const snp_plp *plp, const int *sidx, xo_result *out, int g_lo, int g_hi) {
     static const char NT16[] = "=ACMGRSVTWYHKDBN";
-    (void)nb;
-    snp_plp *plp = (snp_plp*)calloc(cf->n_snps ? cf->n_snps : 1, sizeof(snp_plp));
-    for (int s = 0; s < cf->n_snps; s++) pileup_snp(cf, bt, ci, &cf->snps[s], &plp[s]);
     cub_t *set = NULL; int64_t cap = 0;
-    int *sidx = (int*)malloc(sizeof(int) * (cf->n_snps + 1));
-    for (int s = 0; s < cf->n_snps; s++) sidx[s] = s;
-    g_snps = cf->snps;
-    qsort(sidx, cf->n_snps, sizeof(int), cmp_snp_idx);
-    for (int g = 0; g < cf->n_regions; g++) {
+    for (int g = g_lo; g < g_hi; g++) {
         const xck_region *rg = &cf->regions[g];
         int64_t n = 0;
         /* snp_set.fetch(reg.chrom, reg.start, reg.end): start <= pos <= end_incl (main.py:93);
@@ -380,20 +375,87 @@ static void run_baf(const xck_config *cf, const xck_batch *bt, int nb, contig_id
             if (oth > 0) coo_push(out, 3, g, cell, oth);
         }
     }
-    free(set); free(sidx);
+    free(set);
+}
+
+static int *sorted_snp_index(const xck_config *cf) {
+    int *sidx = (int*)malloc(sizeof(int) * (cf->n_snps + 1));
+    for (int s = 0; s < cf->n_snps; s++) sidx[s] = s;
+    g_snps = cf->snps;
+    qsort(sidx, cf->n_snps, sizeof(int), cmp_snp_idx);
+    return sidx;
+}
+
+static void run_baf(const xck_config *cf, const xck_batch *bt, int nb, contig_idx *ci, xo_result *out) {
+    (void)nb;
+    snp_plp *plp = (snp_plp*)calloc(cf->n_snps ? cf->n_snps : 1, sizeof(snp_plp));
+    for (int s = 0; s < cf->n_snps; s++) pileup_snp(cf, bt, ci, &cf->snps[s], &plp[s]);
+    int *sidx = sorted_snp_index(cf);
+    baf_regions(cf, plp, sidx, out, 0, cf->n_regions);
+    free(sidx);
     for (int s = 0; s < cf->n_snps; s++) free(plp[s].e);
     free(plp);
 }
 
 /* ---------------------------------------------------------------- entry points */
+void xo_free(xo_result *r);
 int xo_run(const xck_config *cf, const xck_batch *batches, int n_batches, xo_result *out) {
     memset(out, 0, sizeof(*out));
     contig_idx *ci = (contig_idx*)calloc(cf->n_contigs ? cf->n_contigs : 1, sizeof(contig_idx));
     build_index(cf, batches, n_batches, ci);
     for (int b = 0; b < n_batches; b++) out->n_reads += batches[b].n_reads;
-    if (cf->mode == XCK_MODE_BASEFC) run_basefc(cf, batches, n_batches, ci, out);
+    if (cf->mode == XCK_MODE_BASEFC) run_basefc(cf, batches, n_batches, ci, out, 0, cf->n_regions);
     else if (cf->mode == XCK_MODE_BAF) run_baf(cf, batches, n_batches, ci, out);
     else { free(ci); return -1; }
+    for (int c = 0; c < cf->n_contigs; c++) { free(ci[c].reads); free(ci[c].seg_beg); }
+    free(ci);
+    return 0;
+}
+
+/* The same work on n_threads host threads, split the way the reference splits it (fc_core / afc_core, rdr/fc/main.py:196-208):
+ * contiguous chunks of regions per worker, results concatenated in chunk order - here many small chunks handed out
+ * dynamically, because a few genes hold most reads.  The per-SNP pileups of the BAF path (independent of each other) run in
+ * parallel first.  Output is identical to xo_run() (tests/test_oracle_kat.py).  Used for bench.py's cpu_baseline. */
+int xo_run_mt(const xck_config *cf, const xck_batch *batches, int n_batches, xo_result *out, int n_threads) {
+    if (n_threads <= 1) return xo_run(cf, batches, n_batches, out);
+    if (cf->mode != XCK_MODE_BASEFC && cf->mode != XCK_MODE_BAF) return -1;
+    memset(out, 0, sizeof(*out));
+    contig_idx *ci = (contig_idx*)calloc(cf->n_contigs ? cf->n_contigs : 1, sizeof(contig_idx));
+    build_index(cf, batches, n_batches, ci);
+    for (int b = 0; b < n_batches; b++) out->n_reads += batches[b].n_reads;
+    const int G = cf->n_regions;
+    int n_chunk = n_threads * 16; if (n_chunk > G) n_chunk = G > 0 ? G : 1;
+    xo_result *part = (xo_result*)calloc(n_chunk, sizeof(xo_result));
+    snp_plp *plp = NULL; int *sidx = NULL;
+    if (cf->mode == XCK_MODE_BAF) {
+        plp = (snp_plp*)calloc(cf->n_snps ? cf->n_snps : 1, sizeof(snp_plp));
+        #pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads)
+        for (int s = 0; s < cf->n_snps; s++) pileup_snp(cf, batches, ci, &cf->snps[s], &plp[s]);
+        sidx = sorted_snp_index(cf);
+    }
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int c = 0; c < n_chunk; c++) {
+        const int g_lo = (int)((int64_t)G * c / n_chunk), g_hi = (int)((int64_t)G * (c + 1) / n_chunk);
+        if (cf->mode == XCK_MODE_BASEFC) run_basefc(cf, batches, n_batches, ci, &part[c], g_lo, g_hi);
+        else baf_regions(cf, plp, sidx, &part[c], g_lo, g_hi);
+    }
+    for (int m = 0; m < 4; m++) {
+        int64_t tot = 0;
+        for (int c = 0; c < n_chunk; c++) tot += part[c].nnz[m];
+        out->nnz[m] = out->cap[m] = tot;
+        if (!tot) continue;
+        out->row[m] = (int32_t*)malloc(sizeof(int32_t) * tot); out->col[m] = (int32_t*)malloc(sizeof(int32_t) * tot); out->val[m] = (int32_t*)malloc(sizeof(int32_t) * tot);
+        int64_t at = 0;
+        for (int c = 0; c < n_chunk; c++) {
+            const int64_t k = part[c].nnz[m];
+            if (k) { memcpy(out->row[m] + at, part[c].row[m], sizeof(int32_t) * k); memcpy(out->col[m] + at, part[c].col[m], sizeof(int32_t) * k);
+                     memcpy(out->val[m] + at, part[c].val[m], sizeof(int32_t) * k); at += k; }
+        }
+    }
+    for (int c = 0; c < n_chunk; c++) xo_free(&part[c]);
+    free(part);
+    if (plp) { for (int s = 0; s < cf->n_snps; s++) free(plp[s].e); free(plp); }
+    free(sidx);
     for (int c = 0; c < cf->n_contigs; c++) { free(ci[c].reads); free(ci[c].seg_beg); }
     free(ci);
     return 0;

@@ -70,3 +70,19 @@ def test_kat_rdr_1(tmp_path, oracle_lib, min_include, exp):
                           min_include=min_include)
         got.append(int(coo["count"][2].sum()))
     assert got == exp
+
+
+@pytest.mark.parametrize("threads", [2, 5])
+def test_threaded_oracle_gives_the_same_matrices(oracle_lib, threads):
+    """xo_run_mt (region chunks on host threads, the CPU baseline of bench.py) == xo_run, entry for entry."""
+    import util
+    from xcltk_amd.synth import soa
+    regions, snps, names = soa.make_tables(300, 5000, soa.HG38_LENGTHS[:3], seed=5, max_len=150000)
+    batches = [util.batch_from_dict(b) for b in soa.gen_reads(regions, names, 120000, 150, seed=6, max_batch=50000)]
+    for mode, sn in ((capi.XCK_MODE_BASEFC, []), (capi.XCK_MODE_BAF, snps)):
+        cfg, keep = O.make_config(mode, names, regions, sn, 150, min_count=2 if sn else 1)
+        one = O.run_oracle(cfg, [b for b, _ in batches])
+        many = O.run_oracle(cfg, [b for b, _ in batches], n_threads=threads)
+        assert sum(len(v[0]) for v in one.values()) > 1000
+        for k in one:
+            assert all(np.array_equal(x, y) for x, y in zip(one[k], many[k])), k
