@@ -244,7 +244,9 @@ class AlignmentFile(object):
         tid = self.get_tid(contig)
         if tid < 0:
             raise ValueError("invalid contig `%s`" % contig)
-        max_pos = (1 << 29) - 1      # pysam parse_region() limit for BAI
+        # pysam parse_region() rejects coordinates beyond MAX_POS: (1 << 31) - 1 in current pysam (libchtslib.pyx), smaller in
+        # some 0.15.x builds (BAI's 2^29); version dependent and beyond any real contig - the oracle and the engine accept int32
+        max_pos = (1 << 31) - 1
         rstart = 0 if start is None else int(start)
         rstop = max_pos if stop is None else int(stop)
         if rstart > rstop:
