@@ -227,8 +227,8 @@ def main():
         n_launch = max(1, int(sbaf["n_join_launches"]))
     avg_ms = dom[1] / n_launch
     achieved = (dom[2] / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    if os.path.isfile(args.pmc_json):
+    traffic = None                                       # PMC bytes were collected at the default workload only (profiles/pmc_traffic.json)
+    if os.path.isfile(args.pmc_json) and (args.reads, args.cells, args.snps) == (500_000_000, 10000, 1_000_000) and not args.contig_subset:
         try:
             traffic = json.load(open(args.pmc_json)).get(dom[0])
         except Exception:
