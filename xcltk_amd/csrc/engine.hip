@@ -173,6 +173,12 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double
 #ifndef XCK_STAMPS
 #define XCK_STAMPS 0
 #endif
+// which of the 16 cursor shards a join block appends to: block index modulo 16 (XCK_SHARD_SHIFT 0), or runs of 2^shift
+// consecutive tiles per shard (experiment for a cross-tile duplicate filter)
+#ifndef XCK_SHARD_SHIFT
+#define XCK_SHARD_SHIFT 0
+#endif
+#define JOIN_SHARD ((int)((blockIdx.x >> XCK_SHARD_SHIFT) & (NSHARD - 1)))
 #ifndef XCK_TILE_ITEMS
 #define XCK_TILE_ITEMS 4
 #endif
@@ -314,7 +320,7 @@ __device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const Batc
 // append straight to HBM (slow path: LDS set/queue saturated)
 template <class K, int MODE>
 __device__ __forceinline__ void emit_global(const JoinArgs<K>& a, K key, uint64_t val) {
-    const int shard = blockIdx.x & (NSHARD - 1);
+    const int shard = JOIN_SHARD;
     unsigned long long idx = atomicAdd(&a.ctl[ctl_cursor(shard)], 1ull);
     if (idx < a.cap) { idx += (unsigned long long)shard * a.cap; a.keys[idx] = key; if (MODE == XCK_MODE_BAF) a.vals[idx] = val; }
     else atomicExch(&a.ctl[CTL_OVERFLOW], 1ull);
@@ -357,7 +363,7 @@ __device__ __forceinline__ void emit_nobase(const JoinArgs<K>& a, JoinSmem<K, MO
     const uint32_t idx = atomicAdd(&sm.ncount, 1u);
     if (idx < (uint32_t)JoinSmem<K, MODE>::NQCAP) { sm.nq_key[idx] = (uint64_t)key; sm.nq_val[idx] = val; }
     else {
-        const int shard = blockIdx.x & (NSHARD - 1);
+        const int shard = JOIN_SHARD;
         unsigned long long g = atomicAdd(&a.ctl[ctl_ncursor(shard)], 1ull);
         if (g < a.cap) { g += (unsigned long long)shard * a.cap; a.nkeys[g] = key; a.nvals[g] = val; }
         else atomicExch(&a.ctl[CTL_OVERFLOW], 1ull);
@@ -371,7 +377,7 @@ __device__ __forceinline__ void flush_split(const JoinArgs<K>& a, JoinSmem<K, MO
         const uint32_t total = threadIdx.x ? tn : tb;
         unsigned long long b = 0;
         if (total) {
-            const int shard = blockIdx.x & (NSHARD - 1);
+            const int shard = JOIN_SHARD;
             b = atomicAdd(&a.ctl[threadIdx.x ? ctl_ncursor(shard) : ctl_cursor(shard)], (unsigned long long)total);
             if (b + total > a.cap) { atomicExch(&a.ctl[CTL_OVERFLOW], 1ull); b = ~0ull; }
             else b += (unsigned long long)shard * a.cap;
@@ -405,7 +411,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
             uint32_t total = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
             unsigned long long b = 0;
             if (total) {
-                const int shard = blockIdx.x & (NSHARD - 1);
+                const int shard = JOIN_SHARD;
                 b = atomicAdd(&a.ctl[ctl_cursor(shard)], (unsigned long long)total);
                 if (b + total > a.cap) { atomicExch(&a.ctl[CTL_OVERFLOW], 1ull); b = ~0ull; }
                 else b += (unsigned long long)shard * a.cap;
@@ -434,7 +440,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
         if (threadIdx.x == 0) {
             unsigned long long b = 0;
             if (total) {
-                const int shard = blockIdx.x & (NSHARD - 1);
+                const int shard = JOIN_SHARD;
                 b = atomicAdd(&a.ctl[ctl_cursor(shard)], (unsigned long long)total);
                 if (b + total > a.cap) { atomicExch(&a.ctl[CTL_OVERFLOW], 1ull); b = ~0ull; }
                 else b += (unsigned long long)shard * a.cap;
@@ -768,10 +774,10 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
 #pragma unroll
         for (int w = 0; w < JOIN_BLOCK / 64; w++) uor |= ((unsigned long long)sm.wuor[2 * w + 1] << 32) | sm.wuor[2 * w];
         // one word per shard, on the shard cursor's cache line (a single shared word serialises at ~90 atomics/us)
-        if (uor) atomicOr(&a.ctl[ctl_umi_or(blockIdx.x & (NSHARD - 1))], uor);
+        if (uor) atomicOr(&a.ctl[ctl_umi_or(JOIN_SHARD)], uor);
     }
     if (tid == 0) { acc = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
-                    if (acc) atomicAdd(&a.ctl[ctl_accepted(blockIdx.x & (NSHARD - 1))], (unsigned long long)acc); }
+                    if (acc) atomicAdd(&a.ctl[ctl_accepted(JOIN_SHARD)], (unsigned long long)acc); }
     STAMP(6);
 }
 
