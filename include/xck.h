@@ -227,6 +227,26 @@ int  xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t
  * 0 at end of file, <0 on error. */
 int  xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out);
 
+/* -- phased-SNP lists (fast path of load_snp_from_tsv / load_snp_from_vcf, baf/fc/utils.py:51-110, :114-193) --- */
+/* The accepted SNPs of a TSV (header line, then chrom pos ref alt ref_hap alt_hap) or a phased VCF (first sample,
+ * GT exactly 0|1, 1|0, 0/1, 1/0; single-base REF/ALT in ACGTN, upper-cased), in file order, chrom without a leading
+ * "chr".  gzip / bgzip input is read through zlib.  Returns 0, or 1 when the file is outside what this parser
+ * reproduces exactly (non-ASCII bytes, carriage returns, a position that is not plain decimal digits): the caller then
+ * uses its generic loader.  <0 on I/O errors. */
+typedef struct xck_snp_text {
+    int64_t n;
+    const int32_t* chrom_id;        /* [n] index into chroms[]                               */
+    const int64_t* pos;             /* [n] 1-based                                           */
+    const char*    ref;             /* [n]                                                   */
+    const char*    alt;             /* [n]                                                   */
+    const int8_t*  ref_hap;         /* [n] 0 / 1                                             */
+    const int8_t*  alt_hap;         /* [n]                                                   */
+    int32_t n_chroms;
+    const char* const* chroms;      /* in order of first appearance                          */
+} xck_snp_text;
+int  xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out);
+void xck_free_snp_text(xck_snp_text* t);
+
 /* -- output (replaces merge_mtx(), rdr/fc/utils.py:54-93) ------------------------------------ */
 /* Write a MatrixMarket file byte-identical to the reference: header
  * "%%MatrixMarket matrix coordinate integer general\n%%\n{nrow}\t{ncol}\t{nnz}\n" then

@@ -536,13 +536,91 @@ def test_decoder_survives_corrupt_bams_under_sanitizers(tmp_path):
     mut = os.path.join(asan, "mutate_bams.py")
     subprocess.check_call([sys.executable, mut, src, str(tmp_path / "a"), "160", "5"])
     subprocess.check_call([sys.executable, mut, multi, str(tmp_path / "i"), "40", "6", "--bai"])
+    rnd = np.random.default_rng(9)                                 # SNP lists with random byte damage: the text parser (csrc/snptext.cpp)
+    os.makedirs(str(tmp_path / "s"))
+    for k in range(120):
+        lines = (_VCF_LINES if k & 1 else _TSV_LINES) * 3
+        b = bytearray(("\n".join(lines) + "\n").encode())
+        for _ in range(int(rnd.integers(1, 12))):
+            b[int(rnd.integers(0, len(b)))] = int(rnd.choice([9, 10, 58, 124, 47, 48, 49, 0, 255, 65, 13, int(rnd.integers(0, 256))]))
+        open(str(tmp_path / "s" / ("m%03d.%s" % (k, "vcf" if k & 1 else "tsv"))), "wb").write(bytes(b))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")          # the reader parks its buffers in a process-wide pool on purpose
-    for sub, extra in (("a", {}), ("i", {"XCK_ASAN_INDEX": "1"})):
-        files = sorted(str(p) for p in (tmp_path / sub).glob("*.bam"))
+    for sub, extra in (("a", {}), ("i", {"XCK_ASAN_INDEX": "1"}), ("s", {})):
+        files = sorted(str(p) for p in (tmp_path / sub).glob("*.bam" if sub != "s" else "*.*"))
         r = subprocess.run([os.path.join(asan, "decoder_asan")] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                            env=dict(env, **extra), timeout=600)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
         m = re.search(r"(\d+) files: (\d+) clean decodes, (\d+) rejected", r.stdout)
-        assert m and int(m.group(1)) == len(files) and int(m.group(2)) + int(m.group(3)) == 4 * len(files)
+        assert m and int(m.group(1)) == len(files) and int(m.group(2)) + int(m.group(3)) == (2 if sub == "s" else 4) * len(files)
         if sub == "a":
             assert int(m.group(3)) > len(files)                      # most damage is detected and reported as an error
+
+
+# ---------------------------------------------------------------- native SNP text parser (csrc/snptext.cpp) == the generic loaders
+_TSV_LINES = [
+    "chrom\tpos\tref\talt\tref_hap\talt_hap",
+    "chr1\t100\tA\tG\t0\t1", "1\t101\tc\tt\t1\t0", "CHRX\t7\tN\tA\t0\t1\textra\tcolumns", "chr2\t5\tA\tG\t0\t1\t\t ",
+    "chr2\t6\tAC\tG\t0\t1", "chr2\t7\tA\tG,T\t0\t1", "chr2\t8\tA\tG\t0\t0", "chr2\t9\tA\tG\t1\t1", "chr2\t10\tA\tG\t0", "",
+    "chr2\t11\tR\tG\t0\t1", "chr2\t12\tA\tG\t0 \t1", "chr2\t0012\tA\tG\t1\t0", "chrM\t13\tt\tn\t0\t1", "2\t13\tA\tG\t0\t1", "\t14\tA\tG\t0\t1",
+    "chr\t15\tA\tG\t0\t1", " chr3\t16\tA\tG\t0\t1", "chr2\t17\tA\tG\t0\t1 ", "chr2\t18\t\tG\t0\t1", "chr2\t19\tA\tG\t01\t0",
+]
+_VCF_LINES = [
+    "##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2", "",
+    "chr1\t100\t.\tA\tG\t.\tPASS\t.\tGT\t0|1", "1\t101\trs1\tc\tt\t50\t.\tAC=1\tGT:PS\t1|0:77", "chr1\t102\t.\tA\tG\t.\t.\t.\tDP:GT\t9:0/1\t1|1",
+    "chr1\t103\t.\tA\tG\t.\t.\t.\tGT\t1/0 ", "chr1\t104\t.\tA\tG\t.\t.\t.\tGT\t0|0", "chr1\t105\t.\tA\tG,T\t.\t.\t.\tGT\t0|1",
+    "chr1\t106\t.\tAT\tG\t.\t.\t.\tGT\t0|1", "chr1\t107\t.\tA\tG\t.\t.\t.\tDP\t9", "chr1\t108\t.\tA\tG\t.\t.\t.\tGT:DP\t0|1",
+    "chr1\t109\t.\tA\tG\t.\t.\t.\tGT\t01", "chr1\t110\t.\tA\tG\t.\t.\t.\tGT\t0|1|1", "chr1\t111\t.\tA\tG\t.\t.\t.\tGT\t.|1", "chr1\t112\t.\tA\tG\t.\t.\t.\tGT",
+    "chr1\t113\t.\tn\tA\t.\t.\t.\tGT\t1|0", "chrY\t114\t.\tA\tG\t.\t.\t.\tGQ:GT:DP\t3:0|1:4\t0|1", "chr1\t115\t.\tA\tG\t.\t.\t.\tGT\t0/1|x", "chr1\t116\t.\tA\tG\t.\t.\t.\tgt\t0|1",
+    "chr1\t117\t.\tA\tG\t.\t.\t.\tGT:GT\t1|0:0|1", "#late comment", "chr1\t118\t.\tA\t*\t.\t.\t.\tGT\t0|1",
+]
+
+
+@pytest.mark.parametrize("kind", ["tsv", "vcf", "tsv.gz", "vcf.gz", "tsv_nonl"])
+def test_native_snp_parser_equals_generic_loaders(kind, tmp_path, monkeypatch):
+    import gzip
+    from xcltk_amd import fc_common as F
+    from xcltk_amd.snptable import SnpTable
+    vcf = kind.startswith("vcf")
+    text = "\n".join(_VCF_LINES if vcf else _TSV_LINES) + ("" if kind == "tsv_nonl" else "\n")
+    fn = str(tmp_path / ("snps." + kind.replace("_nonl", "")))
+    if kind.endswith(".gz"):
+        with gzip.open(fn, "wt") as fp:
+            fp.write(text)
+    else:
+        open(fn, "w").write(text)
+    loader = F.load_snp_from_vcf if vcf else F.load_snp_from_tsv
+    got = loader(fn)
+    assert isinstance(got, SnpTable)
+    monkeypatch.setenv("XCK_PY_LOADERS", "1")
+    exp = loader(fn)
+    assert isinstance(exp, list) and len(exp) >= 8
+    assert got == exp and list(got) == exp and len(got) == len(exp) and got[3] == exp[3] and got[-1] == exp[-1] and got[2:5] == exp[2:5]
+    assert got.chroms() == list(dict.fromkeys(s[0] for s in exp))
+    regs = [("1", 1, 200, "a"), ("2", 14, 20, "b"), ("X", 8, 9, "c"), ("M", 13, 13, "d"), ("nope", 1, 5, "e"), ("1", 300, 200, "f")]
+    from xcltk_amd.baf.fc.main import regions_with_snps
+    assert regions_with_snps(regs, got) == regions_with_snps(regs, exp)
+    assert F.contig_table(regs, got) == F.contig_table(regs, exp)
+
+
+def test_native_snp_parser_declines_what_it_cannot_reproduce(tmp_path, monkeypatch):
+    """Carriage returns, non-ASCII bytes and positions that are not plain digits go to the generic loader, whose result
+    (or exception) is the behaviour of record."""
+    from xcltk_amd import fc_common as F
+    head = "chrom\tpos\tref\talt\tref_hap\talt_hap\n"
+    for name, body in (("crlf", "chr1\t5\tA\tG\t0\t1\r\nchr1\t6\tA\tG\t1\t0\r\n"), ("plus", "chr1\t+5\tA\tG\t0\t1\n"), ("blank", "chr1\t 5\tA\tG\t0\t1\n"),
+                       ("latin", "chr1\t5\tA\tG\t0\t1\n# café\t1\tA\tG\t0\t1\n"), ("big", "chr1\t1234567890123456789012\tA\tG\t0\t1\n")):
+        fn = str(tmp_path / (name + ".tsv"))
+        open(fn, "w", encoding="utf-8").write(head + body)
+        got = F.load_snp_from_tsv(fn)
+        assert isinstance(got, list), name                     # the generic loop ran
+        monkeypatch.setenv("XCK_PY_LOADERS", "1")
+        assert got == F.load_snp_from_tsv(fn)
+        monkeypatch.delenv("XCK_PY_LOADERS")
+    bad = str(tmp_path / "bad.tsv")
+    open(bad, "w").write(head + "chr1\tfive\tA\tG\t0\t1\n")
+    with pytest.raises(ValueError):                            # int("five"), exactly as before
+        F.load_snp_from_tsv(bad)
+    assert F.load_snp_from_tsv(str(tmp_path / "crlf.tsv"))[1][:2] == ("1", 6)
+    empty = str(tmp_path / "empty.tsv")
+    open(empty, "w").write(head)
+    assert len(F.load_snp_from_tsv(empty)) == 0

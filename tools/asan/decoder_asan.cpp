@@ -31,6 +31,17 @@ int main(int argc, char** argv) {
     std::vector<const char*> bp; for (auto& s : bcs) bp.push_back(s.c_str());
     long ok = 0, bad = 0, recs = 0;
     for (int a = 1; a < argc; a++) {
+        const size_t al = strlen(argv[a]);
+        if (al > 4 && (!strcmp(argv[a] + al - 4, ".tsv") || !strcmp(argv[a] + al - 4, ".vcf"))) {       // SNP lists: the text parser
+            for (int vcf = 0; vcf < 2; vcf++) {
+                xck_snp_text* t = nullptr;
+                const int rc = xck_parse_snp_text(argv[a], vcf, &t);
+                if (rc == 0 && t) { unsigned long long s = 0; for (int64_t i = 0; i < t->n; i++) s += (unsigned)t->chrom_id[i] + (unsigned long long)t->pos[i] + t->ref[i] + t->alt[i] + t->ref_hap[i] + t->alt_hap[i];
+                                    for (int c = 0; c < t->n_chroms; c++) s += strlen(t->chroms[c]); if (s == 0x123456789abcull) puts(""); recs += t->n; ok++; xck_free_snp_text(t); }
+                else bad++;
+            }
+            continue;
+        }
         for (int mode : {XCK_MODE_BASEFC, XCK_MODE_BAF}) {
             for (int threads : {1, 3}) {
                 xck_config cfg; memset(&cfg, 0, sizeof cfg);

@@ -89,19 +89,23 @@ def regions_with_snps(regions, snps):
     """Boolean per region: at least one SNP with start <= pos <= end on the same (stripped)
     chromosome - the IntervalTree fetch of baf/fc/main.py:92-101."""
     import bisect
-    by_chrom = {}
-    for s in snps:
-        by_chrom.setdefault(s[0], []).append(s[1])
-    for v in by_chrom.values():
-        v.sort()
+    from ...snptable import SnpTable
+    if isinstance(snps, SnpTable):
+        by_chrom = snps.positions_by_chrom()
+    else:
+        by_chrom = {}
+        for s in snps:
+            by_chrom.setdefault(s[0], []).append(s[1])
+        for v in by_chrom.values():
+            v.sort()
     out = []
     for ch, s, e, _ in regions:
         pos = by_chrom.get(ch)
-        if not pos or e < s:
+        if pos is None or len(pos) == 0 or e < s:
             out.append(False)
             continue
         k = bisect.bisect_left(pos, s)
-        out.append(k < len(pos) and pos[k] <= e)
+        out.append(bool(k < len(pos) and pos[k] <= e))
     return out
 
 

@@ -100,6 +100,11 @@ class IngestOpts(C.Structure):
 
 # every symbol include/xck.h declares: (name, restype, argtypes)
 _P = C.POINTER
+class SnpText(C.Structure):
+    _fields_ = [("n", C.c_int64), ("chrom_id", _P(C.c_int32)), ("pos", _P(C.c_int64)), ("ref", _P(C.c_char)), ("alt", _P(C.c_char)),
+                ("ref_hap", _P(C.c_int8)), ("alt_hap", _P(C.c_int8)), ("n_chroms", C.c_int32), ("chroms", _P(C.c_char_p))]
+
+
 SYMBOLS = [
     ("xck_version", C.c_char_p, []),
     ("xck_abi_version", C.c_int, []),
@@ -125,6 +130,8 @@ SYMBOLS = [
     ("xck_ingest_bam", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts), _P(C.c_int64)]),
     ("xck_bam_next_batch", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts), _P(Batch)]),
     ("xck_write_mtx", C.c_int, [C.c_char_p, _P(Coo), _P(C.c_int32), C.c_int32, C.c_int32]),
+    ("xck_parse_snp_text", C.c_int, [C.c_char_p, C.c_int, _P(_P(SnpText))]),
+    ("xck_free_snp_text", None, [_P(SnpText)]),
 ]
 
 _lib = None

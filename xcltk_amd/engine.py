@@ -15,6 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
+from .snptable import SnpTable
 from .capi import XCK_MODE_BAF, XCK_MODE_BASEFC
 
 
@@ -53,7 +54,8 @@ class Engine(object):
         self.contig_names = list(contig_names)
         cidx = {n: i for i, n in enumerate(self.contig_names)}
         regions = list(regions)
-        snps = list(snps)
+        if not isinstance(snps, SnpTable):
+            snps = list(snps)
         # column-wise fills (a per-row structured assignment costs ~1.5 us: 1.5 s for 1 M SNPs)
         self._reg = np.zeros(len(regions), dtype=capi.REGION_DTYPE)
         if regions:
@@ -61,7 +63,17 @@ class Engine(object):
             self._reg["start"] = [r[1] for r in regions]
             self._reg["end"] = [r[2] for r in regions]
         self._snp = np.zeros(len(snps), dtype=capi.SNP_DTYPE)
-        if snps:
+        if isinstance(snps, SnpTable):
+            if len(snps):
+                if int(snps.pos.max()) > 2 ** 31 - 1 or int(snps.pos.min()) < -2 ** 31:
+                    raise OverflowError("SNP position does not fit the engine's int32 coordinate")
+                self._snp["contig"] = np.array([cidx[n] for n in snps.names], dtype=np.int32)[snps.chrom_id]
+                self._snp["pos"] = snps.pos
+                self._snp["ref"] = snps.ref
+                self._snp["alt"] = snps.alt
+                self._snp["ref_hap"] = snps.ref_hap
+                self._snp["alt_hap"] = snps.alt_hap
+        elif snps:
             self._snp["contig"] = [cidx[s[0]] for s in snps]
             self._snp["pos"] = [s[1] for s in snps]
             self._snp["ref"] = [ord(s[2]) for s in snps]
