@@ -243,7 +243,17 @@ typedef struct xck_snp_text {
     const int8_t*  alt_hap;         /* [n]                                                   */
     int32_t n_chroms;
     const char* const* chroms;      /* in order of first appearance                          */
+    int64_t n_rejected;             /* lines the loaders warn about in verbose mode ...      */
+    const int64_t* rej_line;        /* [n_rejected] 1-based line numbers, ascending          */
+    const int8_t*  rej_code;        /* [n_rejected] XCK_SNP_REJ_*: the first check that failed */
 } xck_snp_text;
+#define XCK_SNP_REJ_COLUMNS     1   /* too few columns                                        */
+#define XCK_SNP_REJ_REF         2   /* invalid REF base                                       */
+#define XCK_SNP_REJ_ALT         3   /* invalid ALT base                                       */
+#define XCK_SNP_REJ_NO_GT       4   /* VCF: no GT in FORMAT                                   */
+#define XCK_SNP_REJ_FORMAT_LEN  5   /* VCF: FORMAT and sample column differ in length         */
+#define XCK_SNP_REJ_DELIMITER   6   /* VCF: GT without | or /                                 */
+#define XCK_SNP_REJ_GT          7   /* genotype is not 0|1 / 1|0 (0/1, 1/0)                   */
 int  xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out);
 void xck_free_snp_text(xck_snp_text* t);
 

@@ -576,7 +576,7 @@ _VCF_LINES = [
 
 
 @pytest.mark.parametrize("kind", ["tsv", "vcf", "tsv.gz", "vcf.gz", "tsv_nonl"])
-def test_native_snp_parser_equals_generic_loaders(kind, tmp_path, monkeypatch):
+def test_native_snp_parser_equals_generic_loaders(kind, tmp_path, monkeypatch, capsys):
     import gzip
     from xcltk_amd import fc_common as F
     from xcltk_amd.snptable import SnpTable
@@ -591,8 +591,12 @@ def test_native_snp_parser_equals_generic_loaders(kind, tmp_path, monkeypatch):
     loader = F.load_snp_from_vcf if vcf else F.load_snp_from_tsv
     got = loader(fn)
     assert isinstance(got, SnpTable)
+    capsys.readouterr()
+    assert loader(fn, verbose=True) == got                      # what the front-ends call
+    said = capsys.readouterr().err
     monkeypatch.setenv("XCK_PY_LOADERS", "1")
-    exp = loader(fn)
+    exp = loader(fn, verbose=True)
+    assert capsys.readouterr().err == said and said.count("[W::") >= 8          # the same warning for the same lines
     assert isinstance(exp, list) and len(exp) >= 8
     assert got == exp and list(got) == exp and len(got) == len(exp) and got[3] == exp[3] and got[-1] == exp[-1] and got[2:5] == exp[2:5]
     assert got.chroms() == list(dict.fromkeys(s[0] for s in exp))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """scratch: differential fuzz of the native SNP text parser against the generic Python loaders (mutated TSV / VCF text)."""
-import sys, os, numpy as np, tempfile, importlib
+import io, sys, os, numpy as np, tempfile, importlib
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 T = importlib.import_module("test_host_logic")
@@ -23,11 +23,17 @@ for k in range(n):
         os.environ.pop("XCK_PY_LOADERS", None)
         if force:
             os.environ["XCK_PY_LOADERS"] = "1"
+        err = io.StringIO()
+        old, sys.stderr = sys.stderr, err
         try:
-            res.append((loader(fn), None))
+            res.append((loader(fn, verbose=True), None, err))
         except Exception as e:
-            res.append((None, type(e).__name__))
-    (got, gerr), (exp, eerr) = res
+            res.append((None, type(e).__name__, err))
+        finally:
+            sys.stderr = old
+    (got, gerr, e1), (exp, eerr, e2) = res
+    if gerr is None and e1.getvalue() != e2.getvalue():
+        print("STDERR DIFF at", k, bytes(b)); print(e1.getvalue()); print(e2.getvalue()); sys.exit(1)
     if gerr != eerr or (got is not None and not (got == exp)):
         print("DIFF at", k, gerr, eerr, bytes(b)); print(list(got) if got is not None else None); print(exp)
         sys.exit(1)

@@ -102,7 +102,8 @@ class IngestOpts(C.Structure):
 _P = C.POINTER
 class SnpText(C.Structure):
     _fields_ = [("n", C.c_int64), ("chrom_id", _P(C.c_int32)), ("pos", _P(C.c_int64)), ("ref", _P(C.c_char)), ("alt", _P(C.c_char)),
-                ("ref_hap", _P(C.c_int8)), ("alt_hap", _P(C.c_int8)), ("n_chroms", C.c_int32), ("chroms", _P(C.c_char_p))]
+                ("ref_hap", _P(C.c_int8)), ("alt_hap", _P(C.c_int8)), ("n_chroms", C.c_int32), ("chroms", _P(C.c_char_p)),
+                ("n_rejected", C.c_int64), ("rej_line", _P(C.c_int64)), ("rej_code", _P(C.c_int8))]
 
 
 SYMBOLS = [

@@ -17,6 +17,7 @@ struct SnpTextImpl {
     xck_snp_text pub;
     std::vector<int32_t> chrom_id; std::vector<int64_t> pos; std::string ref, alt; std::vector<int8_t> rh, ah;
     std::vector<std::string> chrom_store; std::vector<const char*> chrom_ptr;
+    std::vector<int64_t> rej_line; std::vector<int8_t> rej_code;
 };
 
 inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }   // str.isspace() over ASCII
@@ -75,10 +76,11 @@ int xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out) {
         at += len + (e ? 1 : 0);
         nl++;
         Field chrom, posf, a1, a2; int rb, ab;
+        auto reject = [&](int code) { t->rej_line.push_back(nl); t->rej_code.push_back((int8_t)code); };
         if (!is_vcf) {
             if (nl == 1) continue;                                          // header
             split_tabs(line, len, parts);
-            if (parts.size() < 6) continue;
+            if (parts.size() < 6) { reject(XCK_SNP_REJ_COLUMNS); continue; }
             chrom = parts[0]; posf = parts[1];
             rb = parts[2].n == 1 ? base_code((unsigned char)parts[2].p[0]) : 0;
             ab = parts[3].n == 1 ? base_code((unsigned char)parts[3].p[0]) : 0;
@@ -86,25 +88,28 @@ int xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out) {
         } else {
             if (len == 0 || line[0] == '#') continue;                       // line[0] in ("#", "\n")
             split_tabs(line, len, parts);
-            if (parts.size() < 10) continue;
+            if (parts.size() < 10) { reject(XCK_SNP_REJ_COLUMNS); continue; }
             chrom = parts[0]; posf = parts[1];
             rb = parts[3].n == 1 ? base_code((unsigned char)parts[3].p[0]) : 0;
             ab = parts[4].n == 1 ? base_code((unsigned char)parts[4].p[0]) : 0;
-            if (!rb || !ab) continue;
+            if (!rb) { reject(XCK_SNP_REJ_REF); continue; }
+            if (!ab) { reject(XCK_SNP_REJ_ALT); continue; }
             split_char(parts[8], ':', fields); split_char(parts[9], ':', values);
             size_t gi = fields.size();
             for (size_t i = 0; i < fields.size(); i++) if (is_str(fields[i], "GT")) { gi = i; break; }
-            if (gi == fields.size() || values.size() != fields.size()) continue;
+            if (gi == fields.size()) { reject(XCK_SNP_REJ_NO_GT); continue; }
+            if (values.size() != fields.size()) { reject(XCK_SNP_REJ_FORMAT_LEN); continue; }
             const Field gt = values[gi];
             char sep = 0;
             if (memchr(gt.p, '|', gt.n)) sep = '|'; else if (memchr(gt.p, '/', gt.n)) sep = '/';
-            if (!sep) continue;
+            if (!sep) { reject(XCK_SNP_REJ_DELIMITER); continue; }
             split_char(gt, sep, gts);                                       // >= 2 pieces because sep occurs
             a1 = gts[0]; a2 = gts[1];
         }
-        if (!rb || !ab) continue;
+        if (!rb) { reject(XCK_SNP_REJ_REF); continue; }
+        if (!ab) { reject(XCK_SNP_REJ_ALT); continue; }
         const bool g01 = is_str(a1, "0") && is_str(a2, "1"), g10 = is_str(a1, "1") && is_str(a2, "0");
-        if (!g01 && !g10) continue;
+        if (!g01 && !g10) { reject(XCK_SNP_REJ_GT); continue; }
         int64_t pv;
         if (!plain_int(posf, pv)) { eligible = false; break; }              // int() of an accepted line: leave every odd spelling to Python
         size_t skip = (chrom.n >= 3 && (chrom.p[0] | 32) == 'c' && (chrom.p[1] | 32) == 'h' && (chrom.p[2] | 32) == 'r') ? 3 : 0;
@@ -121,6 +126,7 @@ int xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out) {
     t->pub.chrom_id = t->chrom_id.data(); t->pub.pos = t->pos.data(); t->pub.ref = t->ref.data(); t->pub.alt = t->alt.data();
     t->pub.ref_hap = t->rh.data(); t->pub.alt_hap = t->ah.data();
     t->pub.n_chroms = (int32_t)t->chrom_ptr.size(); t->pub.chroms = t->chrom_ptr.data();
+    t->pub.n_rejected = (int64_t)t->rej_line.size(); t->pub.rej_line = t->rej_line.data(); t->pub.rej_code = t->rej_code.data();
     *out = &t->pub;
     return XCK_OK;
 }

@@ -132,9 +132,15 @@ def _snp_from_fields(chrom, pos, ref, alt, a1, a2):
     return (format_chrom(chrom), int(pos), ref, alt, int(a1), int(a2))
 
 
-def _load_snps_native(fn, is_vcf):
+_REJ_TSV = {1: "too few columns of", 2: "invalid REF base of", 3: "invalid ALT base of", 7: "invalid GT of"}
+_REJ_VCF = {1: "too few columns of", 2: "invalid REF base", 3: "invalid ALT base", 4: "GT not in", 5: "len(fields) != len(values) in",
+            6: "invalid delimiter of", 7: "invalid GT of"}
+
+
+def _load_snps_native(fn, is_vcf, verbose=False, func=""):
     """The library's parser (csrc/snptext.cpp): same list as the loops below for plain-ASCII files, about 4x sooner for a
-    million SNPs; None when the file is outside what it reproduces exactly (or XCK_PY_LOADERS=1): the caller then loops."""
+    million SNPs; None when the file is outside what it reproduces exactly (or XCK_PY_LOADERS=1): the caller then loops.
+    verbose: the per-line warnings of the loops, printed from the parser's list of rejected lines."""
     if os.environ.get("XCK_PY_LOADERS") == "1":
         return None
     from . import capi
@@ -145,7 +151,12 @@ def _load_snps_native(fn, is_vcf):
         return None                              # 1 = not eligible; I/O errors surface from the generic loader with Python's own message
     try:
         v = t.contents
-        n = int(v.n)
+        n, nr = int(v.n), int(v.n_rejected)
+        if verbose and nr:
+            text = _REJ_VCF if is_vcf else _REJ_TSV
+            lines = np.ctypeslib.as_array(v.rej_line, shape=(nr,)).tolist()
+            codes = np.ctypeslib.as_array(v.rej_code, shape=(nr,)).tolist()
+            sys.stderr.write("".join("[W::%s] %s line %d.\n" % (func, text[c], l) for l, c in zip(lines, codes)))
         if n == 0:
             return []
         names = [v.chroms[i].decode("ascii") for i in range(v.n_chroms)]
@@ -163,10 +174,9 @@ def load_snp_from_tsv(fn, verbose=False):
     snps = []
     if verbose:
         sys.stderr.write("[I::%s] start to load SNPs from tsv '%s' ...\n" % (func, fn))
-    else:
-        native = _load_snps_native(fn, False)    # (verbose runs print a warning per rejected line: they take the loop)
-        if native is not None:
-            return native
+    native = _load_snps_native(fn, False, verbose, func)
+    if native is not None:
+        return native
     with zopen(fn, "rt") as fp:
         for nl, line in enumerate(fp, 1):
             if nl == 1:
@@ -196,10 +206,9 @@ def load_snp_from_vcf(fn, verbose=False):
     snps = []
     if verbose:
         sys.stderr.write("[I::%s] start to load SNPs from vcf '%s' ...\n" % (func, fn))
-    else:
-        native = _load_snps_native(fn, True)
-        if native is not None:
-            return native
+    native = _load_snps_native(fn, True, verbose, func)
+    if native is not None:
+        return native
     with zopen(fn, "rt") as fp:
         for nl, line in enumerate(fp, 1):
             if line[0] in ("#", "\n"):
