@@ -217,10 +217,15 @@ typedef struct xck_ingest_opts {
     int32_t  use_index;         /* 1: decode only the virtual-offset ranges of the wanted tids
                                    (needs PATH.bai; silently decodes everything if absent)   */
     int64_t  max_records;       /* stop after this many records (0 = all)                    */
+    int64_t  pause_records;     /* xck_ingest_bam only: return 1 ("paused") after the decode chunk in
+                                   which at least this many further records were pushed by THIS call;
+                                   the reader keeps its position and the next call continues
+                                   (0 = run to the end of the file).  Read only when struct_size covers it. */
 } xck_ingest_opts;
 
 /* Decode the BAM with the engine's decoder settings and push every batch; returns the number
- * of records decoded through *n_records. */
+ * of records decoded so far (over all calls on this reader) through *n_records.
+ * Returns 0 at the end of the file, 1 when paused by pause_records, <0 on error. */
 int  xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records);
 /* Pull-style decoding for tests / other consumers: fills *out with the next batch (arrays are
  * owned by the xck_bam and valid until the next call); returns 1 if a batch was produced,

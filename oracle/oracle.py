@@ -251,7 +251,8 @@ def encode_bam(records, tid_to_contig, sample, cell_index, cell_tag, umi_tag, um
             key = None
             if r.has_tag(umi_tag):
                 v = r.get_tag(umi_tag)
-                key = v if isinstance(v, str) else "\x01int:%r" % (v,)
+                # a numeric tag is its VALUE; 0 / 0.0 is falsy and the read is skipped (`if not umi`, rdr/fc/mcount.py:41, baf/fc/mcount.py:116-117)
+                key = v if isinstance(v, str) else (None if not v else "\x01int:%r" % (v,))
         else:
             key = r.query_name
         cur["umi"].append(encode_umi(key, umi_bits, intern))

@@ -95,7 +95,7 @@ class Stats(C.Structure):
 class IngestOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("sample", C.c_int32),
                 ("tid_to_contig", C.POINTER(C.c_int32)), ("use_index", C.c_int32),
-                ("max_records", C.c_int64)]
+                ("max_records", C.c_int64), ("pause_records", C.c_int64)]
 
 
 # every symbol include/xck.h declares: (name, restype, argtypes)

@@ -165,7 +165,7 @@ int xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map, in
     const int64_t n = m->nnz;
     const int64_t CH = 1 << 20;
     const int64_t n_chunks = (n + CH - 1) / CH;
-    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
+    unsigned nt = (unsigned)default_threads(); if (nt > 16) nt = 16;
     if (const char* e = getenv("XCK_WRITE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
     if ((int64_t)nt > n_chunks) nt = (unsigned)std::max<int64_t>(n_chunks, 1);
     auto for_chunks = [&](int64_t c0, int64_t c1, const std::function<void(int64_t)>& fn) {

@@ -11,14 +11,18 @@
 // chunk i+1 runs while chunk i is walked and parsed.
 #include <zlib.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
 #include <condition_variable>
+#include <cstddef>
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include "xck_internal.h"
 #include "inflate_fast.h"
@@ -31,6 +35,25 @@ namespace xck {
 static thread_local std::string t_err;
 void set_thread_error(const std::string& s) { t_err = s; }
 const char* get_thread_error() { return t_err.c_str(); }
+
+int default_threads() {
+    static const int cached = [] {
+        long n = (long)std::thread::hardware_concurrency(); if (n <= 0) n = 4;
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+        long long quota = -1, period = 100000;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                                  // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0}; if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q); fclose(f);
+        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {              // cgroup v1
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1; fclose(f1);
+            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &period) != 1) period = 100000; fclose(f2); }
+        }
+        if (quota > 0 && period > 0) { const long c = (long)((quota + period - 1) / period); if (c > 0 && c < n) n = c; }
+        if (const char* e = getenv("XCK_THREADS")) { const int v = atoi(e); if (v > 0) n = v; }
+        return (int)std::max(1l, n);
+    }();
+    return cached;
+}
 
 uint64_t hash_bytes(const char* s, size_t n) {                       // 8 bytes per step (read names are 20-40 characters)
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
@@ -207,12 +230,14 @@ static bool bgzf_peek(const uint8_t* map, uint64_t fsize, uint64_t coff, BlockRe
     if (coff + 12 + xlen > fsize) { if (err) *err = "truncated BGZF extra field"; return false; }
     const uint8_t* x = p + 12; const uint8_t* xe = x + xlen;
     int64_t bsize = -1;
-    while (x + 4 <= xe) { uint32_t sl = le16(x + 2); if (x[0] == 'B' && x[1] == 'C' && sl == 2) { bsize = le16(x + 4); } x += 4 + sl; }
+    while (x + 4 <= xe) { uint32_t sl = le16(x + 2); if (x + 4 + sl > xe) break;          // subfield payload must lie inside the extra field
+                          if (x[0] == 'B' && x[1] == 'C' && sl == 2) { bsize = le16(x + 4); } x += 4 + sl; }
     if (bsize < 0) { if (err) *err = "BGZF block without BC subfield"; return false; }
     uint32_t total = (uint32_t)bsize + 1;
     if (coff + total > fsize || total < 12 + xlen + 8) { if (err) *err = "truncated BGZF block"; return false; }
     out->coff = coff; out->clen = total; out->data_off = 12 + xlen; out->data_len = total - (12 + xlen) - 8;
     out->isize = le32(p + total - 4); out->uoff = 0;
+    if (out->isize > 65536) { if (err) *err = "BGZF block claims more than 64 KiB of data"; return false; }   // SAMv1 4.1: ISIZE <= 65536
     return true;
 }
 
@@ -358,7 +383,7 @@ static std::vector<BamScratch*> g_scratch;                            // at most
 
 extern "C" {
 
-int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen) {
+static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen) {
     auto fail = [&](const std::string& m, xck_bam* b) { if (err && errlen) { snprintf(err, errlen, "%s: %s", path ? path : "(null)", m.c_str()); } set_thread_error(m); if (b) xck_bam_close(b); return XCK_E_IO; };
     if (!path || !out) return fail("null argument", nullptr);
     xck_bam* b = new xck_bam();
@@ -388,7 +413,7 @@ int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size
     // first alignment record: inside the last inflated block at offset (r.pos - r.blk_start), or at the next block
     if (r.pos == r.buf.size()) { b->next_coff = r.coff; b->first_skip = 0; }
     else { b->next_coff = r.blk_coff; b->first_skip = (uint32_t)(r.pos - r.blk_start); }
-    if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads <= 0) n_threads = 4; }
+    if (n_threads <= 0) n_threads = default_threads();
     b->n_threads = n_threads;
     { BamScratch* sc = nullptr;
       { std::lock_guard<std::mutex> lk(g_scratch_mu); if (!g_scratch.empty()) { sc = g_scratch.back(); g_scratch.pop_back(); } }
@@ -594,10 +619,19 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
                 if (*ub == 'Z' || *ub == 'A' || *ub == 'H') {
                     const char* v = (const char*)ub + 1; size_t n = (*ub == 'A') ? 1 : strnlen(v, (size_t)(end - (ub + 1)));
                     key = encode_key(v, n, dc.umi_bits, e->intern, &ovf);
-                } else {                                                   // numeric tag: a non-string key; intern its bytes
+                } else {                                                   // numeric tag: get_tag() gives a number; the key is its VALUE
+                    // (an int 0 / float 0.0 is falsy: `if not umi` skips the read, rdr/fc/mcount.py:41, baf/fc/mcount.py:116-117)
                     const uint8_t* nx = aux_skip(ub, end);
-                    std::string t("\1num:"); if (nx) t.append((const char*)ub, (size_t)(nx - ub));
-                    key = encode_key(t.data(), t.size(), dc.umi_bits, e->intern, &ovf);
+                    bool zero = false; std::string t("\1num:");
+                    if (nx) {
+                        const uint8_t* v = ub + 1; long long iv = 0; bool is_int = true;
+                        switch (*ub) { case 'c': iv = (int8_t)v[0]; break; case 'C': iv = v[0]; break; case 's': iv = (int16_t)le16(v); break; case 'S': iv = le16(v); break;
+                                       case 'i': iv = (int32_t)le32(v); break; case 'I': iv = le32(v); break; default: is_int = false; }
+                        if (is_int) { zero = iv == 0; t += std::to_string(iv); }          // equal integers are equal keys whatever their storage width
+                        else if (*ub == 'f') { float f; memcpy(&f, v, 4); zero = f == 0.0f; t.append("f", 1); t.append((const char*)v, 4); }
+                        else t.append((const char*)ub, (size_t)(nx - ub));                 // B arrays: their bytes
+                    }
+                    if (!zero) key = encode_key(t.data(), t.size(), dc.umi_bits, e->intern, &ovf);
                 }
             }
         } else if (encode_key_direct(qname, qlen, dc.umi_bits, &key)) { /* empty or 2-bit codable name */ }
@@ -731,7 +765,7 @@ int xck_bam_ref_records(xck_bam* b, int tid, int64_t* n_mapped, int64_t* n_unmap
     return XCK_OK;
 }
 
-int xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) {
+static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) {
     if (!e || !b || !o || !out) return XCK_E_ARG;
     while (b->pending.empty()) {
         if (b->done) return 0;
@@ -749,16 +783,39 @@ int xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_
     return 1;
 }
 
-int xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) {
+static int ingest_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) {
     if (!e || !b || !o) return XCK_E_ARG;
     xck_batch bt;
     int rc;
-    while ((rc = xck_bam_next_batch(e, b, o, &bt)) == 1) {
+    const int64_t pause = o->struct_size >= offsetof(xck_ingest_opts, pause_records) + sizeof(int64_t) ? o->pause_records : 0;
+    const int64_t start = b->n_records;
+    while ((rc = next_batch_impl(e, b, o, &bt)) == 1) {
         int prc = xck::push_trusted(e, &bt);                  // fused handles feed both pipelines
         if (prc) return prc;
+        if (pause > 0 && b->pending.empty() && !b->done && b->n_records - start >= pause) {   // chunk boundary: the reader stays positioned
+            if (n_records) *n_records = b->n_records;
+            return 1;
+        }
     }
     if (n_records) *n_records = b->n_records;
     return rc < 0 ? rc : XCK_OK;
 }
+
+// C++ exceptions (std::bad_alloc from a buffer that a damaged file made huge, ...) must not unwind through the C ABI into
+// ctypes: they become error codes here.
+#define XCK_GUARD(e_, expr)                                                                              \
+    try { return (expr); }                                                                               \
+    catch (const std::bad_alloc&) { if (e_) (e_)->err = "out of host memory"; set_thread_error("out of host memory"); return XCK_E_NOMEM; } \
+    catch (const std::exception& x) { if (e_) (e_)->err = x.what(); set_thread_error(x.what()); return XCK_E_IO; }                        \
+    catch (...) { if (e_) (e_)->err = "unknown C++ exception"; set_thread_error("unknown C++ exception"); return XCK_E_IO; }
+int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen) {
+    xck_engine* none = nullptr;
+    try { return bam_open_impl(path, n_threads, out, err, errlen); }
+    catch (const std::bad_alloc&) { if (err && errlen) snprintf(err, errlen, "%s: out of host memory", path ? path : "(null)"); set_thread_error("out of host memory"); (void)none; return XCK_E_NOMEM; }
+    catch (const std::exception& x) { if (err && errlen) snprintf(err, errlen, "%s: %s", path ? path : "(null)", x.what()); set_thread_error(x.what()); return XCK_E_IO; }
+    catch (...) { if (err && errlen) snprintf(err, errlen, "%s: unknown C++ exception", path ? path : "(null)"); return XCK_E_IO; }
+}
+int xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) { XCK_GUARD(e, next_batch_impl(e, b, o, out)) }
+int xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) { XCK_GUARD(e, ingest_impl(e, b, o, n_records)) }
 
 }  // extern "C"

@@ -6,6 +6,8 @@
 #include <zlib.h>
 #include <cstdint>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -51,7 +53,7 @@ inline bool plain_int(const Field& f, int64_t& v) {
 
 extern "C" {
 
-int xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out) {
+static int parse_snp_text_impl(const char* path, int is_vcf, xck_snp_text** out) {
     if (!path || !out) return XCK_E_ARG;
     *out = nullptr;
     gzFile gz = gzopen(path, "rb");                                         // plain files are read through unchanged
@@ -129,6 +131,13 @@ int xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out) {
     t->pub.n_rejected = (int64_t)t->rej_line.size(); t->pub.rej_line = t->rej_line.data(); t->pub.rej_code = t->rej_code.data();
     *out = &t->pub;
     return XCK_OK;
+}
+
+int xck_parse_snp_text(const char* path, int is_vcf, xck_snp_text** out) {
+    try { return parse_snp_text_impl(path, is_vcf, out); }                   // no C++ exception crosses the C ABI
+    catch (const std::bad_alloc&) { xck::set_thread_error("out of host memory"); return XCK_E_NOMEM; }
+    catch (const std::exception& x) { xck::set_thread_error(x.what()); return XCK_E_IO; }
+    catch (...) { xck::set_thread_error("unknown C++ exception"); return XCK_E_IO; }
 }
 
 void xck_free_snp_text(xck_snp_text* t) { delete reinterpret_cast<SnpTextImpl*>(t); }   // pub is the first member

@@ -84,6 +84,9 @@ inline KeyBits key_layout(const xck_config* cfg) {
 
 // the decoder's own batches are valid by construction and skip the O(n) check of xck_push_batch()
 int push_trusted(xck_engine* e, const xck_batch* b);
+// host threads this process may really use: min(hardware threads, CPU affinity, cgroup CPU quota) - a container with a
+// 16-CPU quota on a 256-thread host must not start 256 decoder threads
+int  default_threads();
 void set_thread_error(const std::string& s);
 const char* get_thread_error();
 

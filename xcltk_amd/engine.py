@@ -210,6 +210,11 @@ class Engine(object):
         finally:
             self.lib.xck_bam_close(b)
 
+    def open_stream(self, path, sample=0, n_threads=0, contig_mask=None, use_index=False):
+        """Resumable ingest of one BAM: -> BamStream whose advance(n) decodes and joins about n further
+        records (whole decode chunks) and returns (records so far, done)."""
+        return BamStream(self, path, sample, n_threads, contig_mask, use_index)
+
     def decode_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False):
         """Pull-style decode (tests / inspection): yields dicts of numpy copies per batch."""
         b, refs = self._open(path, n_threads or self.cfg.n_threads)
@@ -294,3 +299,38 @@ class Engine(object):
         st = capi.Stats()
         self._check(self.lib.xck_get_stats(self.h, C.byref(st)), "xck_get_stats")
         return {k: getattr(st, k) for k, _ in capi.Stats._fields_}
+
+
+class BamStream(object):
+    """One open BAM being streamed through an Engine in slices (xck_ingest_opts.pause_records)."""
+
+    def __init__(self, eng, path, sample=0, n_threads=0, contig_mask=None, use_index=False):
+        self.eng = eng
+        self.b, refs = eng._open(path, n_threads or eng.cfg.n_threads)
+        self.opts, self._keep = eng._opts(refs, sample, 0, contig_mask, use_index)
+        self.n_records = 0
+        self.done = False
+
+    def advance(self, n_records=0):
+        """Decode and join at least n_records further records (0 = the rest of the file)."""
+        if self.done:
+            return self.n_records, True
+        self.opts.pause_records = int(n_records)
+        n = C.c_int64(0)
+        rc = self.eng.lib.xck_ingest_bam(self.eng.h, self.b, C.byref(self.opts), C.byref(n))
+        if rc < 0:
+            self.eng._check(rc, "xck_ingest_bam")
+        self.n_records = int(n.value)
+        self.done = rc == 0
+        return self.n_records, self.done
+
+    def close(self):
+        if self.b:
+            self.eng.lib.xck_bam_close(self.b)
+            self.b = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

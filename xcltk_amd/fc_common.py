@@ -350,11 +350,26 @@ class Dist(object):
                 weights[:] = 1.0
                 break
             weights += c
-        return contig_owner(eng.contig_names, weights + 1e-9, self.world) == self.rank
+        self.owner = contig_owner(eng.contig_names, weights + 1e-9, self.world)     # contig -> rank, identical on every rank
+        return self.owner == self.rank
 
-    def gather(self, coo):
-        from .shard import gather_coo
-        return {k: gather_coo(v, self.world, self.device) for k, v in coo.items()}
+    def gather(self, eng, regions):
+        """all-gatherv of the per-rank sparse blocks to rank 0, straight from HBM (xck_get_result_device): one
+        all-gather of sizes + one padded gather (RCCL over xGMI; host tensors over gloo).  Ranks own whole contigs,
+        hence disjoint rows: rank 0 stitches the row runs together without sorting.  -> coo dict on rank 0, else None."""
+        import torch
+        from .shard import BlockGatherer, merge_row_blocks
+        nccl = self.backend == "nccl"
+        dev = torch.device(self.device) if nccl else torch.device("cuda", int(os.environ.get("XCK_DEVICE", self.local_rank if torch.cuda.device_count() > self.local_rank else 0)))
+        blocks = eng.result_device()
+        g = BlockGatherer(self.world, self.rank, dev, names=tuple(blocks), backend_is_nccl=nccl)
+        g.start(blocks)
+        res = g.wait()
+        if self.rank != 0:
+            return None
+        cidx = {n: i for i, n in enumerate(eng.contig_names)}
+        row_owner = self.owner[np.array([cidx[r[0]] for r in regions], dtype=np.int64)] if len(regions) else np.zeros(0, dtype=np.int32)
+        return {k: merge_row_blocks([b.cpu().numpy() for b in res[k]], row_owner) for k in res}
 
 
 def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None):
@@ -379,7 +394,5 @@ def count_all(eng, conf, log_prefix="[engine]"):
     stream_bams(eng, conf, log_prefix, mask)
     coo = eng.finish(copy=False)
     if dist.active:
-        coo = dist.gather(coo)
-        if dist.rank != 0:
-            coo = None
+        coo = dist.gather(eng, conf.reg_list)
     return coo, dist

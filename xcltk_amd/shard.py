@@ -52,6 +52,49 @@ def gather_coo(coo, world, device="cpu", group=None):
     return cat[0].copy(), cat[1].copy(), cat[2].copy()
 
 
+def merge_row_blocks(blocks, row_owner):
+    """Concatenate per-rank sparse blocks into one (row, col, val) sorted by (row, col) without sorting.
+    blocks[r] = int32 array [row | col | val] (3 * nnz_r) of rank r, itself sorted by (row, col) and holding only rows
+    owned by r; row_owner[row] = owning rank.  Ranks own disjoint rows, so the result is the sequence of maximal runs of
+    rows with one owner, each cut out of its owner's block with two binary searches (regions of a contig are normally
+    adjacent in the region file: a few dozen runs)."""
+    row_owner = np.asarray(row_owner)
+    n = len(row_owner)
+    views = []
+    for b in blocks:
+        b = np.asarray(b, dtype=np.int32)
+        z = len(b) // 3
+        views.append((b[:z], b[z:2 * z], b[2 * z:3 * z]))
+    if n == 0:
+        z = np.zeros(0, dtype=np.int32)
+        return z, z.copy(), z.copy()
+    change = np.flatnonzero(np.diff(row_owner)) + 1
+    starts = np.concatenate([[0], change])
+    ends = np.concatenate([change, [n]])
+    owners = row_owner[starts]
+    cuts = {}
+    for r in set(int(x) for x in owners):
+        if 0 <= r < len(views):
+            sel = owners == r
+            cuts[r] = (np.searchsorted(views[r][0], starts[sel], "left"), np.searchsorted(views[r][0], ends[sel], "left"))
+    seq, pos = [], {r: 0 for r in cuts}
+    for r in owners.tolist():
+        if r in cuts:
+            i = pos[r]; pos[r] += 1
+            lo, hi = int(cuts[r][0][i]), int(cuts[r][1][i])
+            if hi > lo:
+                seq.append((r, lo, hi))
+    total = sum(hi - lo for _, lo, hi in seq)
+    assert total == sum(len(v[0]) for v in views), "a rank holds rows it does not own"
+    out = tuple(np.empty(total, dtype=np.int32) for _ in range(3))
+    o = 0
+    for r, lo, hi in seq:
+        for j in range(3):
+            out[j][o:o + hi - lo] = views[r][j][lo:hi]
+        o += hi - lo
+    return out
+
+
 def linear_partition(weights, n_bins):
     """Contiguous partition of items (in order) into n_bins minimising the largest bin
     (used when per-rank row ranges must stay contiguous so that concatenating the per-rank
