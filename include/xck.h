@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define XCK_ABI_VERSION 1
+#define XCK_ABI_VERSION 2   /* 2: xck_config.n_excl_pairs / excl_region / excl_snp, xck_ingest_opts.pause_records (older, shorter structs are still accepted) */
 
 /* status codes */
 #define XCK_OK            0
@@ -95,8 +95,15 @@ typedef struct xck_config {
     char     umi_tag[4];        /* e.g. "UB"; "" = key is the read name                      */
     /* sizing */
     int64_t  max_batch_reads;   /* upper bound on reads per xck_push_batch (0 = default)     */
-    int32_t  n_threads;         /* host decode threads (0 = hardware concurrency)            */
+    int32_t  n_threads;         /* host decode threads (0 = the CPUs this process may use)   */
     int32_t  flags;             /* XCK_F_*                                                   */
+    /* BAF: (region, SNP) pairs left OUT of the SNP -> region join although start <= pos <= end.  Region-wise
+     * local phasing drops the SNPs without coverage in the cellsnp data from that region's list
+     * (baf/fc/phasing.py:44-49; the SNP still counts in other regions that contain it).  Indices into
+     * regions[] / snps[].  Read only when struct_size covers the fields.                      */
+    int32_t  n_excl_pairs;
+    const int32_t* excl_region;
+    const int32_t* excl_snp;
 } xck_config;
 
 #define XCK_F_FORCE_KEY128   1  /* always use 128-bit sort keys (testing)                    */

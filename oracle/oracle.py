@@ -326,10 +326,15 @@ def contig_table(regions, snps=()):
 
 def run_files(mode, bam_fns, region_fn, out_dir=None, barcode_fn=None, sample_ids=None,
               snp_fn=None, cell_tag="CB", umi_tag="UB", excl_flag=None,
-              output_all_reg=True, umi_bits=None, **kw):
-    """Whole-run oracle: files in -> COO dict (and reference-format files if out_dir)."""
+              output_all_reg=True, umi_bits=None, phase=None, **kw):
+    """Whole-run oracle: files in -> COO dict (and reference-format files if out_dir).
+    phase: optional callable (regions, snps) -> (snps with their final haplotype indices, (excl_region, excl_snp)): the
+    outcome of region-wise local phasing, which is host logic in front of the counting (baf/fc/main.py:107-153)."""
     regions = load_regions(region_fn)
     snps = load_snps(snp_fn) if snp_fn else []
+    excl = None
+    if phase is not None:
+        snps, excl = phase(regions, snps)
     if barcode_fn:
         with _zopen(barcode_fn) as fp:
             samples = sorted(x.strip() for x in fp)
@@ -343,6 +348,12 @@ def run_files(mode, bam_fns, region_fn, out_dir=None, barcode_fn=None, sample_id
         excl_flag = 772 if umi_tag else 1796
     names = contig_table(regions, snps)
     cfg, keep = make_config(mode, names, regions, snps, len(samples), excl_flag=excl_flag, **kw)
+    if excl is not None and len(excl[0]):
+        er, es = (np.ascontiguousarray(x, dtype=np.int32) for x in excl)
+        cfg.n_excl_pairs = len(er)
+        cfg.excl_region = er.ctypes.data_as(C.POINTER(C.c_int32))
+        cfg.excl_snp = es.ctypes.data_as(C.POINTER(C.c_int32))
+        keep = keep + (er, es)
     if umi_bits is None:
         umi_bits = default_umi_bits(mode, len(regions), len(snps), len(samples))
     cell_index = {s: i for i, s in enumerate(samples)}

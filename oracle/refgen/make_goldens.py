@@ -165,7 +165,89 @@ def ds_special(d):
     return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
 
 
-DATASETS = {"c1": ds_c1, "dense": ds_dense, "multibam": ds_multibam, "well": ds_well, "special": ds_special}
+def ds_phasing(d):
+    """Region-wise local phasing (cellsnp_dir / ref_cell_fn): long regions whose SNPs carry a block of phase-switch errors,
+    a cellsnp-lite style pileup directory with allelic imbalance in two thirds of the cells (the rest near BAF 0.5, some of
+    them listed as reference cells), overlapping regions sharing SNPs, a region too short for phasing, one with a single
+    SNP, one whose SNPs are only covered by reference cells (phasing fails, its SNP list empties), one with an uncovered SNP."""
+    import gzip
+    import numpy as np
+    os.makedirs(os.path.join(d, "cellsnp"), exist_ok=True)
+    rng = np.random.default_rng(77)
+    contigs = [("chr1", 900000)]
+    cells = sorted("".join("ACGT"[i] for i in rng.integers(0, 4, 8)) + "-1" for _ in range(36))
+    n_cell = len(cells)
+    regions = [("chr1", 10001, 250000, "long_a"), ("chr1", 200001, 430000, "long_b_overlaps_a"), ("chr1", 440001, 470000, "short"),
+               ("chr1", 480001, 560000, "one_snp"), ("chr1", 570001, 700000, "ref_cells_only"), ("chr1", 710001, 880000, "long_c")]
+    snp_pos = sorted(set(int(x) for x in np.concatenate([
+        rng.integers(12000, 248000, 26), rng.integers(252000, 428000, 14), rng.integers(441000, 469000, 4), [500000],
+        rng.integers(575000, 695000, 8), rng.integers(715000, 875000, 22)])))
+    n_snp = len(snp_pos)
+    bases = "ACGT"
+    ref = [bases[i] for i in rng.integers(0, 4, n_snp)]
+    alt = [bases[(bases.index(r) + int(k)) % 4] for r, k in zip(ref, rng.integers(1, 4, n_snp))]
+    true_ref_hap = rng.integers(0, 2, n_snp)                      # haplotype of the REF allele in truth
+    err = np.zeros(n_snp, dtype=int)                              # phase-switch errors of the "Eagle" phase given to xcltk
+    for lo, hi in ((60000, 120000), (300000, 360000), (780000, 860000)):
+        err[[i for i, p in enumerate(snp_pos) if lo <= p < hi]] = 1
+    err[rng.random(n_snp) < 0.06] ^= 1
+    given_ref_hap = true_ref_hap ^ err
+    # cells: 0..23 imbalanced towards haplotype 0 or 1, 24..35 balanced; reference cells = 28..35
+    p_hap0 = np.concatenate([np.full(14, 0.88), np.full(10, 0.15), np.full(12, 0.5)])
+    ref_cells = [cells[i] for i in range(28, 36)]
+    uncovered = {snp_pos[3], snp_pos[-2]}
+    AD = np.zeros((n_snp, n_cell), dtype=np.int64); DP = np.zeros_like(AD); OTH = np.zeros_like(AD)
+    R = []
+    for j, p in enumerate(snp_pos):
+        only_ref_cells = 570001 <= p <= 700000
+        for c in range(n_cell):
+            if p in uncovered or (only_ref_cells and c < 28):
+                continue
+            n = int(rng.poisson(1.6))
+            for k in range(n):
+                hap = 0 if rng.random() < p_hap0[c] else 1
+                is_ref = (true_ref_hap[j] == hap)
+                base = ref[j] if is_ref else alt[j]
+                if rng.random() < 0.02:
+                    base = bases[(bases.index(ref[j]) + 2) % 4] if bases[(bases.index(ref[j]) + 2) % 4] != alt[j] else "N"
+                if base == alt[j]: AD[j, c] += 1
+                if base in (ref[j], alt[j]): DP[j, c] += 1
+                else: OTH[j, c] += 1
+                off = int(rng.integers(5, 45))
+                seq = "".join(bases[i] for i in rng.integers(0, 4, 50))
+                seq = seq[:off] + base + seq[off + 1:]
+                umi = "".join(bases[i] for i in rng.integers(0, 4, 10))
+                R.append((0, p - 1 - off, "q%06d" % len(R), 0, 255, "50M", seq, [("CB", cells[c]), ("UB", umi)]))
+    R.sort(key=lambda r: (r[0], r[1]))
+    bw = BamWriter(os.path.join(d, "possorted.bam"), contigs)
+    for (tid, pos, qn, flag, mapq, cig, seq, tags) in R:
+        bw.write(tid, pos, qn, flag, mapq, cig, seq, tags)
+    bw.close(); bw.write_index()
+    with open(os.path.join(d, "barcodes.tsv"), "w") as fp:
+        fp.write("".join(c + "\n" for c in cells))
+    with open(os.path.join(d, "regions.tsv"), "w") as fp:
+        fp.write("".join("%s\t%d\t%d\t%s\n" % r for r in regions))
+    with open(os.path.join(d, "snps.tsv"), "w") as fp:
+        fp.write("chrom\tpos\tref\talt\tref_hap\talt_hap\n")
+        fp.write("".join("chr1\t%d\t%s\t%s\t%d\t%d\n" % (p, r, a, h, 1 - h) for p, r, a, h in zip(snp_pos, ref, alt, given_ref_hap)))
+    with open(os.path.join(d, "ref_cells.tsv"), "w") as fp:
+        fp.write("".join(c + "\n" for c in ref_cells))
+    # the pileup directory in cellsnp-lite's layout (SNP x cell .mtx, 1-based, coordinate integer general)
+    with gzip.open(os.path.join(d, "cellsnp", "cellSNP.base.vcf.gz"), "wt") as fp:
+        fp.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for j, p in enumerate(snp_pos):
+            fp.write("chr1\t%d\t.\t%s\t%s\t.\tPASS\tAD=%d;DP=%d;OTH=%d\n" % (p, ref[j], alt[j], AD[j].sum(), DP[j].sum(), OTH[j].sum()))
+    with open(os.path.join(d, "cellsnp", "cellSNP.samples.tsv"), "w") as fp:
+        fp.write("".join(c + "\n" for c in cells))
+    for name, M in (("AD", AD), ("DP", DP), ("OTH", OTH)):
+        rr, cc = np.nonzero(M)
+        with open(os.path.join(d, "cellsnp", "cellSNP.tag.%s.mtx" % name), "w") as fp:
+            fp.write("%%%%MatrixMarket matrix coordinate integer general\n%%\n%d\t%d\t%d\n" % (n_snp, n_cell, len(rr)))
+            fp.write("".join("%d\t%d\t%d\n" % (r + 1, c + 1, M[r, c]) for r, c in zip(rr, cc)))
+    return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
+
+
+DATASETS = {"c1": ds_c1, "dense": ds_dense, "multibam": ds_multibam, "well": ds_well, "special": ds_special, "phasing": ds_phasing}
 
 # ------------------------------------------------------------------------------- cases
 # kwargs use "$D/" for the dataset directory and "$O" for the output directory.
@@ -222,6 +304,9 @@ CASES = [
     baf("special", "special_baf", output_all_reg=True, **_baf10x("special")),
     baf("special", "special_baf_dup_sparse", no_dup_hap=False, **_baf10x("special")),
     baf("special", "special_baf_minlen0", output_all_reg=True, min_len=0, min_mapq=0, **_baf10x("special")),
+    baf("phasing", "phasing_baf_refcells", cellsnp_dir="$D/cellsnp", ref_cell_fn="$D/ref_cells.tsv", **_baf10x("phasing")),
+    baf("phasing", "phasing_baf_allreg", cellsnp_dir="$D/cellsnp", output_all_reg=True, no_dup_hap=False, **_baf10x("phasing")),
+    baf("phasing", "phasing_baf_off", output_all_reg=True, **_baf10x("phasing")),
 ]
 
 
@@ -241,9 +326,9 @@ def main():
         if os.path.isdir(d):
             shutil.rmtree(d)
         info = fn(d)
-        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv"}
+        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv", "cellsnp", "ref_cells.tsv"}
         keep_only(d, keep)
-        info["md5"] = {f: md5(os.path.join(d, f)) for f in sorted(os.listdir(d))}
+        info["md5"] = {os.path.relpath(os.path.join(dp, f), d): md5(os.path.join(dp, f)) for dp, _, fs in sorted(os.walk(d)) for f in sorted(fs)}
         meta[name] = info
         with open(os.path.join(d, "dataset.json"), "w") as fp:
             json.dump(info, fp, indent=1, sort_keys=True)

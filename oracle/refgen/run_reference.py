@@ -9,7 +9,7 @@ given).  As recorded in SURVEY.md section 8c they are replaced by stand-ins:
 
   * pysam   -> oracle/pybam.py (AlignmentFile.fetch + AlignedSegment accessors restated
                from the SAM spec / pysam documentation);
-  * anndata -> empty module (never touched on the paths exercised here).
+  * anndata -> oracle/refgen/anndata_standin.py (a minimal AnnData; touched only when cellsnp_dir is given).
 
 `intervaltree` (xcltk/utils/grange.py:4) exists only for /opt/conda/bin/python3.9, hence
 the interpreter.  Nothing from the reference is copied: it is imported in place with
@@ -32,6 +32,7 @@ warnings.filterwarnings("ignore")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))          # oracle/ -> pybam
+sys.path.insert(0, HERE)                           # oracle/refgen -> anndata_standin
 REF = os.environ.get("XCLTK_REFERENCE", "/root/reference")
 
 
@@ -42,7 +43,10 @@ def install_standins():
     m.BGZFile = pybam.BGZFile
     m.__version__ = "0.0-standin"
     sys.modules["pysam"] = m
-    sys.modules["anndata"] = types.ModuleType("anndata")
+    import anndata_standin                                    # minimal AnnData: only the local-phasing path touches it
+    a = types.ModuleType("anndata")
+    a.AnnData = anndata_standin.AnnData
+    sys.modules["anndata"] = a
 
 
 def main():

@@ -336,6 +336,8 @@ static void baf_regions(const xck_config *cf, const snp_plp *plp, const int *sid
             const xck_snp *sn = &cf->snps[s];
             if (sn->contig != rg->contig || sn->pos > rg->end) break;
             if (plp[s].filtered) continue;
+            /* SNPs that region-wise local phasing dropped from THIS region's list (baf/fc/phasing.py:44-49) */
+            { int skip = 0; for (int x = 0; x < cf->n_excl_pairs; x++) if (cf->excl_region[x] == g && cf->excl_snp[x] == s) { skip = 1; break; } if (skip) continue; }
             for (int64_t k = 0; k < plp[s].n; k++) {
                 const cua_t *u = &plp[s].e[k];
                 if (u->allele < 0) continue;

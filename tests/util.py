@@ -130,7 +130,31 @@ def oracle_params(case):
         p["min_include"] = kw.get("min_include", 0.9)
     else:
         p.update(min_count=kw.get("min_count", 1), min_maf=kw.get("min_maf", 0), no_dup_hap=kw.get("no_dup_hap", True))
+        if kw.get("cellsnp_dir"):
+            p["phase"] = phase_from_cellsnp(kw["cellsnp_dir"], kw.get("ref_cell_fn"), p["output_all_reg"])
     return p
+
+
+def phase_from_cellsnp(cellsnp_dir, ref_cell_fn, output_all_reg):
+    """Region-wise local phasing for the oracle runs: the product's HOST code (xcltk_amd/baf/fc/phasing.py - float64 numpy,
+    no GPU) decides the final haplotype indices and the dropped (region, SNP) pairs; the oracle then does the counting.
+    Against the reference's golden outputs this pins that host code on machines without a GPU."""
+    from xcltk_amd.baf.fc.main import regions_with_snps
+    from xcltk_amd.baf.fc.phasing import local_phasing
+    from xcltk_amd.utils.csp_io import load_data
+
+    def phase(regions, snps):
+        csp = load_data(cellsnp_dir)
+        ref_cells = None
+        if ref_cell_fn:
+            with open(ref_cell_fn) as fp:
+                ref_cells = [x.strip() for x in fp if x.strip()]
+        has = regions_with_snps(regions, snps)
+        idx = list(range(len(regions))) if output_all_reg else [i for i, h in enumerate(has) if h]
+        rh, ah, er, es, _ = local_phasing([regions[i] for i in idx], snps, csp, ref_cells)
+        snps2 = [(s[0], s[1], s[2], s[3], int(r), int(a)) for s, r, a in zip(snps, rh.tolist(), ah.tolist())]
+        return snps2, (np.array([idx[i] for i in er.tolist()], dtype=np.int32), es)
+    return phase
 
 
 def assert_dirs_equal(got_dir, exp_dir):

@@ -5,9 +5,10 @@ produces xcltk.region.tsv, xcltk.samples.tsv, xcltk.{AD,DP,OTH}.mtx (:373-379). 
 pysam pileup of plp_snp()/fc_fet1() (baf/fc/core.py:143-247) runs as HIP kernels
 (csrc/engine.hip) behind the C-ABI of include/xck.h.
 
-Not implemented (out of the hot path): region-wise local
-phasing from cellsnp-lite matrices (`cellsnp_dir`, baf/fc/main.py:107-153).  When it is
-requested a warning is logged and the SNP phase is used as given.
+Region-wise local phasing from a cellsnp-lite pileup (`cellsnp_dir` / `ref_cell_fn`,
+baf/fc/main.py:107-153) runs on the host before the counting (baf/fc/phasing.py, baf/localphase.py):
+it changes the haplotype index of SNP alleles and drops uncovered SNPs from region lists; the
+engine then counts with that phase.
 """
 
 import os
@@ -16,8 +17,11 @@ import time
 from logging import error, info
 from logging import warning as warn
 
+import numpy as np
+
 from ... import fc_common as fcc
 from ...capi import XCK_MODE_BAF
+from ...engine import XckError
 from .config import Config
 
 
@@ -76,8 +80,43 @@ def prepare_config(conf):
         error("failed to load snp file.")
         return -1
     info("%d SNPs loaded." % len(conf.snp_list))
+    conf.snp_csp, conf.ref_cells = None, None
     if conf.cellsnp_dir is not None:
-        warn("local phasing from '%s' is not implemented by this engine; using the given phase." % conf.cellsnp_dir)
+        # the per-SNP x cell pileup that local phasing works on (baf/fc/main.py:419-454)
+        from ...utils.csp_io import load_data as csp_load_data
+        from ...utils.grange import format_chrom
+        if not os.path.isdir(conf.cellsnp_dir):
+            error("cellsnp dir '%s' does not exist." % conf.cellsnp_dir)
+            return -1
+        try:
+            csp = csp_load_data(conf.cellsnp_dir)
+        except (IOError, OSError, ValueError) as e:
+            error("failed to load cellsnp dir '%s': %s" % (conf.cellsnp_dir, e))
+            return -1
+        info("cellsnp SNP adata shape = %s." % str(csp.shape))
+        if len(conf.samples) != csp.shape[0] or not set(conf.samples) <= set(csp.cells):
+            error("cells of the cellsnp pileup do not match the barcodes / sample IDs.")
+            return -1
+        if csp.shape[1] != len(conf.snp_list):
+            warn("n_snp: snp_adata=%d; snp_set=%d!" % (csp.shape[1], len(conf.snp_list)))
+            if csp.shape[1] < len(conf.snp_list):
+                error("the cellsnp pileup holds fewer SNPs than the phased SNP list.")
+                return -1
+        known = set((s[0], s[1]) for s in conf.snp_list)
+        keep = [i for i in range(csp.shape[1]) if (format_chrom(str(csp.chrom[i])), int(csp.pos[i])) in known]
+        if len(keep) < csp.shape[1]:                          # SNPs that were filtered in phasing
+            csp = csp.subset_snps(keep)
+            info("SNP adata shape after subset: %s." % str(csp.shape))
+        conf.snp_csp = csp
+    if conf.ref_cell_fn is not None:
+        if not os.path.isfile(conf.ref_cell_fn):
+            error("ref cell file '%s' does not exist." % conf.ref_cell_fn)
+            return -1
+        with open(conf.ref_cell_fn) as fp:
+            conf.ref_cells = [x.rstrip("\n").split("\t")[0] for x in fp if x.strip()]
+        if len(conf.ref_cells) > len(conf.samples) or not set(conf.ref_cells) <= set(conf.samples):
+            error("reference cells are not a subset of the barcodes / sample IDs.")
+            return -1
     if fcc.resolve_tags(conf) < 0:
         return -1
     if fcc.is_writer_rank():
@@ -117,7 +156,23 @@ def afc_core(conf):
     regions, snps = conf.reg_list, conf.snp_list
     has_snp = regions_with_snps(regions, snps)
     info("#regions: total=%d; with_snps=%d." % (len(regions), sum(has_snp)))
-    eng = fcc.make_engine(conf, XCK_MODE_BAF, regions, snps)
+    excl = None
+    if conf.use_local_phasing():
+        # region-wise local phasing (baf/fc/main.py:107-153): new haplotype indices for flipped SNPs, and the SNPs without
+        # coverage in the pileup leave the SNP list of the region that was phased
+        from .phasing import local_phasing
+        from ...snptable import SnpTable
+        phase_regions = regions if conf.output_all_reg else [r for r, h in zip(regions, has_snp) if h]
+        phase_index = list(range(len(regions))) if conf.output_all_reg else [i for i, h in enumerate(has_snp) if h]
+        rh, ah, ex_r, ex_s, _ = local_phasing(phase_regions, snps, conf.snp_csp, conf.ref_cells, conf.debug)
+        ex_r = np.array([phase_index[i] for i in ex_r.tolist()], dtype=np.int32)
+        if isinstance(snps, SnpTable):
+            snps = SnpTable(snps.names, snps.chrom_id, snps.pos, snps.ref, snps.alt, rh, ah)
+        else:
+            snps = [(s[0], s[1], s[2], s[3], int(r), int(a)) for s, r, a in zip(snps, rh.tolist(), ah.tolist())]
+        excl = (ex_r, ex_s)
+        conf.snp_csp = conf.ref_cells = None
+    eng = fcc.make_engine(conf, XCK_MODE_BAF, regions, snps, excl_pairs=excl)
     try:
         coo, dist = fcc.count_all(eng, conf)
         if coo is not None:                               # rank 0 (or the only process) writes
@@ -146,7 +201,7 @@ def afc_run(conf):
         info("CMD: %s" % cmdline)
     try:
         afc_core(conf)
-    except ValueError as e:
+    except (ValueError, XckError) as e:
         error(str(e))
         error("Running program failed.")
         error("Quiting ...")

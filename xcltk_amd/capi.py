@@ -52,6 +52,7 @@ class Config(C.Structure):
         ("barcodes", C.POINTER(C.c_char_p)),
         ("cell_tag", C.c_char * 4), ("umi_tag", C.c_char * 4),
         ("max_batch_reads", C.c_int64), ("n_threads", C.c_int32), ("flags", C.c_int32),
+        ("n_excl_pairs", C.c_int32), ("excl_region", C.POINTER(C.c_int32)), ("excl_snp", C.POINTER(C.c_int32)),
     ]
 
 
@@ -183,7 +184,7 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.xck_abi_version() != 1:
+    if lib.xck_abi_version() != 2:
         raise XckLibraryError("ABI mismatch")
     if path is None:
         _lib = lib

@@ -1,5 +1,6 @@
 // api.cpp - C-ABI entry points of libxck.so (include/xck.h) except the BAM functions (bam.cpp).
 #include <hip/hip_runtime_api.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -26,10 +27,14 @@ int xck_device_count(void) {
 
 const char* xck_last_error(const xck_engine* e) { return e ? e->err.c_str() : get_thread_error(); }
 
-int xck_create(const xck_config* cfg, xck_engine** out) {
-    if (!cfg || !out) { set_thread_error("null argument"); return XCK_E_ARG; }
+int xck_create(const xck_config* cfg_in, xck_engine** out) {
+    if (!cfg_in || !out) { set_thread_error("null argument"); return XCK_E_ARG; }
     *out = nullptr;
-    if (cfg->struct_size != sizeof(xck_config)) { set_thread_error("xck_config.struct_size mismatch (ABI)"); return XCK_E_ARG; }
+    // ABI 1 structs (without the exclusion pairs) are accepted: the missing tail reads as zero
+    if (cfg_in->struct_size != offsetof(xck_config, n_excl_pairs) && cfg_in->struct_size != sizeof(xck_config)) { set_thread_error("xck_config.struct_size mismatch (ABI)"); return XCK_E_ARG; }
+    xck_config cfg_full; memset(&cfg_full, 0, sizeof cfg_full); memcpy(&cfg_full, cfg_in, cfg_in->struct_size); cfg_full.struct_size = sizeof(xck_config);
+    const xck_config* cfg = &cfg_full;
+    if (cfg->n_excl_pairs < 0 || (cfg->n_excl_pairs > 0 && (!cfg->excl_region || !cfg->excl_snp))) { set_thread_error("invalid exclusion pairs"); return XCK_E_ARG; }
     if (cfg->mode != XCK_MODE_BASEFC && cfg->mode != XCK_MODE_BAF && cfg->mode != XCK_MODE_BOTH) { set_thread_error("invalid mode"); return XCK_E_ARG; }
     if (cfg->n_cells <= 0 || cfg->n_contigs < 0 || cfg->n_regions < 0 || cfg->n_snps < 0) { set_thread_error("invalid table sizes"); return XCK_E_ARG; }
     if ((cfg->n_regions > 0 && !cfg->regions) || (cfg->n_snps > 0 && !cfg->snps)) { set_thread_error("null table pointer"); return XCK_E_ARG; }
@@ -73,6 +78,7 @@ int xck_create(const xck_config* cfg, xck_engine** out) {
 void xck_destroy(xck_engine* e) {
     if (!e) return;
     for (int k = 0; k < e->n_impl; k++) { e->impl = e->impls[k]; engine_destroy(e); }
+    if (e->stager) engine_release_staging(e);
     delete e;
 }
 int xck_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }

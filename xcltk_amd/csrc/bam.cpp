@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <cstring>
@@ -276,10 +277,14 @@ using namespace xck;
 // ---------------------------------------------------------------------------------------------
 // the BAM file object
 // ---------------------------------------------------------------------------------------------
+// One decoded chunk as structure-of-arrays, all columns carved out of ONE pinned block: the whole chunk crosses PCIe in a
+// single hipMemcpyAsync (engine_push_block) and the batches of the chunk are slices of it.  Three blocks rotate, so the
+// decoder fills block i + 1 while block i is still being copied; `fence` (an event owned by this block, recorded by the
+// engine behind the copy) is waited for before the block is overwritten.
 struct HostSoA {
+    uint8_t* base = nullptr; size_t cap = 0, used = 0; bool pinned = false; void* fence = nullptr;
     int32_t* pos = nullptr; uint16_t* flag = nullptr; uint8_t* mapq = nullptr; int32_t* cell = nullptr; uint64_t* umi = nullptr;
     uint32_t* cig_off = nullptr; uint32_t* cigar = nullptr; uint32_t* seq_off = nullptr; uint8_t* seq = nullptr;
-    size_t cap_reads = 0, cap_cig = 0, cap_seq = 0; bool pinned = false;
 };
 
 struct RecRef { const uint8_t* p; uint32_t len; int32_t tid; uint32_t l_seq; uint16_t n_cig; };
@@ -287,71 +292,135 @@ struct RecRef { const uint8_t* p; uint32_t len; int32_t tid; uint32_t l_seq; uin
 // Records found by one inflate task in its own byte range, walked right after inflating (data
 // still hot in that core's cache) under the SPECULATION that a record starts at the first byte of
 // the range - true for BGZF writers that flush a block before a record that would not fit (htslib,
-// samtools, this repo's writers).  The serial stitch keeps a part only if the previous part ended
-// exactly at its start; otherwise that range is re-walked serially from the true offset.
-struct WalkPart { size_t u_begin = 0, u_end = 0, spec_start = 0, stop = 0; std::vector<RecRef> recs; };
+// samtools, this repo's writers).  The task also sums up what its records need in the SoA (kept records, CIGAR words,
+// sequence bytes) and notes where the contig changes, so that when every speculation of a chunk holds the output layout
+// is a prefix sum over the parts and each part is parsed by its own task; otherwise the stitch re-walks serially.
+struct ContigRun { uint32_t first; int32_t contig; };                    // records [first, next run's first) of the part are on `contig` (-1: unused)
+struct WalkPart {
+    size_t u_begin = 0, u_end = 0, spec_start = 0, stop = 0; std::vector<RecRef> recs;
+    size_t n_out = 0, n_cig = 0, n_seq = 0; std::vector<ContigRun> runs;
+    size_t out_base = 0, cig_base = 0, seq_base = 0;                      // filled by the coordinator (fast path)
+};
 
 struct Chunk {
     std::vector<BlockRef> blocks;
     std::vector<uint8_t> ubuf; size_t usize = 0;
     std::vector<WalkPart> parts;
     TaskGroup tg; std::atomic<bool> failed{false}; std::string err; std::mutex emu;
-    bool valid = false;
+    bool valid = false, new_range = false; uint32_t first_skip = 0;
 };
 
 struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
 
+// where the ingest time goes (XCK_DEBUG_TIMING=1 prints it when the reader is closed): pool-side CPU time summed over
+// threads, and the phases of the coordinating thread
+struct DecodeTimes {
+    std::atomic<uint64_t> inflate{0}, walk{0}, parse{0};                 // ns, summed over pool threads
+    uint64_t wait_inflate = 0, sched = 0, stitch = 0, layout = 0, wait_parse = 0, push = 0;   // ns, coordinating thread
+    uint64_t chunks = 0, slow_chunks = 0; std::chrono::steady_clock::time_point t_open;
+};
+static inline uint64_t ns_since(std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+
+// The BGZF block headers form a chain (every header gives the offset of the next one): a scanner thread walks it ahead of
+// the decoder - it also takes the page faults of the mapping - and hands over one plan per chunk.
+struct ChunkPlan { std::vector<BlockRef> blocks; size_t usize = 0; uint32_t first_skip = 0; bool new_range = false, failed = false, end = false; std::string err; };
+struct ScanRange { uint64_t coff; uint32_t skip; uint64_t stop; };
+class Scanner {
+public:
+    Scanner(const uint8_t* map, uint64_t fsize, size_t chunk_target, std::vector<ScanRange> ranges)
+        : map_(map), fsize_(fsize), target_(chunk_target), ranges_(std::move(ranges)) { th_ = std::thread([this] { run(); }); }
+    ~Scanner() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+    ChunkPlan next() {                                                  // blocks until a plan is ready; `end` after the last chunk
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        ChunkPlan p = std::move(q_.front()); q_.pop_front();
+        lk.unlock(); cv_.notify_all();
+        return p;
+    }
+private:
+    bool put(ChunkPlan&& p) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return stop_ || q_.size() < 3; });
+        if (stop_) return false;
+        q_.push_back(std::move(p)); lk.unlock(); cv_.notify_all();
+        return true;
+    }
+    void run() {
+        for (const ScanRange& rg : ranges_) {
+            uint64_t coff = rg.coff; bool first = true, ended = false;
+            while (!ended) {
+                ChunkPlan p; p.new_range = first; p.first_skip = first ? rg.skip : 0; first = false;
+                size_t usz = 0;
+                while (usz < target_) {
+                    if (coff > rg.stop) { ended = true; break; }          // end of the indexed range
+                    BlockRef br; std::string e;
+                    if (!bgzf_peek(map_, fsize_, coff, &br, &e)) { ended = true; if (!e.empty()) { p.failed = true; p.err = e; } break; }
+                    br.uoff = usz; usz += br.isize; coff += br.clen;
+                    p.blocks.push_back(br);
+                }
+                p.usize = usz;
+                if (p.blocks.empty() && !p.failed) { if (p.new_range) { /* an empty range: nothing to hand over */ } break; }
+                const bool failed = p.failed;
+                if (!put(std::move(p))) return;
+                if (failed) { ChunkPlan z; z.end = true; put(std::move(z)); return; }
+            }
+        }
+        ChunkPlan z; z.end = true; put(std::move(z));
+    }
+    const uint8_t* map_; uint64_t fsize_; size_t target_; std::vector<ScanRange> ranges_;
+    std::thread th_; std::mutex mu_; std::condition_variable cv_; std::deque<ChunkPlan> q_; bool stop_ = false;
+};
+
+constexpr int N_CHUNK = 3, N_SOA = 3;
 struct xck_bam {
     std::string path; int fd = -1; const uint8_t* map = nullptr; uint64_t fsize = 0;
     std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
-    uint64_t next_coff = 0;            // next BGZF block to schedule
-    uint64_t stop_coff = ~0ull;        // last block (file offset) of the virtual-offset range being decoded
+    uint64_t next_coff = 0;            // first BGZF block with alignment records
     // .bai: per reference [beg, end) virtual offsets + record counts (samtools pseudo-bin 37450 or bin chunks)
     bool idx_loaded = false, idx_ok = false;
     std::vector<uint64_t> idx_beg, idx_end; std::vector<int64_t> idx_mapped, idx_unmapped;
-    std::vector<std::pair<uint64_t, uint64_t>> ranges; size_t range_i = 0; bool use_ranges = false, ranges_set = false;
-    uint32_t first_skip = 0;           // bytes of the first scheduled block that precede the first record
-    uint32_t stitch_skip = 0;          // same value, consumed by the first stitch
-    bool eof_sched = false;
+    std::vector<std::pair<uint64_t, uint64_t>> ranges; bool use_ranges = false, ranges_set = false;
+    uint32_t first_skip = 0;           // bytes of the first block that precede the first record
+    uint32_t stitch_skip = 0;          // same for the chunk being stitched
+    Scanner* scanner = nullptr; bool scan_end = false;
     Pool* pool = nullptr; int n_threads = 1;
-    Chunk ch[2]; int cur = 0; bool primed = false;
+    Chunk ch[N_CHUNK]; int head = 0, n_sched = 0;      // ring: ch[head] is decoded next, n_sched chunks are inflating / inflated
     std::vector<uint8_t> carry;        // partial record from the previous chunk
     std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
-    std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // walk output
-    HostSoA soa;
+    std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // serial walk output (slow path)
+    HostSoA soa[N_SOA]; int soa_i = 0;                 // soa[soa_i] holds the chunk decoded last
     std::deque<PendingBatch> pending;
     int64_t n_records = 0;             // records walked so far (all, including unused contigs)
     bool done = false;
     size_t chunk_target = 48u << 20;   // uncompressed bytes per chunk
+    DecodeTimes tm;
     std::string err;
 };
 
 static void soa_free(HostSoA& s) {
-    void* p[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.cigar, s.seq_off, s.seq };
-    for (void* q : p) if (q) { if (s.pinned) pinned_free(q); else free(q); }
+    if (s.fence) { fence_wait(s.fence); fence_destroy(s.fence); }
+    if (s.base) { if (s.pinned) pinned_free(s.base); else free(s.base); }
     s = HostSoA();
 }
-static void* soa_alloc(HostSoA& s, size_t bytes, bool first) {
-    if (first) { void* p = pinned_alloc(bytes); if (p) { s.pinned = true; return p; } s.pinned = false; return malloc(bytes); }
-    return s.pinned ? pinned_alloc(bytes) : malloc(bytes);
-}
+// carve the columns of a chunk with n_reads kept records out of the block (growing it if needed)
 static bool soa_reserve(HostSoA& s, size_t n_reads, size_t n_cig, size_t n_seq) {
-    bool first = s.pos == nullptr && s.cigar == nullptr && s.seq == nullptr;
-    if (n_reads > s.cap_reads) {
-        size_t c = std::max(n_reads, s.cap_reads * 3 / 2);
-        void* old[] = { s.pos, s.flag, s.mapq, s.cell, s.umi, s.cig_off, s.seq_off };
-        for (void* q : old) if (q) { if (s.pinned) pinned_free(q); else free(q); }
-        s.pos = (int32_t*)soa_alloc(s, c * 4, first); first = false;
-        s.flag = (uint16_t*)soa_alloc(s, c * 2, false); s.mapq = (uint8_t*)soa_alloc(s, c, false);
-        s.cell = (int32_t*)soa_alloc(s, c * 4, false); s.umi = (uint64_t*)soa_alloc(s, c * 8, false);
-        s.cig_off = (uint32_t*)soa_alloc(s, (c + 1) * 4, false); s.seq_off = (uint32_t*)soa_alloc(s, (c + 1) * 4, false);
-        s.cap_reads = c;
-        if (!s.pos || !s.flag || !s.mapq || !s.cell || !s.umi || !s.cig_off || !s.seq_off) return false;
+    auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t o_umi = 0, o_pos = o_umi + up(n_reads * 8), o_cell = o_pos + up(n_reads * 4), o_cgo = o_cell + up(n_reads * 4),
+                 o_sqo = o_cgo + up((n_reads + 1) * 4), o_cig = o_sqo + up((n_reads + 1) * 4), o_flag = o_cig + up(n_cig * 4),
+                 o_mapq = o_flag + up(n_reads * 2), o_seq = o_mapq + up(n_reads), total = o_seq + up(n_seq);
+    if (total > s.cap) {
+        if (s.fence) fence_wait(s.fence);
+        if (s.base) { if (s.pinned) pinned_free(s.base); else free(s.base); }
+        const size_t c = total + total / 4;
+        s.base = (uint8_t*)pinned_alloc(c); s.pinned = s.base != nullptr;
+        if (!s.base) s.base = (uint8_t*)malloc(c);
+        if (!s.base) { s.cap = 0; return false; }
+        s.cap = c;
     }
-    if (n_cig > s.cap_cig) { size_t c = std::max(n_cig, s.cap_cig * 3 / 2); if (s.cigar) { if (s.pinned) pinned_free(s.cigar); else free(s.cigar); }
-        s.cigar = (uint32_t*)soa_alloc(s, c * 4, first); first = false; s.cap_cig = c; if (!s.cigar) return false; }
-    if (n_seq > s.cap_seq) { size_t c = std::max(n_seq, s.cap_seq * 3 / 2); if (s.seq) { if (s.pinned) pinned_free(s.seq); else free(s.seq); }
-        s.seq = (uint8_t*)soa_alloc(s, c, first); s.cap_seq = c; if (!s.seq) return false; }
+    s.used = total;
+    s.umi = (uint64_t*)(s.base + o_umi); s.pos = (int32_t*)(s.base + o_pos); s.cell = (int32_t*)(s.base + o_cell);
+    s.cig_off = (uint32_t*)(s.base + o_cgo); s.seq_off = (uint32_t*)(s.base + o_sqo); s.cigar = (uint32_t*)(s.base + o_cig);
+    s.flag = (uint16_t*)(s.base + o_flag); s.mapq = s.base + o_mapq; s.seq = s.base + o_seq;
     return true;
 }
 
@@ -375,7 +444,7 @@ struct SeqReader {
 // pinned SoA arrays (hipHostMalloc pins page by page), the two inflate buffers, the record index, the thread pool - cost
 // ~30 ms to set up, twice the decode time of a 500 k-read file: closed readers park them here for the next open.
 struct BamScratch {
-    HostSoA soa; std::vector<uint8_t> ubuf[2]; std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;
+    HostSoA soa[N_SOA]; std::vector<uint8_t> ubuf[N_CHUNK]; std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;
     Pool* pool = nullptr; int n_threads = 0;
 };
 static std::mutex g_scratch_mu;
@@ -415,10 +484,12 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
     else { b->next_coff = r.blk_coff; b->first_skip = (uint32_t)(r.pos - r.blk_start); }
     if (n_threads <= 0) n_threads = default_threads();
     b->n_threads = n_threads;
+    b->tm.t_open = std::chrono::steady_clock::now();
     { BamScratch* sc = nullptr;
       { std::lock_guard<std::mutex> lk(g_scratch_mu); if (!g_scratch.empty()) { sc = g_scratch.back(); g_scratch.pop_back(); } }
       if (sc) {
-          b->soa = sc->soa; b->ch[0].ubuf.swap(sc->ubuf[0]); b->ch[1].ubuf.swap(sc->ubuf[1]);
+          for (int i = 0; i < N_SOA; i++) b->soa[i] = sc->soa[i];
+          for (int i = 0; i < N_CHUNK; i++) b->ch[i].ubuf.swap(sc->ubuf[i]);
           b->recs.swap(sc->recs); b->rec_contig.swap(sc->rec_contig); b->rec_out.swap(sc->rec_out);
           if (sc->pool && sc->n_threads == n_threads) b->pool = sc->pool; else delete sc->pool;
           delete sc;
@@ -431,14 +502,25 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
 
 void xck_bam_close(xck_bam* b) {
     if (!b) return;
+    delete b->scanner; b->scanner = nullptr;
     for (auto& c : b->ch) c.tg.wait();
+    for (auto& so : b->soa) if (so.fence) fence_wait(so.fence);            // no H2D copy may still read a block that is parked or freed
+    if (getenv("XCK_DEBUG_TIMING") && b->tm.chunks) {
+        const DecodeTimes& t = b->tm; const double ms = 1e-6;
+        fprintf(stderr, "[xck] ingest %s: %lld records, %llu chunks (%llu stitched serially), %.0f ms since open, %d threads | pool CPU ms: inflate %.0f walk %.0f parse %.0f | "
+                        "coordinator ms: wait_inflate %.0f schedule %.0f stitch %.0f layout %.0f wait_parse %.0f push %.0f\n",
+                b->path.c_str(), (long long)b->n_records, (unsigned long long)t.chunks, (unsigned long long)t.slow_chunks, ns_since(t.t_open) * ms, b->n_threads,
+                t.inflate.load() * ms, t.walk.load() * ms, t.parse.load() * ms,
+                t.wait_inflate * ms, t.sched * ms, t.stitch * ms, t.layout * ms, t.wait_parse * ms, t.push * ms);
+    }
     { BamScratch* sc = new BamScratch();
-      sc->soa = b->soa; b->soa = HostSoA(); sc->ubuf[0].swap(b->ch[0].ubuf); sc->ubuf[1].swap(b->ch[1].ubuf);
+      for (int i = 0; i < N_SOA; i++) { sc->soa[i] = b->soa[i]; b->soa[i] = HostSoA(); }
+      for (int i = 0; i < N_CHUNK; i++) sc->ubuf[i].swap(b->ch[i].ubuf);
       sc->recs.swap(b->recs); sc->rec_contig.swap(b->rec_contig); sc->rec_out.swap(b->rec_out);
       sc->pool = b->pool; sc->n_threads = b->n_threads; b->pool = nullptr;
       std::lock_guard<std::mutex> lk(g_scratch_mu);
       if (g_scratch.size() < 4) g_scratch.push_back(sc);
-      else { delete sc->pool; soa_free(sc->soa); delete sc; } }
+      else { delete sc->pool; for (auto& so : sc->soa) soa_free(so); delete sc; } }
     if (b->map) munmap((void*)b->map, b->fsize);
     if (b->fd >= 0) close(b->fd);
     delete b;
@@ -496,47 +578,41 @@ static void set_ranges(xck_bam* b, const xck_ingest_opts* o) {
         if (o->tid_to_contig[t] >= 0 && b->idx_beg[t] != ~0ull && b->idx_end[t] > b->idx_beg[t]) rg.push_back({b->idx_beg[t], b->idx_end[t]});
     std::sort(rg.begin(), rg.end());
     for (auto& x : rg) { if (!b->ranges.empty() && (x.first >> 16) <= (b->ranges.back().second >> 16) + 1) b->ranges.back().second = std::max(b->ranges.back().second, x.second); else b->ranges.push_back(x); }
-    b->use_ranges = true; b->range_i = 0;
+    b->use_ranges = true;
 }
 
-// position the chunk pipeline at the start of the next range; false when no range is left
-static bool begin_range(xck_bam* b) {
-    if (b->range_i >= b->ranges.size()) return false;
-    auto rg = b->ranges[b->range_i++];
-    b->next_coff = rg.first >> 16; b->first_skip = (uint32_t)(rg.first & 0xffff); b->stop_coff = rg.second >> 16;
-    b->eof_sched = false; b->primed = false; b->carry.clear();
-    return true;
-}
-
-// schedule the inflate of the next chunk into c (asynchronous)
-static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc) {
-    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear();
-    if (b->eof_sched) return;
-    uint64_t coff = b->next_coff; size_t usz = 0;
-    while (usz < b->chunk_target) {
-        if (coff > b->stop_coff) { b->eof_sched = true; break; }          // end of the indexed range
-        BlockRef br; std::string e;
-        if (!bgzf_peek(b->map, b->fsize, coff, &br, &e)) { b->eof_sched = true; if (!e.empty()) { c.failed = true; c.err = e; } break; }
-        br.uoff = usz; usz += br.isize; coff += br.clen;
-        c.blocks.push_back(br);
-    }
-    b->next_coff = coff;
+// take the next plan from the scanner and start inflating it into c (asynchronous); tid_to_contig lets the walk tasks
+// prepare the output layout of their own records
+static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const int32_t* t2c, int n_refs, bool want_seq) {
+    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0;
+    if (b->scan_end) return;
+    ChunkPlan pl = b->scanner->next();
+    if (pl.end) { b->scan_end = true; return; }
+    c.blocks.swap(pl.blocks); c.new_range = pl.new_range; c.first_skip = pl.first_skip;
+    if (pl.failed) { c.failed = true; c.err = pl.err; }
     if (c.blocks.empty() && !c.failed) return;
-    c.valid = true; c.usize = usz;
+    c.valid = true; c.usize = pl.usize;
+    const size_t usz = pl.usize;
     if (c.ubuf.size() < usz + 8) c.ubuf.resize(usz + 8);
     const size_t nb = c.blocks.size();
     const size_t per = std::max<size_t>(1, (nb + (size_t)b->n_threads * 4 - 1) / ((size_t)b->n_threads * 4));
     const size_t n_parts = (nb + per - 1) / per;
     c.parts.resize(n_parts);
-    const size_t skip0 = b->first_skip;            // bytes before the first record (first chunk of the file only)
+    const size_t skip0 = c.first_skip;             // bytes before the first record (first chunk of the file / of an index range)
     for (size_t pi = 0; pi < n_parts; pi++) {
         size_t i0 = pi * per, i1 = std::min(nb, i0 + per);
         WalkPart& wp = c.parts[pi];
         wp.u_begin = c.blocks[i0].uoff; wp.u_end = c.blocks[i1 - 1].uoff + c.blocks[i1 - 1].isize;
         wp.spec_start = wp.u_begin + (pi == 0 ? skip0 : 0); wp.stop = wp.spec_start; wp.recs.clear();
-        Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp;
-        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp] {
+        wp.n_out = wp.n_cig = wp.n_seq = 0; wp.runs.clear();
+        Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp; DecodeTimes* tmp_ = &b->tm;
+        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp, tmp_, t2c, n_refs, want_seq] {
             if (!t_zs.ok) { cp->failed = true; return; }
+            const auto t_a = std::chrono::steady_clock::now();
+            struct Acc { DecodeTimes* t; std::chrono::steady_clock::time_point a, b; bool walked = false;
+                         ~Acc() { const auto e = std::chrono::steady_clock::now(); if (!walked) b = e;
+                                  t->inflate += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+                                  t->walk += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(e - b).count(); } } acc{tmp_, t_a, t_a};
             for (size_t i = i0; i < i1; i++) {
                 std::string e;
                 if (!bgzf_inflate(map, cp->blocks[i], cp->ubuf.data() + cp->blocks[i].uoff, verify_crc, &t_zs.zs, &e)) {
@@ -544,13 +620,19 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc) {
                 }
             }
             // speculative record walk over this range
+            acc.b = std::chrono::steady_clock::now(); acc.walked = true;
             const uint8_t* u = cp->ubuf.data(); size_t o = wpp->spec_start; const size_t end = wpp->u_end;
             if (o > end) { wpp->stop = o; return; }
+            int32_t cur_c = INT32_MIN;
             while (o + 4 <= end) {
                 uint32_t bs = le32(u + o);
                 if (bs < 32 || o + 4 + (size_t)bs > end) break;
                 const uint8_t* r = u + o + 4;
-                wpp->recs.push_back({r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)});
+                const RecRef rr{r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)};
+                const int32_t ctg = (rr.tid >= 0 && rr.tid < n_refs && t2c) ? t2c[rr.tid] : -1;
+                if (ctg != cur_c) { wpp->runs.push_back({(uint32_t)wpp->recs.size(), ctg}); cur_c = ctg; }
+                if (ctg >= 0) { wpp->n_out++; wpp->n_cig += rr.n_cig; if (want_seq) wpp->n_seq += (rr.l_seq + 1) / 2; }
+                wpp->recs.push_back(rr);
                 o += 4 + (size_t)bs;
             }
             wpp->stop = o;
@@ -574,16 +656,10 @@ static inline const uint8_t* aux_skip(const uint8_t* p, const uint8_t* e) {     
     return p <= e ? p : nullptr;
 }
 
-static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, int64_t r1, std::atomic<int>* flags) {
-    const DecodeCfg& dc = e->dec;
-    HostSoA& s = b->soa;
-    // UMI-less mode: every read name goes through the intern table - collected here, interned in one batch at the end
-    std::vector<InternTable::Item> names;
-    if (!dc.use_umi) names.reserve((size_t)(r1 - r0));
-    for (int64_t r = r0; r < r1; r++) {
-        int64_t o = b->rec_out[r];
-        if (o < 0) continue;
-        const uint8_t* p = b->recs[r].p; const uint8_t* end = p + b->recs[r].len;
+// one record -> SoA slot o (cig_off[o] / seq_off[o] are already set)
+static inline void parse_record(const DecodeCfg& dc, xck_engine* e, HostSoA& s, const uint8_t* p, uint32_t len, int64_t o, int32_t sample,
+                                std::vector<InternTable::Item>& names, std::atomic<int>* flags) {
+        const uint8_t* end = p + len;
         uint32_t l_name = p[8], n_cig = le16(p + 12), l_seq = le32(p + 16);
         s.pos[o] = (int32_t)le32(p + 4);
         s.mapq[o] = p[9];
@@ -591,7 +667,7 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
         const uint8_t* q = p + 32;
         const char* qname = (const char*)q; size_t qlen = l_name ? l_name - 1 : 0;
         q += l_name;
-        if (q + (size_t)n_cig * 4 + (l_seq + 1) / 2 + l_seq > end) { flags->fetch_or(1); s.cell[o] = -1; s.umi[o] = XCK_UMI_NONE; continue; }
+        if (q + (size_t)n_cig * 4 + (l_seq + 1) / 2 + l_seq > end) { flags->fetch_or(1); s.cell[o] = -1; s.umi[o] = XCK_UMI_NONE; return; }
         memcpy(s.cigar + s.cig_off[o], q, (size_t)n_cig * 4);
         q += (size_t)n_cig * 4;
         if (dc.want_seq) memcpy(s.seq + s.seq_off[o], q, (l_seq + 1) / 2);
@@ -638,6 +714,41 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
         else { names.push_back(InternTable::Item{InternTable::hash(qname, qlen), qname, (uint32_t)qlen, 0, &s.umi[o], dc.umi_bits}); key = XCK_UMI_NONE; }
         if (ovf) flags->fetch_or(2);
         s.umi[o] = key;
+}
+
+// slow path: records [r0, r1) of the serially stitched list (b->recs / b->rec_out)
+static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, int64_t r1, std::atomic<int>* flags) {
+    const auto t_parse0 = std::chrono::steady_clock::now();
+    struct PAcc { xck_bam* b; std::chrono::steady_clock::time_point t0; ~PAcc() { b->tm.parse += ns_since(t0); } } pacc{b, t_parse0};
+    const DecodeCfg& dc = e->dec;
+    HostSoA& s = b->soa[b->soa_i];
+    // UMI-less mode: every read name goes through the intern table - collected here, interned in one batch at the end
+    std::vector<InternTable::Item> names;
+    if (!dc.use_umi) names.reserve((size_t)(r1 - r0));
+    for (int64_t r = r0; r < r1; r++) {
+        const int64_t o = b->rec_out[r];
+        if (o < 0) continue;
+        parse_record(dc, e, s, b->recs[r].p, b->recs[r].len, o, sample, names, flags);
+    }
+    if (!names.empty()) { bool ovf = false; e->intern.intern_batch(names, &ovf); if (ovf) flags->fetch_or(2); }
+}
+
+// fast path: the records of one walk part, whose output slots start at the part's bases (prefix sums over the parts)
+static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart* wp, const int32_t* t2c, int n_refs, std::atomic<int>* flags) {
+    const auto t_parse0 = std::chrono::steady_clock::now();
+    struct PAcc { xck_bam* b; std::chrono::steady_clock::time_point t0; ~PAcc() { b->tm.parse += ns_since(t0); } } pacc{b, t_parse0};
+    const DecodeCfg& dc = e->dec;
+    HostSoA& s = b->soa[b->soa_i];
+    std::vector<InternTable::Item> names;
+    if (!dc.use_umi) names.reserve(wp->n_out);
+    int64_t o = (int64_t)wp->out_base; uint32_t co = (uint32_t)wp->cig_base, so = (uint32_t)wp->seq_base;
+    for (const RecRef& rr : wp->recs) {
+        const int32_t ctg = (rr.tid >= 0 && rr.tid < n_refs && t2c) ? t2c[rr.tid] : -1;
+        if (ctg < 0) continue;
+        s.cig_off[o] = co; s.seq_off[o] = so;
+        parse_record(dc, e, s, rr.p, rr.len, o, sample, names, flags);
+        co += rr.n_cig; if (dc.want_seq) so += (rr.l_seq + 1) / 2;
+        o++;
     }
     if (!names.empty()) { bool ovf = false; e->intern.intern_batch(names, &ovf); if (ovf) flags->fetch_or(2); }
 }
@@ -645,32 +756,97 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
+    const int n_refs = (int)b->ref_names.size();
     if (!b->ranges_set) {
         // well mode without UMIs: the key is the read name and the column is the BAM itself, so names only
         // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads)
         if (!e->dec.use_barcodes && !e->dec.use_umi) e->intern.clear();
-        set_ranges(b, o); if (b->use_ranges && !begin_range(b)) return 0;
+        set_ranges(b, o);
+        std::vector<ScanRange> rg;
+        if (b->use_ranges) for (auto& r : b->ranges) rg.push_back({r.first >> 16, (uint32_t)(r.first & 0xffff), r.second >> 16});
+        else rg.push_back({b->next_coff, b->first_skip, ~0ull});
+        b->scanner = new Scanner(b->map, b->fsize, b->chunk_target, rg);
     }
-    if (!b->primed) { schedule_chunk(b, b->ch[0], crc); b->stitch_skip = b->first_skip; b->first_skip = 0; b->cur = 0; b->primed = true; }
-    Chunk& c = b->ch[b->cur];
-    if (!c.valid && !c.failed) {
-        if (b->use_ranges) {                                           // this range is exhausted: move to the next one
-            b->ch[b->cur ^ 1].tg.wait();
-            if (!begin_range(b)) return 0;
-            return decode_next_chunk(e, b, o);
-        }
-        if (!b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
+    auto t_ph = std::chrono::steady_clock::now();
+    auto phase = [&](uint64_t& acc) { const auto now = std::chrono::steady_clock::now(); acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_ph).count(); t_ph = now; };
+    // keep the ring full: while this chunk is stitched and parsed the pool inflates the next two
+    while (b->n_sched < N_CHUNK && !b->scan_end) {
+        Chunk& nc = b->ch[(b->head + b->n_sched) % N_CHUNK];
+        schedule_chunk(b, nc, crc, o->tid_to_contig, n_refs, e->dec.want_seq);
+        if (b->scan_end) break;
+        b->n_sched++;
+    }
+    phase(b->tm.sched);
+    if (b->n_sched == 0) {
+        if (!b->use_ranges && !b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
         return 0;
     }
+    Chunk& c = b->ch[b->head];
     c.tg.wait();
+    phase(b->tm.wait_inflate); b->tm.chunks++;
     if (c.failed) { b->err = c.err.empty() ? "BGZF decode error" : c.err; return XCK_E_IO; }
-    // start inflating the following chunk while this one is walked and parsed
-    Chunk& nx = b->ch[b->cur ^ 1];
-    schedule_chunk(b, nx, crc);
-    // ---- stitch the per-task record lists (serial, cheap); re-walk only where the speculation failed ----
-    b->recs.clear(); b->rec_contig.clear();
-    const uint8_t* u = c.ubuf.data(); size_t usz = c.usize; size_t off = 0;
+    if (c.new_range) {                                                  // start of the file's records / of an index range
+        if (!b->use_ranges && b->tm.chunks > 1 && !b->carry.empty()) { b->err = "internal: carry at a range start"; return XCK_E_IO; }
+        b->carry.clear(); b->stitch_skip = c.first_skip;
+    }
+    const uint8_t* u = c.ubuf.data(); const size_t usz = c.usize; size_t off = 0;
     if (b->stitch_skip) { off = b->stitch_skip; b->stitch_skip = 0; if (off > usz) { b->err = "corrupt BAM header offset"; return XCK_E_IO; } }
+    // ---- fast path: no carried-over bytes, and every part's speculative walk began where the previous one ended ----
+    bool fast = b->carry.empty() && !(o->max_records > 0);
+    if (fast) {
+        size_t at = off;
+        for (size_t pi = 0; pi < c.parts.size() && fast; pi++) {
+            const WalkPart& wp = c.parts[pi];
+            if (wp.spec_start != at) fast = false;
+            at = wp.stop;
+            if (pi + 1 < c.parts.size() && wp.stop != wp.u_end) fast = false;      // a record straddles two parts
+        }
+        if (fast && at + 4 <= usz && le32(u + at) < 32) fast = false;              // not a straddling tail but a damaged record: the serial walk reports it
+    }
+    HostSoA& s = b->soa[(b->soa_i + 1) % N_SOA];
+    if (s.fence) fence_wait(s.fence);                                   // the H2D copy that last read this block has completed
+    b->soa_i = (b->soa_i + 1) % N_SOA;
+    b->pending.clear();
+    const uint64_t ord_hi = (uint64_t)(uint32_t)o->sample << ORD_REC_BITS;
+    std::atomic<int> flags{0};
+    int64_t limit = 0;
+    bool hit_limit = false;
+    if (fast) {
+        size_t n_out = 0, n_cig = 0, n_seq = 0, n_rec = 0;
+        for (WalkPart& wp : c.parts) { wp.out_base = n_out; wp.cig_base = n_cig; wp.seq_base = n_seq; n_out += wp.n_out; n_cig += wp.n_cig; n_seq += wp.n_seq; n_rec += wp.recs.size(); }
+        const WalkPart& last = c.parts.back();
+        if (last.stop < usz) b->carry.insert(b->carry.end(), u + last.stop, u + usz);
+        phase(b->tm.stitch);
+        if (n_cig >= (size_t(1) << 32) || n_seq >= (size_t(1) << 32)) { b->err = "chunk too large"; return XCK_E_IO; }
+        if (!soa_reserve(s, n_out + 1, n_cig + 1, e->dec.want_seq ? n_seq + 1 : 1)) { b->err = "out of host memory"; return XCK_E_NOMEM; }
+        s.cig_off[n_out] = (uint32_t)n_cig; s.seq_off[n_out] = (uint32_t)n_seq;
+        // batches = runs of records on one contig, across part boundaries
+        { int32_t cur_c = -1; int64_t seg0 = 0, seg_r = 0; int64_t rec0 = 0;
+          for (const WalkPart& wp : c.parts) {
+              int64_t oi = (int64_t)wp.out_base;
+              for (size_t ri = 0; ri < wp.runs.size(); ri++) {
+                  const ContigRun& rn = wp.runs[ri];
+                  const uint32_t nxt = ri + 1 < wp.runs.size() ? wp.runs[ri + 1].first : (uint32_t)wp.recs.size();
+                  if (rn.contig != cur_c) {
+                      if (cur_c >= 0 && oi > seg0) b->pending.push_back({cur_c, seg0, oi, ord_hi | (uint64_t)(b->n_records + seg_r)});
+                      cur_c = rn.contig; seg0 = oi; seg_r = rec0 + rn.first;
+                  }
+                  if (rn.contig >= 0) oi += nxt - rn.first;
+              }
+              rec0 += (int64_t)wp.recs.size();
+          }
+          if (cur_c >= 0 && (int64_t)n_out > seg0) b->pending.push_back({cur_c, seg0, (int64_t)n_out, ord_hi | (uint64_t)(b->n_records + seg_r)}); }
+        phase(b->tm.layout);
+        { TaskGroup tg; const int32_t smp = o->sample; const int32_t* t2c = o->tid_to_contig;
+          for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
+              tg.add(*b->pool, [b, e, smp, wpp, t2c, n_refs, &flags] { parse_part(b, e, smp, wpp, t2c, n_refs, &flags); }); }
+          tg.wait(); }
+        phase(b->tm.wait_parse);
+        limit = (int64_t)n_rec;
+    } else {
+    // ---- slow path: stitch the per-task record lists serially; re-walk where the speculation failed ----
+    b->tm.slow_chunks++;
+    b->recs.clear(); b->rec_contig.clear();
     b->stitch.clear();
     if (!b->carry.empty()) {
         b->stitch = b->carry; b->carry.clear();
@@ -682,7 +858,6 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             else { b->stitch.insert(b->stitch.end(), u + off, u + usz); off = usz; b->carry.swap(b->stitch); }   // record larger than a chunk
         } else { b->carry.swap(b->stitch); }
     }
-    const int n_refs = (int)b->ref_names.size();
     auto contig_of = [&](int32_t tid) { return (tid >= 0 && tid < n_refs && o->tid_to_contig) ? o->tid_to_contig[tid] : -1; };
     if (!b->stitch.empty()) {
         if (b->stitch.size() < 36) { b->err = "corrupt BAM record"; return XCK_E_IO; }
@@ -711,21 +886,20 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
           pi++;
       } }
     if (off < usz) b->carry.insert(b->carry.end(), u + off, u + usz);
+    phase(b->tm.stitch);
     b->rec_contig.resize(b->recs.size());
     for (size_t r = 0; r < b->recs.size(); r++) b->rec_contig[r] = contig_of(b->recs[r].tid);
     // ---- output layout: prefix sums + batch segmentation ----
     const int64_t nrec = (int64_t)b->recs.size();
-    int64_t limit = nrec;
+    limit = nrec;
     if (o->max_records > 0 && b->n_records + nrec > o->max_records) { limit = std::max<int64_t>(0, o->max_records - b->n_records); }
+    hit_limit = limit < nrec;
     b->rec_out.assign(nrec, -1);
     size_t n_out = 0, n_cig = 0, n_seq = 0;
     for (int64_t r = 0; r < limit; r++) if (b->rec_contig[r] >= 0) { n_out++; n_cig += b->recs[r].n_cig; n_seq += (b->recs[r].l_seq + 1) / 2; }
     if (n_cig >= (size_t(1) << 32) || n_seq >= (size_t(1) << 32)) { b->err = "chunk too large"; return XCK_E_IO; }
-    if (!soa_reserve(b->soa, n_out + 1, n_cig + 1, e->dec.want_seq ? n_seq + 1 : 1)) { b->err = "out of host memory"; return XCK_E_NOMEM; }
-    HostSoA& s = b->soa;
-    b->pending.clear();
+    if (!soa_reserve(s, n_out + 1, n_cig + 1, e->dec.want_seq ? n_seq + 1 : 1)) { b->err = "out of host memory"; return XCK_E_NOMEM; }
     { size_t oi = 0; uint32_t co = 0, so = 0; int32_t cur_c = -1; int64_t seg0 = 0, seg_r = 0;
-      const uint64_t ord_hi = (uint64_t)(uint32_t)o->sample << ORD_REC_BITS;
       s.cig_off[0] = 0; s.seq_off[0] = 0;
       for (int64_t r = 0; r < limit; r++) {
           int32_t ctg = b->rec_contig[r];
@@ -740,17 +914,19 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
       }
       if (cur_c >= 0 && (int64_t)oi > seg0) b->pending.push_back({cur_c, seg0, (int64_t)oi, ord_hi | (uint64_t)(b->n_records + seg_r)});
     }
+    phase(b->tm.layout);
     // ---- parse (parallel) ----
-    std::atomic<int> flags{0};
     { TaskGroup tg; const int64_t per = std::max<int64_t>(4096, (limit + b->n_threads * 4 - 1) / (b->n_threads * 4));
       for (int64_t r0 = 0; r0 < limit; r0 += per) { int64_t r1 = std::min(limit, r0 + per); int32_t smp = o->sample;
           tg.add(*b->pool, [b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }); }
       tg.wait(); }
+    phase(b->tm.wait_parse);
+    }
     if (flags.load() & 1) { b->err = "corrupt BAM record (fields exceed block_size)"; return XCK_E_IO; }
     if (flags.load() & 2) { b->err = "too many distinct non-ACGT keys for the key width"; return XCK_E_CAPACITY; }
     b->n_records += limit;
-    b->cur ^= 1;
-    if (limit < nrec) { b->done = true; nx.tg.wait(); }
+    b->head = (b->head + 1) % N_CHUNK; b->n_sched--;
+    if (hit_limit) { b->done = true; for (auto& cc : b->ch) cc.tg.wait(); }
     return 1;
 }
 
@@ -774,7 +950,7 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
         if (rc == 0) { b->done = true; return 0; }
     }
     PendingBatch pb = b->pending.front(); b->pending.pop_front();
-    HostSoA& s = b->soa;
+    HostSoA& s = b->soa[b->soa_i];
     memset(out, 0, sizeof *out);
     out->contig = pb.contig; out->n_reads = (int32_t)(pb.r1 - pb.r0); out->ordinal_base = pb.ordinal_base;
     out->pos = s.pos + pb.r0; out->flag = s.flag + pb.r0; out->mapq = s.mapq + pb.r0; out->cell = s.cell + pb.r0; out->umi = s.umi + pb.r0;
@@ -785,20 +961,38 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
 
 static int ingest_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) {
     if (!e || !b || !o) return XCK_E_ARG;
-    xck_batch bt;
-    int rc;
     const int64_t pause = o->struct_size >= offsetof(xck_ingest_opts, pause_records) + sizeof(int64_t) ? o->pause_records : 0;
     const int64_t start = b->n_records;
-    while ((rc = next_batch_impl(e, b, o, &bt)) == 1) {
-        int prc = xck::push_trusted(e, &bt);                  // fused handles feed both pipelines
-        if (prc) return prc;
-        if (pause > 0 && b->pending.empty() && !b->done && b->n_records - start >= pause) {   // chunk boundary: the reader stays positioned
+    std::vector<xck_batch> bts;
+    while (!b->done) {
+        int rc = decode_next_chunk(e, b, o);
+        if (rc < 0) { e->err = b->path + ": " + b->err; return rc; }
+        if (rc == 0) { b->done = true; break; }
+        if (e->n_impl > 0 && !b->pending.empty()) {            // (a decode-only handle decodes and discards: host-ingest benchmarks)
+            // the whole chunk crosses PCIe as ONE block; its batches are slices of the block (fused handles: both pipelines read the same copy)
+            const auto t_p = std::chrono::steady_clock::now();
+            HostSoA& s = b->soa[b->soa_i];
+            bts.clear();
+            for (const PendingBatch& pb : b->pending) {
+                xck_batch bt; memset(&bt, 0, sizeof bt);
+                bt.contig = pb.contig; bt.n_reads = (int32_t)(pb.r1 - pb.r0); bt.ordinal_base = pb.ordinal_base;
+                bt.pos = s.pos + pb.r0; bt.flag = s.flag + pb.r0; bt.mapq = s.mapq + pb.r0; bt.cell = s.cell + pb.r0; bt.umi = s.umi + pb.r0;
+                bt.cig_off = s.cig_off + pb.r0; bt.cigar = s.cigar;
+                if (e->dec.want_seq) { bt.seq_off = s.seq_off + pb.r0; bt.seq = s.seq; }
+                bts.push_back(bt);
+            }
+            const int prc = xck::engine_push_block(e, s.base, s.used, bts.data(), (int)bts.size(), &s.fence);
+            b->tm.push += ns_since(t_p);
+            if (prc) return prc;
+        }
+        b->pending.clear();
+        if (pause > 0 && !b->done && b->n_records - start >= pause) {   // chunk boundary: the reader stays positioned
             if (n_records) *n_records = b->n_records;
             return 1;
         }
     }
     if (n_records) *n_records = b->n_records;
-    return rc < 0 ? rc : XCK_OK;
+    return XCK_OK;
 }
 
 // C++ exceptions (std::bad_alloc from a buffer that a damaged file made huge, ...) must not unwind through the C ABI into

@@ -33,13 +33,6 @@
 namespace xck {
 
 typedef unsigned __int128 u128;
-#ifndef XCK_WS
-#define XCK_WS 15
-#endif
-#ifndef XCK_EXP
-#define XCK_EXP 0          // timing experiments only (wrong results): 1 no emit, 2 no fp64 divide, 4 no CIGAR re-walk, 8 no flush, 16 no join, 32 pileup: no SNP work, 64 pileup: count only
-#endif
-constexpr int WS = XCK_WS;             // window shift of the interval index (2^WS bp windows)
 #ifndef XCK_WS_SNP
 #define XCK_WS_SNP 10           // 1 kb: the first probe lands within a SNP or two of the read (32 kb windows needed a binary search per read)
 #endif
@@ -90,7 +83,7 @@ struct BatchDesc {
     const uint64_t* umi; const uint32_t* cig_off; const uint32_t* cigar;
     const uint32_t* seq_off; const uint8_t* seq;
     uint64_t ordinal_base;
-    const int32_t* win_off; int32_t n_win;                  // region window index of the batch's contig
+    int32_t reg_lo, reg_hi;                                 // regions of the batch's contig: [reg_lo, reg_hi) of the start-sorted arrays
     const int32_t* snp_win; int32_t n_swin; int32_t snp_end; // SNP window table of the batch's contig
 };
 constexpr int MAX_FUSE = 24;              // batches per fused launch (the table travels in the kernel arguments)
@@ -103,8 +96,8 @@ struct BatchTable { int32_t n_batches; int32_t n_tiles; BatchDesc desc[MAX_FUSE]
 // the join kernel's prologue is ONE load of this record plus ONE round of independent staging loads.
 struct TileMeta {
     uint32_t c_lo, cg_n;                  // CIGAR words of the tile: [c_lo, c_lo + cg_n) are staged
-    int32_t  w0, nw, e0, n_ent;           // basefc: staged windows [w0, w0+nw), their entries [e0, e0+n_ent)
-    int32_t  k0, nk;                      // pileup: staged SNPs [k0, k0+nk)
+    int32_t  w0, nw, e0, n_ent;           // basefc: staged regions [e0, e0 + n_ent) of the start-sorted arrays; pileup: staged SNP windows [w0, w0 + nw)
+    int32_t  k0, nk;                      // pileup: staged SNPs [k0, k0+nk); basefc: k0 = position of the tile's first read
     int32_t  b, r0, r1, pad;              // batch index, first / one-past-last read of the tile
 };
 
@@ -112,7 +105,8 @@ template <class K> struct JoinArgs {
     BatchTable bt;
     const TileMeta* meta;                 // [n_tiles]
     ReadFilter f;
-    const int32_t* win_s0; const int32_t* win_e0; const int32_t* win_row;   // region of every window-list entry
+    const int32_t* reg_s0; const int32_t* reg_e0; const int32_t* reg_row;   // regions per contig sorted by start (0-based half-open + output row)
+    const int32_t* reg_pmax;                                                 // running maximum of reg_e0 inside the contig
     const int32_t* snp_p0;
     KeyLayout<K> kl;
     K* keys; uint64_t* vals; unsigned long long cap;   // cap = capacity of ONE shard
@@ -153,7 +147,6 @@ __device__ __forceinline__ void frac_bounds(ReadInfo& r, double f) {
     r.m_acc = (int32_t)floor(p * (1.0 + 0x1p-50)) + 1;
 }
 __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double f) {
-    if (XCK_EXP & 2) return false;
     ReadInfo r = r0; frac_bounds(r, f);                               // only (read, region) pairs with a partial overlap get here
     if (m < r.m_rej) return true;
     if (m >= r.m_acc) return false;
@@ -226,8 +219,8 @@ template <class K, int MODE> struct JoinSmem {
     int32_t  st_a[ST_CAP], st_b[ST_CAP], st_c[ST_CAP];
     int32_t  st_w[ST_WIN + 1];
     uint32_t cg_lo, cg_n;                // staged CIGAR range [cg_lo, cg_lo + cg_n)
-    int32_t  w0, nw;                     // staged windows [w0, w0 + nw)          (basefc)
-    int32_t  k0, nk;                     // staged SNPs    [k0, k0 + nk)          (pileup)
+    int32_t  w0, nw;                     // basefc: staged regions [w0, w0 + nw) of the start-sorted arrays; pileup: staged SNP windows
+    int32_t  k0, nk;                     // pileup: staged SNPs [k0, k0 + nk); basefc: k0 = position of the tile's first read
     uint32_t count;                      // entries currently in the queue
     uint32_t wuor[2 * (JOIN_BLOCK / 64)];  // per-wave OR of the UMI codes
     uint32_t wcnt[JOIN_BLOCK / 64];
@@ -301,7 +294,7 @@ template <class K, int MODE>
 __device__ __forceinline__ int32_t included_len(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, const ReadInfo& r, int32_t s0, int32_t e0) {
     // both shortcuts need endpos to be the CIGAR's own end (an unmapped-flagged read with a CIGAR is fetched by its first base
     // only, yet its aligned positions are counted over the whole CIGAR)
-    if ((XCK_EXP & 4) || (r.span_is_cigar && r.pos >= s0 && r.endpos <= e0)) return r.n_al;
+    if (r.span_is_cigar && r.pos >= s0 && r.endpos <= e0) return r.n_al;
     // no D / N in the CIGAR (reference span == aligned length): the aligned bases are one block, no walk needed
     if (r.span_is_cigar && r.endpos - r.pos == r.n_al) return max(min(r.endpos, e0) - max(r.pos, s0), 0);
     int32_t p = r.pos, m = 0;
@@ -337,7 +330,6 @@ __device__ __forceinline__ uint32_t set_slot(unsigned long long kk) {
 
 template <class K, int MODE>
 __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, K key, uint64_t val) {
-    if (XCK_EXP & 1) return;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         constexpr int SLOTS = JoinSmem<K, MODE>::SLOTS;
         unsigned long long* set = sm.hkeys();
@@ -359,7 +351,6 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
 // no-base pileup hit (split mode): second LDS queue, spill straight to the second HBM stream
 template <class K, int MODE>
 __device__ __forceinline__ void emit_nobase(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, K key, uint64_t val) {
-    if (XCK_EXP & 1) return;
     const uint32_t idx = atomicAdd(&sm.ncount, 1u);
     if (idx < (uint32_t)JoinSmem<K, MODE>::NQCAP) { sm.nq_key[idx] = (uint64_t)key; sm.nq_val[idx] = val; }
     else {
@@ -397,7 +388,6 @@ __device__ __forceinline__ void flush_split(const JoinArgs<K>& a, JoinSmem<K, MO
 template <class K, int MODE>
 __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (XCK_EXP & 8) return;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = sm.hkeys();
         constexpr int PER_WAVE = JoinSmem<K, MODE>::SLOTS / (JOIN_BLOCK / 64);
@@ -460,32 +450,38 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
     }
 }
 
+// basefc: read x region interval join, region-major.  Regions are sorted by start inside the contig, the reads of a wave are
+// (in a sorted BAM) a narrow position range, so the whole wave walks ONE short list together: from the tile's first
+// candidate (first region whose running-maximum end lies beyond the tile's first position, k_tile_meta) up to the first
+// region that starts at or after the wave's largest read end.  Start, end and row of a region are wave-uniform (LDS
+// broadcast reads of the staged slice); each lane only compares its own read against them - no per-lane index lookups,
+// no divergent loop counts.  A wave that holds a read left of the tile's first read (unsorted input) scans from the
+// contig's first region, so sortedness is a speed assumption, never a correctness one.
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r) {
     uint32_t n_acc = 0;
-    int32_t w_lo = max(r.pos, 0) >> WS;                               // a record may start before the contig (pos -1 with a CIGAR)
-    if (w_lo >= d.n_win) return 0;
-    int32_t w_hi = min((r.endpos - 1) >> WS, d.n_win - 1);
-    for (int32_t w = w_lo; w <= w_hi; w++) {
-        const bool staged = (uint32_t)(w - sm.w0) < (uint32_t)sm.nw;
-        int32_t k0, k1;
-        if (staged) { k0 = sm.st_w[w - sm.w0]; k1 = sm.st_w[w - sm.w0 + 1]; }
-        else { k0 = as_global(d.win_off)[w]; k1 = as_global(d.win_off)[w + 1]; }
-        for (int32_t k = k0; k < k1; k++) {
-            int32_t s0, e0, row;
-            if (staged) { s0 = sm.st_a[k]; e0 = sm.st_b[k]; row = sm.st_c[k]; }
-            else { s0 = as_global(a.win_s0)[k]; e0 = as_global(a.win_e0)[k]; row = as_global(a.win_row)[k]; }
-            if (w != max(w_lo, s0 >> WS)) continue;                 // report each (read, region) pair once
-            if (!(r.pos < e0 && r.endpos > s0)) continue;           // htslib fetch overlap
-            int32_t m = included_len(a, d, sm, r, s0, e0);
-            if (a.f.frac_mode) {
-                if (r.n_al <= 0) continue;
-                // m == n gives exactly 1.0, never below a threshold in (0,1): skip the fp64 divide
-                if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue;   // IEEE double, as m / float(n)
-            } else if (m < a.f.min_inc_len) continue;
-            emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
-            n_acc++;
-        }
+    int32_t mx = r.ok ? r.endpos : INT32_MIN, mn = r.ok ? r.pos : INT32_MAX;
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) { mx = max(mx, __shfl_xor(mx, dd, 64)); mn = min(mn, __shfl_xor(mn, dd, 64)); }
+    if (mx == INT32_MIN) return 0;                                   // no read of this wave passed the filter (wave-uniform)
+    const int32_t lb = sm.w0, n_st = sm.nw;                           // staged slice: regions [lb, lb + n_st)
+    int32_t k = mn >= sm.k0 ? lb : d.reg_lo;                          // sm.k0 = position of the tile's first read
+    for (; k < d.reg_hi; k++) {
+        const uint32_t rel = (uint32_t)(k - lb);
+        const bool staged = rel < (uint32_t)n_st;
+        const int32_t s0 = __builtin_amdgcn_readfirstlane(staged ? sm.st_a[rel] : as_global(a.reg_s0)[k]);
+        if (s0 >= mx) break;                                        // sorted by start: nothing further can overlap
+        const int32_t e0 = __builtin_amdgcn_readfirstlane(staged ? sm.st_b[rel] : as_global(a.reg_e0)[k]);
+        if (!(r.ok && r.pos < e0 && r.endpos > s0)) continue;       // htslib fetch overlap
+        const int32_t m = included_len(a, d, sm, r, s0, e0);
+        if (a.f.frac_mode) {
+            if (r.n_al <= 0) continue;
+            // m == n gives exactly 1.0, never below a threshold in (0,1): skip the fp64 divide
+            if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue;   // IEEE double, as m / float(n)
+        } else if (m < a.f.min_inc_len) continue;
+        const int32_t row = staged ? sm.st_c[rel] : as_global(a.reg_row)[k];
+        emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
+        n_acc++;
     }
     return n_acc;
 }
@@ -569,7 +565,7 @@ __device__ __forceinline__ int nth_aligned_snp(const JoinArgs<K>& a, const Batch
 
 // one thread per tile: locate the batch, read the tile's extent, size the LDS staging
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __restrict__ out, const int32_t* __restrict__ rpmax) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= bt.n_tiles) return;
     int lo = 0, hi = bt.n_batches - 1;
@@ -580,15 +576,15 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     const uint32_t c_lo = as_global(d.cig_off)[m.r0], c_hi = as_global(d.cig_off)[m.r1];
     const int32_t p_first = max(as_global(d.pos)[m.r0], 0), p_last = max(as_global(d.pos)[m.r1 - 1], 0);
     m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
-    m.w0 = p_first >> (MODE == XCK_MODE_BASEFC ? WS : WSS); m.nw = 0; m.e0 = 0; m.n_ent = 0; m.k0 = 0; m.nk = 0;
+    m.w0 = p_first >> WSS; m.nw = 0; m.e0 = 0; m.n_ent = 0; m.k0 = 0; m.nk = 0;
     if (MODE == XCK_MODE_BASEFC) {
-        if (m.w0 < d.n_win && p_last >= p_first) {
-            int nw_max = min(min((p_last >> WS) + 1, d.n_win - 1) - m.w0 + 1, ST_WIN);
-            const int32_t e0 = as_global(d.win_off)[m.w0];
-            int a_ = 0, z_ = nw_max;                              // largest nw with entries <= ST_CAP (offsets are monotone)
-            while (a_ < z_) { int mid = (a_ + z_ + 1) >> 1; if (as_global(d.win_off)[m.w0 + mid] - e0 <= ST_CAP) a_ = mid; else z_ = mid - 1; }
-            m.nw = a_; m.e0 = e0; m.n_ent = as_global(d.win_off)[m.w0 + a_] - e0;
-        }
+        // first candidate region of the tile: the first one whose running-maximum end lies beyond the first read's position
+        // (every region before it ends at or before that position; reads further right cannot reach them either)
+        const int32_t p0 = as_global(d.pos)[m.r0];
+        int32_t lo = d.reg_lo, hi = d.reg_hi;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (as_global(rpmax)[mid] > p0) hi = mid; else lo = mid + 1; }
+        m.e0 = lo; m.n_ent = min(d.reg_hi - lo, ST_CAP); m.k0 = p0;
+        (void)p_last;
     } else {
         if (m.w0 < d.n_swin) { m.k0 = as_global(d.snp_win)[m.w0]; m.nk = min(d.snp_end - m.k0, ST_CAP); m.nw = min(d.n_swin - m.w0, ST_WIN); }
     }
@@ -621,7 +617,8 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         unsigned long long* set = sm.hkeys();                         // all ones = empty
         for (int s = tid; s < JoinSmem<K, MODE>::SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.w0 = w0; sm.nw = nw; sm.k0 = k0; sm.nk = nk; }
+    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.k0 = k0; sm.nk = nk;
+                    if (MODE == XCK_MODE_BASEFC) { sm.w0 = e0; sm.nw = n_ent; } else { sm.w0 = w0; sm.nw = nw; } }
     // Every global load of the prologue is issued BEFORE the first LDS store: written as load/store loops the
     // compiler waits (s_waitcnt vmcnt(0)) inside each iteration, which serialised ~7 HBM round trips per tile.
     static_assert(ST_CAP <= JOIN_BLOCK && ST_WIN + 1 <= JOIN_BLOCK, "staging assumes one element per thread");
@@ -631,10 +628,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; cw[q] = c < cg_n ? as_global(d.cigar)[c_lo + c] : 0u; }
     int32_t g_a = 0, g_b = 0, g_c = 0, g_w = 0;
     if (MODE == XCK_MODE_BASEFC) {
-        if (nw > 0) {
-            if (tid < n_ent) { g_a = as_global(a.win_s0)[e0 + tid]; g_b = as_global(a.win_e0)[e0 + tid]; g_c = as_global(a.win_row)[e0 + tid]; }
-            if (tid <= nw) g_w = as_global(d.win_off)[w0 + tid] - e0;
-        }
+        if (tid < n_ent) { g_a = as_global(a.reg_s0)[e0 + tid]; g_b = as_global(a.reg_e0)[e0 + tid]; g_c = as_global(a.reg_row)[e0 + tid]; }
     } else {
         if (tid < nk) g_a = as_global(a.snp_p0)[k0 + tid];
         if (tid < nw) g_w = as_global(d.snp_win)[w0 + tid];           // first SNP of each window
@@ -642,10 +636,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
 #pragma unroll
     for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; if (c < cg_n) sm.cig[c] = cw[q]; }
     if (MODE == XCK_MODE_BASEFC) {
-        if (nw > 0) {
-            if (tid <= nw) sm.st_w[tid] = g_w;
-            if (tid < n_ent) { sm.st_a[tid] = g_a; sm.st_b[tid] = g_b; sm.st_c[tid] = g_c; }
-        }
+        if (tid < n_ent) { sm.st_a[tid] = g_a; sm.st_b[tid] = g_b; sm.st_c[tid] = g_c; }
     } else {
         if (tid < nk) sm.st_a[tid] = g_a;
         if (tid < nw) sm.st_w[tid] = g_w;
@@ -673,7 +664,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
             int32_t k_lo = 0; uint32_t c = 0, n_gap = 0;
             const int32_t w_lo = max(r.pos, 0) >> WSS;
-            if (r.ok && w_lo < d.n_swin && !(XCK_EXP & 32)) {
+            if (r.ok && w_lo < d.n_swin) {
                 const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
                 k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
                 if constexpr (JoinSmem<K, MODE>::SPLIT) {
@@ -683,7 +674,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                     // costs one 16-byte record instead of 20 hits.
                     const uint64_t ordv = (d.ordinal_base + (uint64_t)i) << ALLELE_BITS;
                     auto gap = [&](int32_t ka, int32_t kb) {
-                        if (!(XCK_EXP & 64)) for (int32_t ks = ka; ks < kb; ks += 32)
+                        for (int32_t ks = ka; ks < kb; ks += 32)
                             emit_nobase<K, MODE>(a, sm, a.kl.make((uint32_t)ks, (uint32_t)r.cell, r.umi), ordv | (uint64_t)(min(kb - ks, 32) - 1));
                         n_gap += (uint32_t)(kb - ka);
                     };
@@ -708,8 +699,8 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             uint32_t inc = c;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t_ = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t_; }
-            const uint32_t total = (XCK_EXP & 64) ? 0u : __shfl(inc, 63, 64);
-            const unsigned long long has = __ballot(c > 0 && !(XCK_EXP & 64));
+            const uint32_t total = __shfl(inc, 63, 64);
+            const unsigned long long has = __ballot(c > 0);
             const int n_new = __popcll(has);
             const int wb = tid & ~63;                                       // first slot of this wave's segment
             auto drain = [&]() {
@@ -733,7 +724,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                 pr_n = 0; pr_total = 0;
             };
             if (pr_n + n_new > 64) drain();
-            if (c > 0 && !(XCK_EXP & 64)) {
+            if (c > 0) {
                 const int u = wb + pr_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
                 sm.pr_pos[u] = r.pos; sm.pr_end[u] = r.endpos; sm.pr_c0[u] = r.c0; sm.pr_c1[u] = r.c1; sm.pr_cell[u] = r.cell; sm.pr_umi[u] = r.umi;
                 sm.pr_klo[u] = k_lo; sm.pr_s0[u] = cur.s0; sm.pr_sl[u] = cur.s1 - cur.s0; sm.pr_off[u] = pr_total + inc - c; sm.pr_idx[u] = i;
@@ -741,9 +732,9 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             pr_n += n_new; pr_total += total;
             if (j + 1 == TILE_ITEMS && pr_n) drain();
             acc += c + n_gap;
-        } else if (r.ok) {
-            uor |= r.umi;
-            acc += join_regions<K, MODE>(a, d, sm, r);
+        } else {
+            if (r.ok) uor |= r.umi;
+            acc += join_regions<K, MODE>(a, d, sm, r);                   // wave-uniform call: the sweep over the regions is shared by all 64 lanes
         }
         // Flush points are fixed at compile time, never decided from sm.count: a count-based decision read
         // after the barrier races with the next sweep's inserts (threads could disagree and split at the
@@ -1302,7 +1293,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_cp_scatter(const int32_t* __restri
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct ContigTab { int32_t reg_base = 0, n_reg = 0, win_base = 0, n_win = 0, snp_base = 0, n_snp = 0, swin_base = 0, n_swin = 0; };
+struct ContigTab { int32_t reg_base = 0, n_reg = 0, snp_base = 0, n_snp = 0, swin_base = 0, n_swin = 0; };
 
 struct BatchSlot {
     int32_t* pos = nullptr; uint16_t* flag = nullptr; uint8_t* mapq = nullptr; int32_t* cell = nullptr;
@@ -1322,6 +1313,15 @@ struct Arena {
     }
 };
 
+// Device staging of decoded chunks for the host ingest (engine_push_block): the decoder hands over one pinned block per
+// chunk, it is copied with ONE hipMemcpyAsync into one of three slots, and every pipeline of the handle (basefc and pileup of a
+// fused handle) reads the same copy.  A slot is reused once every launch that reads it has been confirmed (its hits fitted).
+struct Stager {
+    int device = 0; hipStream_t s_copy = nullptr;
+    struct Slot { char* buf = nullptr; size_t cap = 0; hipEvent_t t0 = nullptr, copied = nullptr; int users = 0; bool timed = false; } slot[3];
+    int next = 0;
+};
+
 struct EngineImpl {
     xck_engine* eng = nullptr;
     int mode = 0, device = 0;
@@ -1332,7 +1332,7 @@ struct EngineImpl {
     int n_cells = 0, n_regions = 0, n_snps_sorted = 0;
     std::vector<ContigTab> ctab;
     // device tables
-    int32_t *d_win_s0 = nullptr, *d_win_e0 = nullptr, *d_win_row = nullptr, *d_win_off = nullptr;
+    int32_t *d_reg_s0 = nullptr, *d_reg_e0 = nullptr, *d_reg_row = nullptr, *d_reg_pmax = nullptr;   // basefc: regions per contig sorted by start
     int32_t *d_snp_p0 = nullptr, *d_snp_win = nullptr, *d_csr_off = nullptr, *d_csr_reg = nullptr;
     uint32_t *d_snp_info = nullptr, *d_tally = nullptr;
     hipStream_t s_copy = nullptr, s_comp = nullptr;
@@ -1354,6 +1354,7 @@ struct EngineImpl {
     std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
     std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
     int inflight_slot = -1;
+    int inflight_shared = -1;                  // staging slot (Stager) the launch in flight reads, -1 = none
     int64_t queued_reads = 0, inflight_reads = 0;
     TileMeta* d_meta = nullptr; size_t meta_cap = 0;
     // timing
@@ -1384,7 +1385,7 @@ static uint32_t nib_of(uint8_t ch) {
 static int build_tables(EngineImpl* im, const xck_config* cfg) {
     const int nc = cfg->n_contigs;
     im->ctab.assign(std::max(nc, 1), ContigTab());
-    std::vector<int32_t> reg_s0, reg_e0, reg_row, win_off, win_list;
+    std::vector<int32_t> reg_s0, reg_e0, reg_row, reg_pmax;
     std::vector<int32_t> snp_p0, snp_win, csr_off, csr_reg;
     std::vector<uint32_t> snp_info;
     if (im->mode == XCK_MODE_BASEFC) {
@@ -1410,25 +1411,9 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
             for (int32_t g : v) {
                 const xck_region& r = cfg->regions[g];
                 reg_s0.push_back(r.start - 1); reg_e0.push_back(r.end); reg_row.push_back(g);
-                max_e = std::max(max_e, std::max(r.end, r.start));
+                max_e = std::max(max_e, r.end); reg_pmax.push_back(max_e);          // running maximum of the ends: first candidate of a position by binary search
             }
-            t.n_win = v.empty() ? 0 : (max_e >> WS) + 1;
-            t.win_base = (int32_t)win_off.size();
-            std::vector<int32_t> cnt(t.n_win + 1, 0);
-            auto span = [&](int32_t idx, int32_t& w0, int32_t& w1) {
-                int32_t s0 = reg_s0[idx], e0 = reg_e0[idx];
-                w0 = s0 >> WS; w1 = (e0 > s0 ? (e0 - 1) : s0) >> WS;
-            };
-            for (int32_t k = 0; k < t.n_reg; k++) { int32_t w0, w1; span(t.reg_base + k, w0, w1); for (int32_t w = w0; w <= w1; w++) cnt[w]++; }
-            size_t lbase = win_list.size();
-            std::vector<int32_t> off(t.n_win + 1, 0);
-            for (int32_t w = 0; w < t.n_win; w++) off[w + 1] = off[w] + cnt[w];
-            if ((int64_t)lbase + off[t.n_win] > std::numeric_limits<int32_t>::max()) { im->eng->err = "window index too large"; return XCK_E_ARG; }
-            win_list.resize(lbase + off[t.n_win]);
-            std::vector<int32_t> fill(off.begin(), off.end() - 1);
-            for (int32_t k = 0; k < t.n_reg; k++) { int32_t w0, w1; span(t.reg_base + k, w0, w1);
-                for (int32_t w = w0; w <= w1; w++) win_list[lbase + fill[w]++] = t.reg_base + k; }
-            for (int32_t w = 0; w <= t.n_win; w++) win_off.push_back((int32_t)lbase + off[w]);
+            (void)max_e;
         }
     } else {
         std::vector<std::vector<int32_t>> by_c(nc);
@@ -1440,6 +1425,9 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
         // regions per contig sorted by start for the SNP -> region join (baf/fc/main.py:92-101)
         std::vector<std::vector<int32_t>> reg_c(nc);
         for (int g = 0; g < cfg->n_regions; g++) { const xck_region& r = cfg->regions[g]; if (r.contig >= 0 && r.contig < nc) reg_c[r.contig].push_back(g); }
+        std::vector<uint64_t> excl;                                       // (snp index << 32 | region index), sorted
+        for (int i = 0; i < cfg->n_excl_pairs; i++) excl.push_back(((uint64_t)(uint32_t)cfg->excl_snp[i] << 32) | (uint32_t)cfg->excl_region[i]);
+        std::sort(excl.begin(), excl.end());
         csr_off.push_back(0);
         for (int c = 0; c < nc; c++) {
             auto& v = by_c[c];
@@ -1457,27 +1445,27 @@ static int build_tables(EngineImpl* im, const xck_config* cfg) {
             t.swin_base = (int32_t)snp_win.size();
             { int32_t k = 0; for (int32_t w = 0; w < t.n_swin; w++) { while (k < t.n_snp && snp_p0[t.snp_base + k] < (w << WSS)) k++; snp_win.push_back(t.snp_base + k); } }
             // SNP -> regions: start <= pos <= end_incl; rows ascending so keys stay deterministic
+            // (minus the caller's exclusion pairs: SNPs that local phasing removed from one region's list)
             std::vector<std::vector<int32_t>> hits(t.n_snp);
             for (int32_t g : reg_c[c]) {
                 const xck_region& r = cfg->regions[g];
                 if (r.end < r.start) continue;
                 auto lo = std::lower_bound(snp_p0.begin() + t.snp_base, snp_p0.begin() + t.snp_base + t.n_snp, r.start - 1);
-                for (auto it = lo; it != snp_p0.begin() + t.snp_base + t.n_snp && *it <= r.end - 1; ++it)
-                    hits[(it - snp_p0.begin()) - t.snp_base].push_back(g);
+                for (auto it = lo; it != snp_p0.begin() + t.snp_base + t.n_snp && *it <= r.end - 1; ++it) {
+                    const size_t k = (size_t)((it - snp_p0.begin()) - t.snp_base);
+                    if (!excl.empty() && std::binary_search(excl.begin(), excl.end(), ((uint64_t)(uint32_t)v[k] << 32) | (uint32_t)g)) continue;
+                    hits[k].push_back(g);
+                }
             }
             for (int32_t k = 0; k < t.n_snp; k++) { std::sort(hits[k].begin(), hits[k].end()); for (int32_t g : hits[k]) csr_reg.push_back(g); csr_off.push_back((int32_t)csr_reg.size()); }
         }
         im->n_snps_sorted = (int)snp_p0.size();
     }
     int rc;
-    {   // window-list entries carry their region inline (one load level less in the join)
-        std::vector<int32_t> ws0(win_list.size()), we0(win_list.size()), wrow(win_list.size());
-        for (size_t k = 0; k < win_list.size(); k++) { int32_t g = win_list[k]; ws0[k] = reg_s0[g]; we0[k] = reg_e0[g]; wrow[k] = reg_row[g]; }
-        if ((rc = dev_upload(im, &im->d_win_s0, ws0))) return rc;
-        if ((rc = dev_upload(im, &im->d_win_e0, we0))) return rc;
-        if ((rc = dev_upload(im, &im->d_win_row, wrow))) return rc;
-    }
-    if ((rc = dev_upload(im, &im->d_win_off, win_off))) return rc;
+    if ((rc = dev_upload(im, &im->d_reg_s0, reg_s0))) return rc;
+    if ((rc = dev_upload(im, &im->d_reg_e0, reg_e0))) return rc;
+    if ((rc = dev_upload(im, &im->d_reg_row, reg_row))) return rc;
+    if ((rc = dev_upload(im, &im->d_reg_pmax, reg_pmax))) return rc;
     if ((rc = dev_upload(im, &im->d_snp_p0, snp_p0))) return rc;
     if ((rc = dev_upload(im, &im->d_snp_win, snp_win))) return rc;
     if ((rc = dev_upload(im, &im->d_snp_info, snp_info))) return rc;
@@ -1575,7 +1563,7 @@ static int launch_join_t(EngineImpl* im) {
         im->meta_cap = c;
     }
     a.meta = im->d_meta; a.f = im->rf;
-    a.win_s0 = im->d_win_s0; a.win_e0 = im->d_win_e0; a.win_row = im->d_win_row;
+    a.reg_s0 = im->d_reg_s0; a.reg_e0 = im->d_reg_e0; a.reg_row = im->d_reg_row; a.reg_pmax = im->d_reg_pmax;
     a.snp_p0 = im->d_snp_p0;
     a.kl.ubits = im->ubits; a.kl.cbits = im->cbits;
     a.keys = (K*)im->d_keys; a.vals = im->d_vals; a.cap = im->hit_cap; a.ctl = im->d_ctl;
@@ -1584,10 +1572,10 @@ static int launch_join_t(EngineImpl* im) {
     HIP_TRY(hipEventRecord(im->ev0, im->s_comp));
     const dim3 mgrid((tiles + 255) / 256), mblock(256);
     if (im->mode == XCK_MODE_BASEFC) {
-        hipLaunchKernelGGL((k_tile_meta<XCK_MODE_BASEFC>), mgrid, mblock, 0, im->s_comp, a.bt, im->d_meta);
+        hipLaunchKernelGGL((k_tile_meta<XCK_MODE_BASEFC>), mgrid, mblock, 0, im->s_comp, a.bt, im->d_meta, (const int32_t*)im->d_reg_pmax);
         hipLaunchKernelGGL((k_join<K, XCK_MODE_BASEFC>), grid, block, 0, im->s_comp, a);
     } else {
-        hipLaunchKernelGGL((k_tile_meta<XCK_MODE_BAF>), mgrid, mblock, 0, im->s_comp, a.bt, im->d_meta);
+        hipLaunchKernelGGL((k_tile_meta<XCK_MODE_BAF>), mgrid, mblock, 0, im->s_comp, a.bt, im->d_meta, (const int32_t*)nullptr);
         hipLaunchKernelGGL((k_join<K, XCK_MODE_BAF>), grid, block, 0, im->s_comp, a);
     }
     HIP_TRY(hipGetLastError());
@@ -1620,13 +1608,14 @@ static int complete_pending(EngineImpl* im) {
         for (int sh = 0; sh < NSHARD; sh++) { im->cur[sh] = im->h_ctl[ctl_cursor(sh)]; im->cursor += im->cur[sh];
                                               im->ncur[sh] = split_mode(im) ? im->h_ctl[ctl_ncursor(sh)] : 0; im->ncursor += im->ncur[sh]; }
         if (im->inflight_slot >= 0) im->slot[im->inflight_slot].busy = false;
+        if (im->inflight_shared >= 0 && im->eng->stager) { ((Stager*)im->eng->stager)->slot[im->inflight_shared].users--; im->inflight_shared = -1; }
         im->inflight.clear(); im->inflight_slot = -1; im->inflight_reads = 0;
     }
     return 0;
 }
 
 // launch whatever is queued (after the previous launch has been confirmed)
-static int launch_queue(EngineImpl* im, int slot_idx) {
+static int launch_queue(EngineImpl* im, int slot_idx, int shared_slot = -1) {
     if (im->queue.empty()) return 0;
     int rc = complete_pending(im); if (rc) return rc;
     { unsigned long long mx = 0;
@@ -1637,6 +1626,8 @@ static int launch_queue(EngineImpl* im, int slot_idx) {
     im->inflight.swap(im->queue); im->queue.clear();
     im->inflight_reads = im->queued_reads; im->queued_reads = 0;
     im->inflight_slot = slot_idx;
+    im->inflight_shared = shared_slot;
+    if (shared_slot >= 0) ((Stager*)im->eng->stager)->slot[shared_slot].users++;
     for (int sh = 0; sh < NSHARD; sh++) { im->cur_before[sh] = im->cur[sh]; im->ncur_before[sh] = im->ncur[sh]; im->acc_before[sh] = im->h_ctl[ctl_accepted(sh)]; }
     if (slot_idx >= 0) im->slot[slot_idx].busy = true;
     return launch_join(im);
@@ -1658,7 +1649,7 @@ int engine_push(xck_engine* e, const xck_batch* b, bool device_resident) {
     BatchDesc d;
     memset(&d, 0, sizeof d);
     d.n = b->n_reads; d.ordinal_base = b->ordinal_base;
-    d.win_off = im->d_win_off + t.win_base; d.n_win = t.n_win;
+    d.reg_lo = t.reg_base; d.reg_hi = t.reg_base + t.n_reg;
     d.snp_win = im->d_snp_win + t.swin_base; d.n_swin = t.n_swin; d.snp_end = t.snp_base + t.n_snp;
     if (device_resident) {
         // deferred: consecutive device-resident batches are fused into one launch (>> 256 workgroups)
@@ -1698,6 +1689,90 @@ int engine_push(xck_engine* e, const xck_batch* b, bool device_resident) {
     im->queue.push_back(d); im->queued_reads += b->n_reads;
     return launch_queue(im, slot_idx);                         // the kernel overlaps the caller's next decode + copy
 }
+
+// ---- host ingest: one decoded chunk = one H2D copy, shared by every pipeline of the handle ----
+#define HIP_TRY_E(e_, expr)                                                                 \
+    do { hipError_t e__ = (expr); if (e__ != hipSuccess) {                                  \
+        char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr,               \
+                               hipGetErrorString(e__), __FILE__, __LINE__);                 \
+        (e_)->err = b_; return XCK_E_DEVICE; } } while (0)
+
+int engine_push_block(xck_engine* e, const void* host_base, size_t bytes, const xck_batch* batches, int n, void** fence) {
+    if (e->n_impl <= 0) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
+    EngineImpl* im0 = (EngineImpl*)e->impls[0];
+    HIP_TRY_E(e, hipSetDevice(im0->device));
+    Stager* st = (Stager*)e->stager;
+    if (!st) {
+        st = new Stager(); st->device = im0->device; e->stager = st;
+        HIP_TRY_E(e, hipStreamCreateWithFlags(&st->s_copy, hipStreamNonBlocking));
+        for (auto& sl : st->slot) { HIP_TRY_E(e, hipEventCreate(&sl.t0)); HIP_TRY_E(e, hipEventCreate(&sl.copied)); }
+    }
+    const int si = st->next; st->next = (st->next + 1) % 3;
+    Stager::Slot& sl = st->slot[si];
+    for (int k = 0; k < e->n_impl && sl.users > 0; k++) {                // launches that still read this slot: confirm them
+        EngineImpl* im = (EngineImpl*)e->impls[k];
+        if (im->inflight_shared == si) { int rc = complete_pending(im); if (rc) return rc; }
+    }
+    if (sl.users != 0) { e->err = "internal: staging slot still in use"; return XCK_E_STATE; }
+    if (sl.timed) { float ms = 0; if (hipEventElapsedTime(&ms, sl.t0, sl.copied) == hipSuccess) im0->st.ms_h2d += ms; sl.timed = false; }
+    if (bytes > sl.cap) {
+        if (sl.buf) HIP_TRY_E(e, hipFree(sl.buf));
+        sl.buf = nullptr; sl.cap = 0;
+        const size_t c = bytes + bytes / 4 + (1 << 20);
+        HIP_TRY_E(e, hipMalloc((void**)&sl.buf, c));
+        sl.cap = c;
+    }
+    if (!*fence) { hipEvent_t ev; HIP_TRY_E(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); *fence = (void*)ev; }
+    HIP_TRY_E(e, hipEventRecord(sl.t0, st->s_copy));
+    HIP_TRY_E(e, hipMemcpyAsync(sl.buf, host_base, bytes, hipMemcpyHostToDevice, st->s_copy));
+    HIP_TRY_E(e, hipEventRecord(sl.copied, st->s_copy));
+    HIP_TRY_E(e, hipEventRecord((hipEvent_t)*fence, st->s_copy));
+    sl.timed = true;
+    const char* hb = (const char*)host_base;
+    auto dev = [&](const void* hp) { return (void*)(sl.buf + ((const char*)hp - hb)); };
+    for (int k = 0; k < e->n_impl; k++) {
+        EngineImpl* im = (EngineImpl*)e->impls[k];
+        if (im->finished) { e->err = "push after finish (call xck_reset)"; return XCK_E_STATE; }
+        int rc = launch_queue(im, -1); if (rc) return rc;                 // earlier device-resident pushes keep their order
+        HIP_TRY_E(e, hipStreamWaitEvent(im->s_comp, sl.copied, 0));
+        for (int i = 0; i < n; i++) {
+            const xck_batch* b = &batches[i];
+            im->st.n_batches++; im->st.n_reads += b->n_reads;
+            if (b->n_reads <= 0 || b->contig < 0) continue;
+            if (b->contig >= (int)im->ctab.size()) { e->err = "batch contig out of range"; return XCK_E_ARG; }
+            const ContigTab& t = im->ctab[b->contig];
+            if (!(im->mode == XCK_MODE_BASEFC ? t.n_reg > 0 : t.n_snp > 0)) continue;
+            if (im->mode == XCK_MODE_BAF && (!b->seq_off || !b->seq)) { e->err = "BAF mode needs seq arrays"; return XCK_E_ARG; }
+            BatchDesc d; memset(&d, 0, sizeof d);
+            d.n = b->n_reads; d.ordinal_base = b->ordinal_base;
+            d.reg_lo = t.reg_base; d.reg_hi = t.reg_base + t.n_reg;
+            d.snp_win = im->d_snp_win + t.swin_base; d.n_swin = t.n_swin; d.snp_end = t.snp_base + t.n_snp;
+            d.pos = (const int32_t*)dev(b->pos); d.flag = (const uint16_t*)dev(b->flag); d.mapq = (const uint8_t*)dev(b->mapq);
+            d.cell = (const int32_t*)dev(b->cell); d.umi = (const uint64_t*)dev(b->umi);
+            d.cig_off = (const uint32_t*)dev(b->cig_off); d.cigar = (const uint32_t*)dev(b->cigar);
+            if (im->mode == XCK_MODE_BAF) { d.seq_off = (const uint32_t*)dev(b->seq_off); d.seq = (const uint8_t*)dev(b->seq); }
+            const size_t nr = (size_t)b->n_reads;
+            im->st.algo_bytes_join += (int64_t)nr * 20 + (int64_t)(b->cig_off[nr] - b->cig_off[0]) * 4 + (im->mode == XCK_MODE_BAF ? (int64_t)((b->seq_off[nr] - b->seq_off[0]) / 2) : 0);
+            im->queue.push_back(d); im->queued_reads += b->n_reads;
+            if ((int)im->queue.size() >= MAX_FUSE) { rc = launch_queue(im, -1, si); if (rc) return rc; }
+        }
+        rc = launch_queue(im, -1, si); if (rc) return rc;                  // one fused launch per chunk and pipeline
+    }
+    return XCK_OK;
+}
+
+void engine_release_staging(xck_engine* e) {
+    Stager* st = (Stager*)e->stager;
+    if (!st) return;
+    hipSetDevice(st->device);
+    if (st->s_copy) hipStreamSynchronize(st->s_copy);
+    for (auto& sl : st->slot) { if (sl.buf) hipFree(sl.buf); if (sl.t0) hipEventDestroy(sl.t0); if (sl.copied) hipEventDestroy(sl.copied); }
+    if (st->s_copy) hipStreamDestroy(st->s_copy);
+    delete st; e->stager = nullptr;
+}
+
+void fence_wait(void* f) { if (f) hipEventSynchronize((hipEvent_t)f); }
+void fence_destroy(void* f) { if (f) hipEventDestroy((hipEvent_t)f); }
 
 int engine_flush(xck_engine* e) {
     EngineImpl* im = (EngineImpl*)e->impl;
@@ -2148,7 +2223,7 @@ void engine_destroy(xck_engine* e) {
     if (!im) return;
     hipSetDevice(im->device);
     if (im->s_comp) hipStreamSynchronize(im->s_comp);
-    void* ptrs[] = { im->d_win_s0, im->d_win_e0, im->d_win_row, im->d_win_off, im->d_snp_p0, im->d_snp_win,
+    void* ptrs[] = { im->d_reg_s0, im->d_reg_e0, im->d_reg_row, im->d_reg_pmax, im->d_snp_p0, im->d_snp_win,
                      im->d_csr_off, im->d_csr_reg, im->d_snp_info, im->d_tally, im->d_keys, im->d_vals, im->d_nkeys, im->d_nvals, im->d_ctl, im->d_meta,
                      im->ws1.base, im->ws2.base };
     for (void* p : ptrs) if (p) hipFree(p);

@@ -100,6 +100,7 @@ struct xck_engine {
     void* impl = nullptr;                // xck::EngineImpl being addressed (engine.hip); null for decode-only handles
     void* impls[2] = {nullptr, nullptr}; // fused handle (XCK_MODE_BOTH): [0] basefc pipeline, [1] pileup pipeline
     int n_impl = 0;
+    void* stager = nullptr;              // xck::Stager (engine.hip): device staging slots of engine_push_block
     int mode = 0;
     int umi_bits = 64;
     int32_t n_cells = 0, n_contigs = 0;  // bounds that caller-supplied batches are checked against (xck_push_batch)
@@ -118,6 +119,13 @@ int  engine_result_device(xck_engine* e, xck_result* out);
 int  engine_reset(xck_engine* e);
 int  engine_stats(const xck_engine* e, xck_stats* out);
 int  engine_umi_bits(const xck_engine* e);
+// One decoded chunk (all SoA columns in one pinned host block of `bytes` bytes at host_base; the batches point into it): ONE
+// asynchronous H2D copy into a device staging slot shared by the handle's pipelines, then the join kernel(s) on the batches.
+// *fence (created on first use) is recorded behind the copy: fence_wait() before the host block is overwritten.
+int  engine_push_block(xck_engine* e, const void* host_base, size_t bytes, const xck_batch* batches, int n, void** fence);
+void engine_release_staging(xck_engine* e);   // frees the staging slots (xck_destroy)
+void fence_wait(void* fence);
+void fence_destroy(void* fence);
 void* pinned_alloc(size_t bytes);        // hipHostMalloc, falls back to malloc when no device
 void  pinned_free(void* p);
 }

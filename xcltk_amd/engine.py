@@ -45,10 +45,11 @@ class Engine(object):
     def __init__(self, mode, contig_names, regions, n_cells, snps=(), barcodes=None,
                  cell_tag=None, umi_tag=None, device=0, min_mapq=20, min_len=30,
                  incl_flag=0, excl_flag=772, no_orphan=True, min_include=0.9, min_count=1,
-                 min_maf=0, no_dup_hap=True, n_threads=0, flags=0, decode_only=False):
+                 min_maf=0, no_dup_hap=True, n_threads=0, flags=0, decode_only=False, excl_pairs=None):
         """regions: iterable of (chrom, start1, end1_incl[, name]); snps: iterable of
         (chrom, pos1, ref, alt, ref_hap, alt_hap); chrom names must already be stripped of
-        'chr' and present in contig_names."""
+        'chr' and present in contig_names.  excl_pairs = (region indices, snp indices): pairs left out of the SNP -> region
+        join (region-wise local phasing, xck_config.excl_*)."""
         self.lib = capi.load()
         self.mode = mode
         self.contig_names = list(contig_names)
@@ -111,6 +112,15 @@ class Engine(object):
             if len(umi_tag) != 2:
                 raise ValueError("umi_tag must be a 2-character tag")
             cfg.umi_tag = umi_tag.encode("ascii")
+        self._excl = None
+        if excl_pairs is not None and len(excl_pairs[0]):
+            er = np.ascontiguousarray(excl_pairs[0], dtype=np.int32)
+            es = np.ascontiguousarray(excl_pairs[1], dtype=np.int32)
+            assert len(er) == len(es)
+            self._excl = (er, es)
+            cfg.n_excl_pairs = len(er)
+            cfg.excl_region = er.ctypes.data_as(C.POINTER(C.c_int32))
+            cfg.excl_snp = es.ctypes.data_as(C.POINTER(C.c_int32))
         cfg.n_threads = int(n_threads)
         cfg.flags = int(flags) | (capi.XCK_F_DECODE_ONLY if decode_only else 0)
         self.cfg = cfg

@@ -15,6 +15,7 @@ from logging import error, info
 
 from ... import fc_common as fcc
 from ...capi import XCK_MODE_BASEFC
+from ...engine import XckError
 from ...config import APP, VERSION
 from ...utils.xlog import init_logging
 from .config import Config
@@ -187,7 +188,7 @@ def fc_run(conf):
         info("CMD: %s" % cmdline)
     try:
         fc_core(conf)
-    except ValueError as e:
+    except (ValueError, XckError) as e:
         error(str(e))
         error("Running program failed.")
         error("Quiting ...")
