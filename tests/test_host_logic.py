@@ -477,9 +477,18 @@ def test_convert_matches_reference_outputs(name, argv, tmp_path):
     """Fixtures = outputs of the reference's `xcltk convert` (oracle/refgen/make_convert_goldens.py)."""
     from xcltk_amd.xcltk import main
     out = str(tmp_path / name)
-    av = [a.replace("$BED", os.path.join(_CONVERT, "in.bed")).replace("$TSV", os.path.join(_CONVERT, "in.tsv")) for a in argv]
+    av = [a.replace("$BED", os.path.join(_CONVERT, "in.bed")).replace("$TSV", os.path.join(_CONVERT, "in.tsv")).replace("$GTF", os.path.join(_CONVERT, "in.gtf")) for a in argv]
     main(["xcltk", "convert"] + av + ["-o", out])
     assert open(out, "rb").read() == open(os.path.join(_CONVERT, name), "rb").read()
+
+
+def test_convert_gff_gene_ids_as_feature_names(tmp_path):
+    """gff branch (utils/gregion.py:60-62): gene lines only; the id is the LAST ID / gene_id attribute, '*' without one."""
+    from xcltk_amd.utils.gregion import load_regions
+    regs = load_regions(os.path.join(_CONVERT, "in.gtf"), "gff")
+    assert [(r.chrom, r.start, r.end, r.id) for r in regs] == [
+        ("chr1", 11869, 14409, "ENSG00000223972.5"), ("chr1", 14404, 29570, "ENSG00000227232.5"), ("2", 100, 2000, "gene:G3"),
+        ("X", 5, 9, "*"), ("X", 50, 90, "second")]
 
 
 def test_convert_errors_and_feature_tables(tmp_path, capsys):

@@ -112,21 +112,41 @@ def pipeline_wrapper(label, sam_fn=None, sam_list_fn=None, barcode_fn=None, samp
         error("out dir needed!")
         return -1
     os.makedirs(out_dir, exist_ok=True)
-    if phased_snp_fn is None:
-        error("steps 1-2 of `%s baf` call the external binaries cellsnp-lite and eagle "
-              "(baf/genotype.py:144-187, baf/refphase.py:112-148), which this engine does not "
-              "replace; run them separately and pass the phased VCF with --phasedSNP." % APP)
-        return -1
     sample_id = None
-    if barcode_fn is None and sample_id_fn is None:
+    mode = "droplet" if barcode_fn is not None else ("well" if sample_id_fn is not None else "bulk")
+    if mode == "bulk":
         sample_id = label                      # bulk: the label is the sample id
+    # step 1: per-SNP x cell pileup of the candidate SNPs.  The reference runs the external cellsnp-lite binary here
+    # (baf/genotype.py:144-187); this engine produces the same directory itself (baf/genotype.py of this package).
+    pileup_dir = None
+    if snp_vcf_fn is not None:
+        from .genotype import pileup
+        pileup_dir = os.path.join(out_dir, "1_pileup")
+        info("start genotyping ...")
+        try:
+            vcf, p_raw, p_new = pileup(sam_fn=sam_fn, sam_list_fn=sam_list_fn, barcode_fn=barcode_fn, sample_id_fn=sample_id_fn,
+                                       sample_id=sample_id, snp_vcf_fn=snp_vcf_fn, out_dir=pileup_dir, mode=mode,
+                                       cell_tag=cell_tag, umi_tag=umi_tag, ncores=ncores, min_count=min_count, min_maf=min_maf)
+        except (ValueError, IOError, OSError) as e:
+            error("pileup failed: %s" % e)
+            return -1
+        if vcf is not None:
+            info("pileup #SNP raw=%d; post-filtering=%d." % (p_raw, p_new))
+            info("pileup VCF is '%s'." % vcf)
+    # step 2: reference phasing with Eagle2 - an external binary plus a phasing panel (baf/refphase.py:112-148) that this
+    # engine does not replace: the phased SNP list has to be given
+    if phased_snp_fn is None:
+        error("step 2 of `%s baf` calls the external binary eagle with a phasing panel (baf/refphase.py:112-148), which this "
+              "engine does not replace; phase the pileup VCF%s separately and pass the result with --phasedSNP."
+              % (APP, " ('%s')" % os.path.join(pileup_dir, "cellSNP.base.vcf.gz") if pileup_dir else ""))
+        return -1
     fc_dir = os.path.join(out_dir, "3_baf_fc")
     os.makedirs(fc_dir, exist_ok=True)
     info("BAF feature counting ...")
-    # same arguments as the reference's call of baf_fc (baf/pipeline.py:341-360)
+    # same arguments as the reference's call of baf_fc (baf/pipeline.py:341-360): the pileup directory drives the local phasing
     ret = baf_fc(sam_fn=sam_fn, barcode_fn=barcode_fn, region_fn=region_fn, phased_snp_fn=phased_snp_fn,
                  out_dir=fc_dir, sam_list_fn=sam_list_fn, sample_ids=sample_id, sample_id_fn=sample_id_fn,
-                 debug_level=0, ncores=ncores, cellsnp_dir=None, ref_cell_fn=ref_cell_fn,
+                 debug_level=0, ncores=ncores, cellsnp_dir=pileup_dir, ref_cell_fn=ref_cell_fn,
                  cell_tag=cell_tag, umi_tag=umi_tag, min_count=1, min_maf=0, output_all_reg=True,
                  no_dup_hap=True, min_mapq=20, min_len=30, incl_flag=0, excl_flag=None, no_orphan=True)
     info("feature BAFs are at '%s'." % fc_dir)

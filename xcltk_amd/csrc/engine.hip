@@ -216,7 +216,8 @@ template <class K, int MODE> struct JoinSmem {
     static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (HAS_VAL ? 8 : 0));
     alignas(16) unsigned char store[STORE_BYTES];
     uint32_t cig[CG_CAP];
-    int32_t  st_a[ST_CAP], st_b[ST_CAP], st_c[ST_CAP];
+    static constexpr int ST_BC = MODE == XCK_MODE_BASEFC ? ST_CAP : 1;    // region ends / rows: basefc only
+    int32_t  st_a[ST_CAP], st_b[ST_BC], st_c[ST_BC];
     int32_t  st_w[ST_WIN + 1];
     uint32_t cg_lo, cg_n;                // staged CIGAR range [cg_lo, cg_lo + cg_n)
     int32_t  w0, nw;                     // basefc: staged regions [w0, w0 + nw) of the start-sorted arrays; pileup: staged SNP windows
@@ -229,11 +230,15 @@ template <class K, int MODE> struct JoinSmem {
     uint64_t nq_key[NQCAP], nq_val[NQCAP];
     uint32_t ncount;
     unsigned long long nbase;
-    // pileup: the reads of a wave that have (read, SNP) pairs, parked so that any lane can work on any pair
+    // pileup: (read, SNP) pairs under aligned blocks, parked per wave (64 slots each) until their bases are fetched together
     static constexpr int PR = MODE == XCK_MODE_BAF ? JOIN_BLOCK : 1;
-    uint64_t pr_umi[PR];
-    int32_t  pr_pos[PR], pr_end[PR], pr_cell[PR], pr_klo[PR];
-    uint32_t pr_c0[PR], pr_c1[PR], pr_s0[PR], pr_sl[PR], pr_off[PR]; int32_t pr_idx[PR];
+    uint64_t pk_umi[PR];
+    // pileup: reads with N / D gaps (or without a CIGAR span) of the whole tile, set aside for pileup_complex()
+    static constexpr int CXCAP = MODE == XCK_MODE_BAF ? 192 : 1;
+    uint64_t cx_umi[CXCAP]; int32_t cx_pos[CXCAP], cx_end[CXCAP], cx_cell[CXCAP], cx_idx[CXCAP]; uint32_t cx_c0[CXCAP], cx_c1[CXCAP], cx_s0[CXCAP], cx_sl[CXCAP];
+    uint32_t cx_n;
+    int32_t  pk_k[PR], pk_qi[PR], pk_cell[PR], pk_idx[PR];
+    uint32_t pk_s0[PR], pk_sl[PR];
     __device__ K* keys() { return reinterpret_cast<K*>(store); }
     __device__ uint64_t* vals() { return reinterpret_cast<uint64_t*>(store + (size_t)QCAP * sizeof(K)); }
     __device__ unsigned long long* hkeys() { return reinterpret_cast<unsigned long long*>(store); }            // set mode
@@ -453,24 +458,22 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
 // basefc: read x region interval join, region-major.  Regions are sorted by start inside the contig, the reads of a wave are
 // (in a sorted BAM) a narrow position range, so the whole wave walks ONE short list together: from the tile's first
 // candidate (first region whose running-maximum end lies beyond the tile's first position, k_tile_meta) up to the first
-// region that starts at or after the wave's largest read end.  Start, end and row of a region are wave-uniform (LDS
+// region that starts at or after the end of every read of the wave (one ballot per step, no reduction).  Start, end and row of a region are wave-uniform (LDS
 // broadcast reads of the staged slice); each lane only compares its own read against them - no per-lane index lookups,
 // no divergent loop counts.  A wave that holds a read left of the tile's first read (unsorted input) scans from the
 // contig's first region, so sortedness is a speed assumption, never a correctness one.
 template <class K, int MODE>
-__device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r) {
+__device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r,
+                                                 const int32_t lb, const int32_t n_st, const int32_t p_first) {   // staged slice: regions [lb, lb + n_st); scalars
     uint32_t n_acc = 0;
-    int32_t mx = r.ok ? r.endpos : INT32_MIN, mn = r.ok ? r.pos : INT32_MAX;
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) { mx = max(mx, __shfl_xor(mx, dd, 64)); mn = min(mn, __shfl_xor(mn, dd, 64)); }
-    if (mx == INT32_MIN) return 0;                                   // no read of this wave passed the filter (wave-uniform)
-    const int32_t lb = sm.w0, n_st = sm.nw;                           // staged slice: regions [lb, lb + n_st)
-    int32_t k = mn >= sm.k0 ? lb : d.reg_lo;                          // sm.k0 = position of the tile's first read
+    if (!__ballot(r.ok)) return 0;                                   // no read of this wave passed the filter (wave-uniform)
+    // p_first = position of the tile's first read: a read left of it means unsorted input, the list is then walked from its start
+    int32_t k = __ballot(r.ok && r.pos < p_first) ? d.reg_lo : lb;
     for (; k < d.reg_hi; k++) {
         const uint32_t rel = (uint32_t)(k - lb);
         const bool staged = rel < (uint32_t)n_st;
         const int32_t s0 = __builtin_amdgcn_readfirstlane(staged ? sm.st_a[rel] : as_global(a.reg_s0)[k]);
-        if (s0 >= mx) break;                                        // sorted by start: nothing further can overlap
+        if (!__ballot(r.ok && s0 < r.endpos)) break;                // sorted by start: no read of the wave reaches this or any later region
         const int32_t e0 = __builtin_amdgcn_readfirstlane(staged ? sm.st_b[rel] : as_global(a.reg_e0)[k]);
         if (!(r.ok && r.pos < e0 && r.endpos > s0)) continue;       // htslib fetch overlap
         const int32_t m = included_len(a, d, sm, r, s0, e0);
@@ -493,6 +496,7 @@ __device__ __forceinline__ int32_t snp_p0(const JoinArgs<K>& a, const JoinSmem<K
     const uint32_t dl = (uint32_t)(k - sm.k0);
     return dl < (uint32_t)sm.nk ? sm.st_a[dl] : as_global(a.snp_p0)[k];
 }
+
 template <class K, int MODE>
 __device__ __forceinline__ int32_t lower_snp_tail(const JoinArgs<K>& a, const BatchDesc& d, int32_t k, int32_t x) {
     while (k < d.snp_end && as_global(a.snp_p0)[k] < x) k++;
@@ -514,54 +518,56 @@ __device__ __forceinline__ int32_t lower_snp(const JoinArgs<K>& a, const BatchDe
     }
     return lower_snp_tail<K, MODE>(a, d, k, x);
 }
-// UCount.push_read + get_query_bases for a read parked in LDS slot u: BAM nibble of the query base at reference p0, or -1
+// One read whose reference span is not one aligned block (N / D gaps, no CIGAR span, unmapped flag): the pileup of
+// baf/fc/mcount.py:109-127 + utils/sam.py:4-40 over its CIGAR.  SNPs under aligned blocks are hits with a base (fetched
+// here: these reads are few); the SNPs inside a gap - where the read holds the key but shows no base - leave as ONE range
+// record per gap, (first SNP, cell, UMI | ordinal, count - 1), in pieces of 32 SNPs: a spliced read over 20 SNPs costs one
+// 16-byte record instead of 20 hits.  Such reads are collected per tile and walked together (k_join), so that the waves
+// that walk them are full and the other 85 % of the reads never wait for them.
 template <class K, int MODE>
-__device__ __forceinline__ int allele_at_slot(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int u, int32_t p0) {
-    const uint32_t s0 = sm.pr_s0[u], sl = sm.pr_sl[u];
-    int32_t rp = sm.pr_pos[u], q = 0;
-    const uint32_t c1 = sm.pr_c1[u];
-    for (uint32_t c = sm.pr_c0[u]; c < c1; c++) {
-        uint32_t w = cig_at(a, d, sm, c); uint32_t op = w & 15u; int32_t l = int32_t(w >> 4);
-        if (op_aligned(op)) {
-            if (p0 >= rp && p0 < rp + l) {
-                const int32_t qi = q + (p0 - rp);
-                if ((uint32_t)(qi >> 1) >= sl) return -1;
-                const uint32_t by = as_global(d.seq)[s0 + (qi >> 1)];
-                return (qi & 1) ? int(by & 15u) : int(by >> 4);
-            }
-            rp += l; q += l;
-        } else if (op == 1u || op == 4u) q += l;
-        else if (op_ref(op)) rp += l;
-    }
-    return -1;
-}
-
-// split mode: the jn-th SNP (in reference order) that lies under an ALIGNED block of the read parked in slot u:
-// returns its query base (BAM nibble, or -1 when the read has no sequence there) and the SNP index in k
-template <class K, int MODE>
-__device__ __forceinline__ int nth_aligned_snp(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, int u, uint32_t jn, int32_t& k_out) {
-    int32_t rp = sm.pr_pos[u], q = 0, k = sm.pr_klo[u];
-    const int32_t endpos = sm.pr_end[u];
-    const uint32_t c1 = sm.pr_c1[u];
-    for (uint32_t c = sm.pr_c0[u]; c < c1 && rp < endpos; c++) {
-        const uint32_t w = cig_at(a, d, sm, c); const uint32_t op = w & 15u; const int32_t l = int32_t(w >> 4);
-        if (op_aligned(op)) {
+__device__ __forceinline__ uint32_t pileup_complex(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, int32_t pos, int32_t endpos,
+                                                   uint32_t c0, uint32_t c1, int32_t cell, uint64_t umi, uint32_t s0, uint32_t sl, int32_t idx) {
+    const int32_t w_lo = max(pos, 0) >> WSS;
+    if (w_lo >= d.n_swin) return 0;
+    constexpr uint64_t AL_MASK = (uint64_t)((1u << ALLELE_BITS) - 1);
+    const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
+    int32_t k = lower_snp<K, MODE>(a, d, sm, k_w, pos);
+    const uint64_t ordv = (d.ordinal_base + (uint64_t)idx) << ALLELE_BITS;
+    uint32_t n = 0;
+    auto gap = [&](int32_t ka, int32_t kb) {
+        if constexpr (JoinSmem<K, MODE>::SPLIT) {
+            for (int32_t ks = ka; ks < kb; ks += 32)
+                emit_nobase<K, MODE>(a, sm, a.kl.make((uint32_t)ks, (uint32_t)cell, umi), ordv | (uint64_t)(min(kb - ks, 32) - 1));
+        } else for (int32_t ks = ka; ks < kb; ks++) emit<K, MODE>(a, sm, a.kl.make((uint32_t)ks, (uint32_t)cell, umi), ordv);
+        n += (uint32_t)(kb - ka);
+    };
+    int32_t rp = pos, q = 0;
+    for (uint32_t cc = c0; cc < c1 && rp < endpos; cc++) {
+        const uint32_t w = cig_at(a, d, sm, cc); const uint32_t op = w & 15u; const int32_t l = int32_t(w >> 4);
+        if (op_ref(op) && l != 0) {
             const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, min(rp + l, endpos));
-            if (jn < (uint32_t)(k2 - k)) {
-                k_out = k + (int32_t)jn;
-                const int32_t qi = q + (snp_p0<K, MODE>(a, sm, k_out) - rp);
-                if ((uint32_t)(qi >> 1) >= sm.pr_sl[u]) return -1;
-                const uint32_t by = as_global(d.seq)[sm.pr_s0[u] + (qi >> 1)];
-                return (qi & 1) ? int(by & 15u) : int(by >> 4);
-            }
-            jn -= (uint32_t)(k2 - k); k = k2; rp += l; q += l;
-        } else if (op == 1u || op == 4u) q += l;
-        else if (op_ref(op)) { k = lower_snp<K, MODE>(a, d, sm, k, min(rp + l, endpos)); rp += l; }
+            if (op_aligned(op)) {
+                for (int32_t kk = k; kk < k2; kk++) {
+                    const int32_t qi = q + (snp_p0<K, MODE>(a, sm, kk) - rp);
+                    int al = -1;
+                    if ((uint32_t)(qi >> 1) < sl) { const uint32_t by = as_global(d.seq)[s0 + (uint32_t)(qi >> 1)]; al = (qi & 1) ? int(by & 15u) : int(by >> 4); }
+                    const K key = a.kl.make((uint32_t)kk, (uint32_t)cell, umi);
+                    if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, ordv);
+                    else emit<K, MODE>(a, sm, key, ordv | (uint64_t)(al + 1));
+                }
+                n += (uint32_t)(k2 - k);
+            } else if (k2 > k) gap(k, k2);
+            k = k2; rp += l;
+        }
+        if (op_aligned(op) || op == 1u || op == 4u) q += l;
     }
-    k_out = k;
-    return -1;                                                           // not reached for jn < the read's pair count
+    if (rp < endpos) {                                                        // no CIGAR / zero reference length: the position itself, without a base
+        const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, endpos);
+        if (k2 > k) gap(k, k2);
+    }
+    (void)AL_MASK;
+    return n;
 }
-
 
 // one thread per tile: locate the batch, read the tile's extent, size the LDS staging
 template <int MODE>
@@ -608,6 +614,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     const int b = __builtin_amdgcn_readfirstlane(mp->b);
     const int tile0 = __builtin_amdgcn_readfirstlane(mp->r0);
     const BatchDesc& d = a.bt.desc[b];                                // kernarg: scalar loads through the constant cache
+    const int32_t u_lb = __builtin_amdgcn_readfirstlane(e0), u_nst = __builtin_amdgcn_readfirstlane(n_ent), u_p0 = __builtin_amdgcn_readfirstlane(k0);   // basefc: the tile's region slice as scalars
     unsigned long long uor = 0;
     STAMP(0);
     RawRead W[TILE_ITEMS];
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         unsigned long long* set = sm.hkeys();                         // all ones = empty
         for (int s = tid; s < JoinSmem<K, MODE>::SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.k0 = k0; sm.nk = nk;
+    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cx_n = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.k0 = k0; sm.nk = nk;
                     if (MODE == XCK_MODE_BASEFC) { sm.w0 = e0; sm.nw = n_ent; } else { sm.w0 = w0; sm.nw = nw; } }
     // Every global load of the prologue is issued BEFORE the first LDS store: written as load/store loops the
     // compiler waits (s_waitcnt vmcnt(0)) inside each iteration, which serialised ~7 HBM round trips per tile.
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     STAMP(2);
     // ---- TILE_ITEMS coalesced sweeps over the tile (the reads were requested in the prologue) ----
     uint32_t acc = 0;
-    int pr_n = 0; uint32_t pr_total = 0;                              // pileup: parked reads / their pairs (wave-uniform)
+    int pr_n = 0;                                                     // pileup: parked pairs of this wave (wave-uniform)
     // sweeps between two flushes: keep the expected fill (256 reads x ~2 pairs per sweep) under half the set / queue
     constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? JoinSmem<K, MODE>::SLOTS : JoinSmem<K, MODE>::QCAP;
     // set mode: the de-duplicated fill of a 1024-read tile is a few hundred keys, so flush once, at the end
@@ -659,82 +666,94 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         const RawRead cur = W[j];
         ReadInfo r = load_read<K, MODE>(a, d, sm, cur);
         if constexpr (MODE == XCK_MODE_BAF) {
-            // A spliced read spans thousands of bases and tens of SNPs, most reads none: looping per read leaves the
-            // wave waiting for its longest read.  So: every read only COUNTS its SNPs, the counts are scanned, and the
-            // (read, SNP) pairs are dealt out evenly - one CIGAR walk + base fetch per lane per round.
-            int32_t k_lo = 0; uint32_t c = 0, n_gap = 0;
-            const int32_t w_lo = max(r.pos, 0) >> WSS;
-            if (r.ok && w_lo < d.n_swin) {
-                const int32_t k_w = (uint32_t)(w_lo - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w_lo - sm.w0] : as_global(d.snp_win)[w_lo];
-                k_lo = lower_snp<K, MODE>(a, d, sm, k_w, r.pos);
-                if constexpr (JoinSmem<K, MODE>::SPLIT) {
-                    // split mode: one CIGAR walk per read.  SNPs under aligned blocks become (read, SNP) pairs (c); the SNPs
-                    // inside an N / D gap - where the read holds the key but shows no base - leave as ONE range record per
-                    // gap, (first SNP, cell, UMI | ordinal, count - 1), in pieces of 32 SNPs: a spliced read over 20 SNPs
-                    // costs one 16-byte record instead of 20 hits.
-                    const uint64_t ordv = (d.ordinal_base + (uint64_t)i) << ALLELE_BITS;
-                    auto gap = [&](int32_t ka, int32_t kb) {
-                        for (int32_t ks = ka; ks < kb; ks += 32)
-                            emit_nobase<K, MODE>(a, sm, a.kl.make((uint32_t)ks, (uint32_t)r.cell, r.umi), ordv | (uint64_t)(min(kb - ks, 32) - 1));
-                        n_gap += (uint32_t)(kb - ka);
-                    };
-                    int32_t k = k_lo, rp = r.pos;
-                    for (uint32_t cc = r.c0; cc < r.c1 && rp < r.endpos; cc++) {
-                        const uint32_t w = cig_at(a, d, sm, cc); const uint32_t op = w & 15u; const int32_t l = int32_t(w >> 4);
-                        if (!op_ref(op) || l == 0) continue;                 // I, S, H, P: no reference bases
-                        const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, min(rp + l, r.endpos));
-                        if (op_aligned(op)) c += (uint32_t)(k2 - k); else if (k2 > k) gap(k, k2);
-                        k = k2; rp += l;
-                    }
-                    if (rp < r.endpos) {                                      // no CIGAR / zero reference length: the position itself, without a base
-                        const int32_t k2 = lower_snp<K, MODE>(a, d, sm, k, r.endpos);
-                        if (k2 > k) gap(k, k2);
-                    }
-                } else
-                c = (uint32_t)(lower_snp<K, MODE>(a, d, sm, k_lo, r.endpos) - k_lo);
-            }
-            // wave-level: only the reads that HAVE pairs are parked (compacted) in the wave's own 64-slot LDS segment; the
-            // pairs are dealt out over the 64 lanes when the segment fills up or the tile ends - one CIGAR walk + base
-            // fetch per lane per round at high lane utilisation, no block barrier (a wave's LDS operations execute in order)
-            uint32_t inc = c;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t_ = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t_; }
-            const uint32_t total = __shfl(inc, 63, 64);
-            const unsigned long long has = __ballot(c > 0);
-            const int n_new = __popcll(has);
+            // read x SNP join, SNP-major: the 64 reads of a wave are (in a sorted BAM) a narrow position range, so the wave
+            // walks the few SNPs of that range TOGETHER - position of SNP k is wave-uniform, every lane only asks "inside my
+            // read?" - instead of every read searching the SNP table for itself (two or three binary searches per read, most of
+            // them to learn that a 91-base read covers no SNP).  A hit parks its (SNP, query offset) pair in the wave's LDS
+            // segment; the bases of the parked pairs are fetched together later (one HBM latency per batch, not per hit).
+            uint32_t c = 0, n_gap = 0;
             const int wb = tid & ~63;                                       // first slot of this wave's segment
+            constexpr uint64_t AL_MASK = (uint64_t)((1u << ALLELE_BITS) - 1);
             auto drain = [&]() {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t pi = lane; pi < pr_total; pi += 64) {
-                    int lo = 0, hi = pr_n - 1;                              // the read this pair belongs to: last u with pr_off[u] <= pi
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sm.pr_off[wb + mid] <= pi) lo = mid; else hi = mid - 1; }
-                    const int u = wb + lo;
-                    int32_t k = sm.pr_klo[u] + (int32_t)(pi - sm.pr_off[u]);
-                    int al;
-                    if constexpr (JoinSmem<K, MODE>::SPLIT) al = nth_aligned_snp<K, MODE>(a, d, sm, u, pi - sm.pr_off[u], k);
-                    else al = allele_at_slot<K, MODE>(a, d, sm, u, snp_p0<K, MODE>(a, sm, k));
-                    const K key = a.kl.make((uint32_t)k, (uint32_t)sm.pr_cell[u], sm.pr_umi[u]);
-                    const uint64_t val = ((d.ordinal_base + (uint64_t)sm.pr_idx[u]) << ALLELE_BITS) | (uint64_t)(al + 1);
-                    if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val & ~(uint64_t)((1u << ALLELE_BITS) - 1));   // a record of one SNP
+                if (lane < pr_n) {
+                    const int u = wb + lane;
+                    const int32_t qi = sm.pk_qi[u];
+                    int al = -1;                                            // no sequence stored for that offset: key held, no base
+                    if ((uint32_t)(qi >> 1) < sm.pk_sl[u]) { const uint32_t by = as_global(d.seq)[sm.pk_s0[u] + (uint32_t)(qi >> 1)]; al = (qi & 1) ? int(by & 15u) : int(by >> 4); }
+                    const K key = a.kl.make((uint32_t)sm.pk_k[u], (uint32_t)sm.pk_cell[u], sm.pk_umi[u]);
+                    const uint64_t val = ((d.ordinal_base + (uint64_t)sm.pk_idx[u]) << ALLELE_BITS) | (uint64_t)(al + 1);
+                    if (JoinSmem<K, MODE>::SPLIT && al < 0) emit_nobase<K, MODE>(a, sm, key, val & ~AL_MASK);   // a record of one SNP
                     else emit<K, MODE>(a, sm, key, val);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();                            // the segment is free again
-                pr_n = 0; pr_total = 0;
+                pr_n = 0;
             };
-            if (pr_n + n_new > 64) drain();
-            if (c > 0) {
-                const int u = wb + pr_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
-                sm.pr_pos[u] = r.pos; sm.pr_end[u] = r.endpos; sm.pr_c0[u] = r.c0; sm.pr_c1[u] = r.c1; sm.pr_cell[u] = r.cell; sm.pr_umi[u] = r.umi;
-                sm.pr_klo[u] = k_lo; sm.pr_s0[u] = cur.s0; sm.pr_sl[u] = cur.s1 - cur.s0; sm.pr_off[u] = pr_total + inc - c; sm.pr_idx[u] = i;
+            // reads whose reference span is ONE aligned block (no N / D; 85 % of a 10x run) take the wave-uniform walk below; the
+            // others are set aside in LDS and walked together after the last sweep (pileup_complex)
+            const bool simple = r.ok && r.span_is_cigar && r.endpos - r.pos == r.n_al;
+            const unsigned long long cxm = __ballot(r.ok && !simple);
+            if (cxm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&sm.cx_n, (uint32_t)__popcll(cxm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (r.ok && !simple) {
+                    const uint32_t u = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(cxm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cxm, 0u));
+                    if (u < (uint32_t)JoinSmem<K, MODE>::CXCAP) {
+                        sm.cx_pos[u] = r.pos; sm.cx_end[u] = r.endpos; sm.cx_c0[u] = r.c0; sm.cx_c1[u] = r.c1; sm.cx_cell[u] = r.cell; sm.cx_umi[u] = r.umi;
+                        sm.cx_s0[u] = cur.s0; sm.cx_sl[u] = cur.s1 - cur.s0; sm.cx_idx[u] = i;
+                    } else n_gap += pileup_complex<K, MODE>(a, d, sm, r.pos, r.endpos, r.c0, r.c1, r.cell, r.umi, cur.s0, cur.s1 - cur.s0, i);   // list full: walk it here
+                }
             }
-            pr_n += n_new; pr_total += total;
-            if (j + 1 == TILE_ITEMS && pr_n) drain();
+            if (__ballot(simple)) {                                         // wave-uniform
+                // first SNP to look at: the 1 kb window of the wave's first read (lane 0 exists whenever any lane does); a read
+                // left of it means unsorted input - then the contig's SNPs are walked from the start (speed, never correctness)
+                const int32_t p_w = __builtin_amdgcn_readfirstlane(cur.pos);
+                int32_t k;
+                if (__ballot(simple && r.pos < p_w)) k = d.n_swin > 0 ? as_global(d.snp_win)[0] : d.snp_end;
+                else { const int32_t w = max(p_w, 0) >> WSS;
+                       k = w >= d.n_swin ? d.snp_end : ((uint32_t)(w - sm.w0) < (uint32_t)sm.nw ? sm.st_w[w - sm.w0] : as_global(d.snp_win)[w]); }
+                k = __builtin_amdgcn_readfirstlane(k);
+                for (; k < d.snp_end; k++) {
+                    const int32_t p = __builtin_amdgcn_readfirstlane(snp_p0<K, MODE>(a, sm, k));
+                    const bool reach = simple && p < r.endpos;
+                    if (!__ballot(reach)) break;                            // SNPs are sorted: no read of the wave reaches this or any later one
+                    const bool hit = reach && p >= r.pos;
+                    const unsigned long long am = __ballot(hit);
+                    if (!am) continue;
+                    int32_t qi = p - r.pos;                                 // one aligned op: query offset = reference offset
+                    if (hit && r.c1 - r.c0 != 1) {                          // I / S / H / P around the aligned blocks shift the query offset
+                        int32_t rp = r.pos, q = 0;
+                        for (uint32_t cc = r.c0; cc < r.c1; cc++) {
+                            const uint32_t w = cig_at(a, d, sm, cc); const uint32_t op = w & 15u; const int32_t l = int32_t(w >> 4);
+                            if (op_aligned(op)) { if (p < rp + l) { qi = q + (p - rp); break; } rp += l; q += l; }
+                            else if (op == 1u || op == 4u) q += l;
+                        }
+                    }
+                    const int n_new = __popcll(am);
+                    if (pr_n + n_new > 64) drain();
+                    if (hit) {
+                        const int u = wb + pr_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                        sm.pk_k[u] = k; sm.pk_qi[u] = qi; sm.pk_cell[u] = r.cell; sm.pk_umi[u] = r.umi; sm.pk_s0[u] = cur.s0; sm.pk_sl[u] = cur.s1 - cur.s0; sm.pk_idx[u] = i;
+                        c++;
+                    }
+                    pr_n += n_new;
+                }
+            }
+            if (j + 1 == TILE_ITEMS) {
+                if (pr_n) drain();
+                // the set-aside reads of the whole tile, one per thread: full waves of long walks instead of one long walk per wave and sweep
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const uint32_t cx_n = min(sm.cx_n, (uint32_t)JoinSmem<K, MODE>::CXCAP);
+                for (uint32_t u = tid; u < cx_n; u += JOIN_BLOCK)
+                    n_gap += pileup_complex<K, MODE>(a, d, sm, sm.cx_pos[u], sm.cx_end[u], sm.cx_c0[u], sm.cx_c1[u], sm.cx_cell[u], sm.cx_umi[u], sm.cx_s0[u], sm.cx_sl[u], sm.cx_idx[u]);
+            }
             acc += c + n_gap;
         } else {
             if (r.ok) uor |= r.umi;
-            acc += join_regions<K, MODE>(a, d, sm, r);                   // wave-uniform call: the sweep over the regions is shared by all 64 lanes
+            acc += join_regions<K, MODE>(a, d, sm, r, u_lb, u_nst, u_p0);   // wave-uniform call: the sweep over the regions is shared by all 64 lanes
         }
         // Flush points are fixed at compile time, never decided from sm.count: a count-based decision read
         // after the barrier races with the next sweep's inserts (threads could disagree and split at the

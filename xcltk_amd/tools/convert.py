@@ -16,7 +16,7 @@ OUT_TYPES = ("bed", "tsv", "features")
 #          flags                 dest        extra keyword arguments
 OPTIONS = (
     (("--input", "-i"),   "in_file",  dict(default=None, help="Path to input region file.")),
-    (("--inType", "-I"),  "in_type",  dict(default=None, help="Input region type, one of bed|tsv.")),
+    (("--inType", "-I"),  "in_type",  dict(default=None, help="Input region type, one of bed|gff|tsv.")),
     (("--output", "-o"),  "out_file", dict(default=None, help="Path to output file; if not set, use stdout.")),
     (("--outType", "-O"), "out_type", dict(default="tsv", help="Output region type, one of bed|tsv|features [default: %default]")),
     (("--binsize", "-B"), "bin_size", dict(default=None, type="int", help="Fixed size of bin in kb. it will be used when no input file.")),
@@ -54,8 +54,6 @@ def _run(argv):
         raise _Fail("Error: out region type should be provided!\n")
     if opt.out_type not in OUT_TYPES:
         raise _Fail("Error: out region type should be one of bed|tsv.\n")
-    if how == "file" and y == "gff":
-        raise _Fail("Error: gff input is not provided by this build (it needs the GTF gene parser).\n")
     regs = gregion.get_fixsize_regions(x, y) if how == "bins" else gregion.load_regions(x, y)
     if not regs:
         raise _Fail("Error: empty region file or failed to parse regions.\n")

@@ -35,12 +35,13 @@ def _is_gz(fn):
 
 
 def load_regions(reg_file, reg_type):
-    """bed (0-based start) or tsv (1-based start) -> [Region] with id "chrom:start-end"; None on any error."""
+    """bed (0-based start), tsv (1-based start) -> [Region] with id "chrom:start-end", or gff (gene lines, id = gene id); None on any error."""
     if not reg_file or not os.path.isfile(reg_file) or not reg_type:
         return None
     reg_type = reg_type.lower()
-    if reg_type == "gff":
-        raise NotImplementedError("gff input needs the GTF gene parser, which is outside the accelerated path")
+    if reg_type == "gff":                               # gene records of a GTF / GFF3 annotation (utils/gregion.py:60-62)
+        from .gtf import load_gene_regions
+        return [Region(c, s, e, gid) for c, s, e, gid in load_gene_regions(reg_file)]
     if reg_type not in ("bed", "tsv"):
         return None
     with (gzip.open(reg_file, "rt") if _is_gz(reg_file) else open(reg_file, "r")) as fp:
