@@ -215,6 +215,10 @@ int64_t     xck_bam_ref_len(const xck_bam* b, int tid);
 /* records per reference from the .bai next to the file (XCK_E_IO if there is no usable index);
  * used to balance contigs over GPUs */
 int  xck_bam_ref_records(xck_bam* b, int tid, int64_t* n_mapped, int64_t* n_unmapped);
+/* the .bai linear index of one reference: virtual offset of the first record overlapping every 16 kb window (SAMv1 5.1.3);
+ * *n = 0 when the index has none.  The array belongs to the reader.  The compressed-byte distance between two windows
+ * weighs the reads between them: used to cut an over-weight contig into position windows of equal work. */
+int  xck_bam_linear_index(xck_bam* b, int tid, int64_t* n, const uint64_t** voffsets);
 
 typedef struct xck_ingest_opts {
     uint32_t struct_size;
@@ -228,6 +232,13 @@ typedef struct xck_ingest_opts {
                                    which at least this many further records were pushed by THIS call;
                                    the reader keeps its position and the next call continues
                                    (0 = run to the end of the file).  Read only when struct_size covers it. */
+    /* Position windows (multi-GPU: ONE over-weight contig split at region boundaries): for BAM tid t only the
+     * records from the first one that overlaps 0-based position tid_beg[t] (found through the .bai linear index; use_index = 1)
+     * up to the last one that STARTS before tid_end[t] are decoded; records that start earlier but reach into the window are
+     * included, so neighbouring windows share the reads that straddle the cut.  NULL = whole references.  tid_end[t] <= 0 =
+     * no upper bound.  Read only when struct_size covers them. */
+    const int32_t* tid_beg;
+    const int32_t* tid_end;
 } xck_ingest_opts;
 
 /* Decode the BAM with the engine's decoder settings and push every batch; returns the number

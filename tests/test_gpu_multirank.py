@@ -17,10 +17,26 @@ def _free_port():
         return str(sk.getsockname()[1])
 
 
-@pytest.mark.parametrize("name", ["multibam_basefc", "multibam_baf", "special_baf", "c1_basefc_default"])
-def test_two_ranks_match_reference(name, tmp_path):
-    env = dict(os.environ, XCK_DIST_BACKEND="gloo", XCK_DEVICE="0", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()                    # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 4), ("nccl", 2)])
+@pytest.mark.parametrize("name", ["multibam_basefc", "multibam_baf", "special_baf", "c1_basefc_default", "phasing_baf_refcells"])
+def test_ranks_match_reference(name, backend, world, tmp_path):
+    """gloo: the ranks share the one GPU of the test box and exchange host tensors; nccl: one GPU per rank, the per-rank
+    sparse blocks travel GPU to GPU over RCCL (runs only where at least two GPUs are visible - the driver's multi-GPU node)."""
+    if backend == "nccl" and _n_gpus() < world:
+        pytest.skip("the RCCL exchange needs %d visible GPUs" % world)
+    if world == 4 and name not in ("multibam_basefc", "special_baf"):
+        pytest.skip("world size 4 is rehearsed on two cases")
+    env = dict(os.environ, XCK_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":
+        env["XCK_DEVICE"] = "0"
+    else:
+        env.pop("XCK_DEVICE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                         "--master-addr", "127.0.0.1", "--master-port", _free_port(),
                         os.path.join(ROOT, "tests", "dist_worker.py"), name, str(tmp_path)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)

@@ -637,3 +637,56 @@ def test_native_snp_parser_declines_what_it_cannot_reproduce(tmp_path, monkeypat
     empty = str(tmp_path / "empty.tsv")
     open(empty, "w").write(head)
     assert len(F.load_snp_from_tsv(empty)) == 0
+
+
+def test_plan_units_cuts_an_overweight_contig_at_region_boundaries():
+    """a contig heavier than 1 / world of the reads is split at region boundaries into pieces of equal bytes."""
+    from xcltk_amd.shard import plan_units
+    regions = [("1", 1 + 10000 * i, 9000 + 10000 * i, "g%d" % i) for i in range(100)] + [("2", 100, 5000, "h0"), ("3", 1, 50, "k0")]
+    regions[10] = ("1", 100001, 400000, "long")                      # a long gene across many others
+    prof = {0: (np.arange(0, 64) * 1000).astype(np.int64)}             # bytes grow linearly along contig 1 (1 Mb = 62 windows)
+    units, owner = plan_units([1000.0, 30.0, 5.0], 4, regions, {"1": 0, "2": 1, "3": 2}, prof)
+    pieces = [u for u in units if u["contig"] == 0]
+    assert len(pieces) == 4 and all(u["window"] is not None for u in pieces)
+    seen = np.concatenate([u["regions"] for u in pieces])
+    assert sorted(seen.tolist()) == list(range(100))                   # every region of the contig in exactly one piece
+    for a, b in zip(pieces[:-1], pieces[1:]):
+        assert max(regions[g][1] for g in a["regions"]) <= min(regions[g][1] for g in b["regions"])   # cut in start order
+        assert a["window"][1] >= max(regions[g][2] for g in a["regions"]) and b["window"][0] == min(regions[g][1] for g in b["regions"]) - 1
+    assert pieces[0]["window"][0] == 0 and pieces[-1]["window"][1] == 0
+    loads = np.bincount(owner, weights=[u["weight"] for u in units], minlength=4)
+    assert loads.max() / loads.sum() < 0.4                             # 1000 of 1035 on one rank without the split
+    # a contig that is not over-weight, or has no byte profile, stays whole
+    units2, _ = plan_units([10.0, 9.0, 8.0], 2, regions, {"1": 0, "2": 1, "3": 2}, prof)
+    assert all(u["window"] is None for u in units2)
+    units3, _ = plan_units([1000.0, 30.0, 5.0], 4, regions, {"1": 0, "2": 1, "3": 2}, {})
+    assert len(units3) == 3
+
+
+def test_position_windows_decode_through_the_linear_index():
+    """xck_ingest_opts.tid_beg / tid_end: [0, X) gives exactly the records that start before X; [X, open) starts at the first
+    record the .bai linear index reports for X's window - a suffix of the file that holds every record reaching X or beyond."""
+    ddir = os.path.join(util.GOLDEN, "datasets", "c1")
+    regions, snps = util.load_tables(ddir)
+    names = O.contig_table(regions, snps)
+    with open(os.path.join(ddir, "barcodes.tsv")) as fp:
+        bcs = sorted(x.strip() for x in fp)
+    eng = Engine(capi.XCK_MODE_BAF, names, regions, len(bcs), snps=snps, barcodes=bcs, cell_tag="CB", umi_tag="UB", decode_only=True, n_threads=3)
+    bam = os.path.join(ddir, "possorted.bam")
+    try:
+        cat = lambda it, k: np.concatenate([b[k] for b in it] or [np.zeros(0, np.int64)])
+        full = list(eng.decode_bam(bam))
+        pos, umi = cat(full, "pos"), cat(full, "umi")
+        X = int(np.median(pos))
+        left = list(eng.decode_bam(bam, use_index=True, windows={0: (0, X)}))
+        assert np.array_equal(cat(left, "pos"), pos[pos < X]) and np.array_equal(cat(left, "umi"), umi[pos < X])
+        right = list(eng.decode_bam(bam, use_index=True, windows={0: (X, 0)}))
+        rp = cat(right, "pos")
+        k = len(pos) - len(rp)
+        assert 0 < k < len(pos) and np.array_equal(rp, pos[k:]) and np.array_equal(cat(right, "umi"), umi[k:])
+        assert pos[k:].min() <= X and (pos[:k] < X).all()              # starts left of X (the 16 kb window), nothing at / beyond X is missing
+        assert (X >> 14) << 14 <= pos[k] + 20000                       # ... and not at the start of the file: within reach of X's window
+        prof = eng.contig_byte_profile(bam, 0)
+        assert prof is not None and len(prof) >= (int(pos.max()) >> 14) and np.all(np.diff(prof[prof > 0]) >= 0)
+    finally:
+        eng.close()

@@ -127,6 +127,8 @@ def pileup(sam_fn=None, sam_list_fn=None, barcode_fn=None, sample_id_fn=None, sa
     eng = fcc.make_engine(conf, XCK_MODE_BAF, regions, snps)
     try:
         coo, dist = fcc.count_all(eng, conf, log_prefix="[pileup]")
+        if coo is not None:                                       # the matrices are views of the engine's pinned buffers: keep copies past close()
+            coo = {k: tuple(np.array(a) for a in v) for k, v in coo.items()}
     finally:
         eng.close()
     if coo is None:                                               # non-writer rank of a multi-GPU run

@@ -96,7 +96,8 @@ class Stats(C.Structure):
 class IngestOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("sample", C.c_int32),
                 ("tid_to_contig", C.POINTER(C.c_int32)), ("use_index", C.c_int32),
-                ("max_records", C.c_int64), ("pause_records", C.c_int64)]
+                ("max_records", C.c_int64), ("pause_records", C.c_int64),
+                ("tid_beg", C.POINTER(C.c_int32)), ("tid_end", C.POINTER(C.c_int32))]
 
 
 # every symbol include/xck.h declares: (name, restype, argtypes)
@@ -129,6 +130,7 @@ SYMBOLS = [
     ("xck_bam_ref_name", C.c_char_p, [C.c_void_p, C.c_int]),
     ("xck_bam_ref_len", C.c_int64, [C.c_void_p, C.c_int]),
     ("xck_bam_ref_records", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64), _P(C.c_int64)]),
+    ("xck_bam_linear_index", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64), _P(_P(C.c_uint64))]),
     ("xck_ingest_bam", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts), _P(C.c_int64)]),
     ("xck_bam_next_batch", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts), _P(Batch)]),
     ("xck_write_mtx", C.c_int, [C.c_char_p, _P(Coo), _P(C.c_int32), C.c_int32, C.c_int32]),

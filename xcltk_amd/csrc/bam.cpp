@@ -307,10 +307,21 @@ struct Chunk {
     std::vector<uint8_t> ubuf; size_t usize = 0;
     std::vector<WalkPart> parts;
     TaskGroup tg; std::atomic<bool> failed{false}; std::string err; std::mutex emu;
-    bool valid = false, new_range = false; uint32_t first_skip = 0;
+    bool valid = false, new_range = false; uint32_t first_skip = 0; int range_id = 0;
 };
 
 struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
+
+// BAM tid (+ record position) -> engine contig: -1 for references that are not wanted and for records that start at or
+// beyond the end of the position window of their reference (xck_ingest_opts.tid_end)
+struct ContigMap {
+    const int32_t* t2c = nullptr; const int32_t* t_end = nullptr; int n_refs = 0;
+    inline int32_t operator()(int32_t tid, int32_t pos) const {
+        if (tid < 0 || tid >= n_refs || !t2c) return -1;
+        if (t_end && t_end[tid] > 0 && pos >= t_end[tid]) return -1;
+        return t2c[tid];
+    }
+};
 
 // where the ingest time goes (XCK_DEBUG_TIMING=1 prints it when the reader is closed): pool-side CPU time summed over
 // threads, and the phases of the coordinating thread
@@ -323,13 +334,14 @@ static inline uint64_t ns_since(std::chrono::steady_clock::time_point t0) { retu
 
 // The BGZF block headers form a chain (every header gives the offset of the next one): a scanner thread walks it ahead of
 // the decoder - it also takes the page faults of the mapping - and hands over one plan per chunk.
-struct ChunkPlan { std::vector<BlockRef> blocks; size_t usize = 0; uint32_t first_skip = 0; bool new_range = false, failed = false, end = false; std::string err; };
+struct ChunkPlan { std::vector<BlockRef> blocks; size_t usize = 0; uint32_t first_skip = 0; int range_id = 0; bool new_range = false, failed = false, end = false; std::string err; };
 struct ScanRange { uint64_t coff; uint32_t skip; uint64_t stop; };
 class Scanner {
 public:
     Scanner(const uint8_t* map, uint64_t fsize, size_t chunk_target, std::vector<ScanRange> ranges)
         : map_(map), fsize_(fsize), target_(chunk_target), ranges_(std::move(ranges)) { th_ = std::thread([this] { run(); }); }
     ~Scanner() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+    void abandon(int range_id) { abandoned_.store(range_id); }          // the decoder has seen everything it wants of that range
     ChunkPlan next() {                                                  // blocks until a plan is ready; `end` after the last chunk
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return !q_.empty(); });
@@ -346,10 +358,12 @@ private:
         return true;
     }
     void run() {
-        for (const ScanRange& rg : ranges_) {
+        for (size_t ri = 0; ri < ranges_.size(); ri++) {
+            const ScanRange& rg = ranges_[ri];
             uint64_t coff = rg.coff; bool first = true, ended = false;
             while (!ended) {
-                ChunkPlan p; p.new_range = first; p.first_skip = first ? rg.skip : 0; first = false;
+                if (abandoned_.load() == (int)ri) break;
+                ChunkPlan p; p.new_range = first; p.first_skip = first ? rg.skip : 0; p.range_id = (int)ri; first = false;
                 size_t usz = 0;
                 while (usz < target_) {
                     if (coff > rg.stop) { ended = true; break; }          // end of the indexed range
@@ -369,6 +383,7 @@ private:
     }
     const uint8_t* map_; uint64_t fsize_; size_t target_; std::vector<ScanRange> ranges_;
     std::thread th_; std::mutex mu_; std::condition_variable cv_; std::deque<ChunkPlan> q_; bool stop_ = false;
+    std::atomic<int> abandoned_{-1};
 };
 
 constexpr int N_CHUNK = 3, N_SOA = 3;
@@ -378,11 +393,12 @@ struct xck_bam {
     uint64_t next_coff = 0;            // first BGZF block with alignment records
     // .bai: per reference [beg, end) virtual offsets + record counts (samtools pseudo-bin 37450 or bin chunks)
     bool idx_loaded = false, idx_ok = false;
-    std::vector<uint64_t> idx_beg, idx_end; std::vector<int64_t> idx_mapped, idx_unmapped;
+    std::vector<uint64_t> idx_beg, idx_end; std::vector<int64_t> idx_mapped, idx_unmapped; std::vector<std::vector<uint64_t>> idx_lin;
     std::vector<std::pair<uint64_t, uint64_t>> ranges; bool use_ranges = false, ranges_set = false;
     uint32_t first_skip = 0;           // bytes of the first block that precede the first record
     uint32_t stitch_skip = 0;          // same for the chunk being stitched
     Scanner* scanner = nullptr; bool scan_end = false;
+    bool per_tid_ranges = false; int skip_range = -1;   // position windows: one range per reference; a range is dropped once a record starts beyond its window
     Pool* pool = nullptr; int n_threads = 1;
     Chunk ch[N_CHUNK]; int head = 0, n_sched = 0;      // ring: ch[head] is decoded next, n_sched chunks are inflating / inflated
     std::vector<uint8_t> carry;        // partial record from the previous chunk
@@ -545,7 +561,7 @@ static void load_index(xck_bam* b) {
     size_t o = 4; auto need = [&](size_t k) { return o + k <= d.size(); };
     uint32_t n_ref = le32(d.data() + o); o += 4;
     if (n_ref != b->ref_names.size()) return;
-    b->idx_beg.assign(n_ref, ~0ull); b->idx_end.assign(n_ref, 0); b->idx_mapped.assign(n_ref, 0); b->idx_unmapped.assign(n_ref, 0);
+    b->idx_beg.assign(n_ref, ~0ull); b->idx_end.assign(n_ref, 0); b->idx_mapped.assign(n_ref, 0); b->idx_unmapped.assign(n_ref, 0); b->idx_lin.assign(n_ref, {});
     auto le64 = [&](size_t at) { return (uint64_t)le32(d.data() + at) | ((uint64_t)le32(d.data() + at + 4) << 32); };
     for (uint32_t r = 0; r < n_ref; r++) {
         if (!need(4)) return;
@@ -562,6 +578,8 @@ static void load_index(xck_bam* b) {
         if (!need(4)) return;
         uint32_t n_intv = le32(d.data() + o); o += 4;
         if (!need((size_t)n_intv * 8)) return;
+        b->idx_lin[r].resize(n_intv);
+        for (uint32_t w = 0; w < n_intv; w++) b->idx_lin[r][w] = le64(o + (size_t)w * 8);
         o += (size_t)n_intv * 8;
     }
     b->idx_ok = true;
@@ -573,22 +591,33 @@ static void set_ranges(xck_bam* b, const xck_ingest_opts* o) {
     if (!o->use_index || !o->tid_to_contig) return;
     load_index(b);
     if (!b->idx_ok) return;                                            // no usable index: decode everything
+    const bool has_win = o->struct_size >= offsetof(xck_ingest_opts, tid_end) + sizeof(void*) && (o->tid_beg || o->tid_end);
     std::vector<std::pair<uint64_t, uint64_t>> rg;
-    for (size_t t = 0; t < b->ref_names.size(); t++)
-        if (o->tid_to_contig[t] >= 0 && b->idx_beg[t] != ~0ull && b->idx_end[t] > b->idx_beg[t]) rg.push_back({b->idx_beg[t], b->idx_end[t]});
+    for (size_t t = 0; t < b->ref_names.size(); t++) {
+        if (!(o->tid_to_contig[t] >= 0 && b->idx_beg[t] != ~0ull && b->idx_end[t] > b->idx_beg[t])) continue;
+        uint64_t beg = b->idx_beg[t];
+        if (has_win && o->tid_beg && o->tid_beg[t] > 0) {                  // first record overlapping the window's first position: linear index
+            const std::vector<uint64_t>& lin = b->idx_lin[t];
+            const size_t w = (size_t)o->tid_beg[t] >> 14;
+            if (w >= lin.size()) continue;                               // nothing overlaps that far right
+            if (lin[w] > beg) beg = lin[w];
+        }
+        if (beg < b->idx_end[t]) rg.push_back({beg, b->idx_end[t]});
+    }
     std::sort(rg.begin(), rg.end());
-    for (auto& x : rg) { if (!b->ranges.empty() && (x.first >> 16) <= (b->ranges.back().second >> 16) + 1) b->ranges.back().second = std::max(b->ranges.back().second, x.second); else b->ranges.push_back(x); }
+    b->per_tid_ranges = has_win;
+    for (auto& x : rg) { if (!has_win && !b->ranges.empty() && (x.first >> 16) <= (b->ranges.back().second >> 16) + 1) b->ranges.back().second = std::max(b->ranges.back().second, x.second); else b->ranges.push_back(x); }
     b->use_ranges = true;
 }
 
 // take the next plan from the scanner and start inflating it into c (asynchronous); tid_to_contig lets the walk tasks
 // prepare the output layout of their own records
-static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const int32_t* t2c, int n_refs, bool want_seq) {
+static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMap cm, bool want_seq) {
     c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0;
     if (b->scan_end) return;
     ChunkPlan pl = b->scanner->next();
     if (pl.end) { b->scan_end = true; return; }
-    c.blocks.swap(pl.blocks); c.new_range = pl.new_range; c.first_skip = pl.first_skip;
+    c.blocks.swap(pl.blocks); c.new_range = pl.new_range; c.first_skip = pl.first_skip; c.range_id = pl.range_id;
     if (pl.failed) { c.failed = true; c.err = pl.err; }
     if (c.blocks.empty() && !c.failed) return;
     c.valid = true; c.usize = pl.usize;
@@ -606,7 +635,7 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const int32_t*
         wp.spec_start = wp.u_begin + (pi == 0 ? skip0 : 0); wp.stop = wp.spec_start; wp.recs.clear();
         wp.n_out = wp.n_cig = wp.n_seq = 0; wp.runs.clear();
         Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp; DecodeTimes* tmp_ = &b->tm;
-        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp, tmp_, t2c, n_refs, want_seq] {
+        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp, tmp_, cm, want_seq] {
             if (!t_zs.ok) { cp->failed = true; return; }
             const auto t_a = std::chrono::steady_clock::now();
             struct Acc { DecodeTimes* t; std::chrono::steady_clock::time_point a, b; bool walked = false;
@@ -629,7 +658,7 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const int32_t*
                 if (bs < 32 || o + 4 + (size_t)bs > end) break;
                 const uint8_t* r = u + o + 4;
                 const RecRef rr{r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)};
-                const int32_t ctg = (rr.tid >= 0 && rr.tid < n_refs && t2c) ? t2c[rr.tid] : -1;
+                const int32_t ctg = cm(rr.tid, (int32_t)le32(r + 4));
                 if (ctg != cur_c) { wpp->runs.push_back({(uint32_t)wpp->recs.size(), ctg}); cur_c = ctg; }
                 if (ctg >= 0) { wpp->n_out++; wpp->n_cig += rr.n_cig; if (want_seq) wpp->n_seq += (rr.l_seq + 1) / 2; }
                 wpp->recs.push_back(rr);
@@ -734,7 +763,7 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
 }
 
 // fast path: the records of one walk part, whose output slots start at the part's bases (prefix sums over the parts)
-static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart* wp, const int32_t* t2c, int n_refs, std::atomic<int>* flags) {
+static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart* wp, const ContigMap cm, std::atomic<int>* flags) {
     const auto t_parse0 = std::chrono::steady_clock::now();
     struct PAcc { xck_bam* b; std::chrono::steady_clock::time_point t0; ~PAcc() { b->tm.parse += ns_since(t0); } } pacc{b, t_parse0};
     const DecodeCfg& dc = e->dec;
@@ -743,7 +772,7 @@ static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart
     if (!dc.use_umi) names.reserve(wp->n_out);
     int64_t o = (int64_t)wp->out_base; uint32_t co = (uint32_t)wp->cig_base, so = (uint32_t)wp->seq_base;
     for (const RecRef& rr : wp->recs) {
-        const int32_t ctg = (rr.tid >= 0 && rr.tid < n_refs && t2c) ? t2c[rr.tid] : -1;
+        const int32_t ctg = cm(rr.tid, (int32_t)le32(rr.p + 4));
         if (ctg < 0) continue;
         s.cig_off[o] = co; s.seq_off[o] = so;
         parse_record(dc, e, s, rr.p, rr.len, o, sample, names, flags);
@@ -757,6 +786,8 @@ static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
     const int n_refs = (int)b->ref_names.size();
+    const bool has_win = o->struct_size >= offsetof(xck_ingest_opts, tid_end) + sizeof(void*);
+    ContigMap cm; cm.t2c = o->tid_to_contig; cm.n_refs = n_refs; cm.t_end = has_win ? o->tid_end : nullptr;
     if (!b->ranges_set) {
         // well mode without UMIs: the key is the read name and the column is the BAM itself, so names only
         // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads)
@@ -772,7 +803,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     // keep the ring full: while this chunk is stitched and parsed the pool inflates the next two
     while (b->n_sched < N_CHUNK && !b->scan_end) {
         Chunk& nc = b->ch[(b->head + b->n_sched) % N_CHUNK];
-        schedule_chunk(b, nc, crc, o->tid_to_contig, n_refs, e->dec.want_seq);
+        schedule_chunk(b, nc, crc, cm, e->dec.want_seq);
         if (b->scan_end) break;
         b->n_sched++;
     }
@@ -783,6 +814,11 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     }
     Chunk& c = b->ch[b->head];
     c.tg.wait();
+    if (b->skip_range >= 0 && c.range_id == b->skip_range && !c.failed) {   // rest of a reference whose position window is behind us
+        b->head = (b->head + 1) % N_CHUNK; b->n_sched--;
+        b->carry.clear();
+        return decode_next_chunk(e, b, o);
+    }
     phase(b->tm.wait_inflate); b->tm.chunks++;
     if (c.failed) { b->err = c.err.empty() ? "BGZF decode error" : c.err; return XCK_E_IO; }
     if (c.new_range) {                                                  // start of the file's records / of an index range
@@ -837,9 +873,9 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
           }
           if (cur_c >= 0 && (int64_t)n_out > seg0) b->pending.push_back({cur_c, seg0, (int64_t)n_out, ord_hi | (uint64_t)(b->n_records + seg_r)}); }
         phase(b->tm.layout);
-        { TaskGroup tg; const int32_t smp = o->sample; const int32_t* t2c = o->tid_to_contig;
+        { TaskGroup tg; const int32_t smp = o->sample;
           for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
-              tg.add(*b->pool, [b, e, smp, wpp, t2c, n_refs, &flags] { parse_part(b, e, smp, wpp, t2c, n_refs, &flags); }); }
+              tg.add(*b->pool, [b, e, smp, wpp, cm, &flags] { parse_part(b, e, smp, wpp, cm, &flags); }); }
           tg.wait(); }
         phase(b->tm.wait_parse);
         limit = (int64_t)n_rec;
@@ -858,7 +894,6 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             else { b->stitch.insert(b->stitch.end(), u + off, u + usz); off = usz; b->carry.swap(b->stitch); }   // record larger than a chunk
         } else { b->carry.swap(b->stitch); }
     }
-    auto contig_of = [&](int32_t tid) { return (tid >= 0 && tid < n_refs && o->tid_to_contig) ? o->tid_to_contig[tid] : -1; };
     if (!b->stitch.empty()) {
         if (b->stitch.size() < 36) { b->err = "corrupt BAM record"; return XCK_E_IO; }
         const uint8_t* r = b->stitch.data() + 4;
@@ -888,7 +923,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     if (off < usz) b->carry.insert(b->carry.end(), u + off, u + usz);
     phase(b->tm.stitch);
     b->rec_contig.resize(b->recs.size());
-    for (size_t r = 0; r < b->recs.size(); r++) b->rec_contig[r] = contig_of(b->recs[r].tid);
+    for (size_t r = 0; r < b->recs.size(); r++) b->rec_contig[r] = cm(b->recs[r].tid, (int32_t)le32(b->recs[r].p + 4));
     // ---- output layout: prefix sums + batch segmentation ----
     const int64_t nrec = (int64_t)b->recs.size();
     limit = nrec;
@@ -924,6 +959,14 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     }
     if (flags.load() & 1) { b->err = "corrupt BAM record (fields exceed block_size)"; return XCK_E_IO; }
     if (flags.load() & 2) { b->err = "too many distinct non-ACGT keys for the key width"; return XCK_E_CAPACITY; }
+    if (b->per_tid_ranges && cm.t_end) {                               // last record of the chunk starts beyond its reference's window: drop the rest
+        const RecRef* last = nullptr;
+        if (fast) { for (size_t pi = c.parts.size(); pi-- > 0 && !last;) if (!c.parts[pi].recs.empty()) last = &c.parts[pi].recs.back(); }
+        else if (!b->recs.empty()) last = &b->recs.back();
+        if (last && last->tid >= 0 && last->tid < n_refs && cm.t_end[last->tid] > 0 && (int32_t)le32(last->p + 4) >= cm.t_end[last->tid]) {
+            b->skip_range = c.range_id; b->scanner->abandon(c.range_id);
+        }
+    }
     b->n_records += limit;
     b->head = (b->head + 1) % N_CHUNK; b->n_sched--;
     if (hit_limit) { b->done = true; for (auto& cc : b->ch) cc.tg.wait(); }
@@ -938,6 +981,14 @@ int xck_bam_ref_records(xck_bam* b, int tid, int64_t* n_mapped, int64_t* n_unmap
     if (!b->idx_ok) return XCK_E_IO;
     if (n_mapped) *n_mapped = b->idx_mapped[tid];
     if (n_unmapped) *n_unmapped = b->idx_unmapped[tid];
+    return XCK_OK;
+}
+
+int xck_bam_linear_index(xck_bam* b, int tid, int64_t* n, const uint64_t** voffsets) {
+    if (!b || !n || !voffsets || tid < 0 || tid >= (int)b->ref_names.size()) return XCK_E_ARG;
+    load_index(b);
+    if (!b->idx_ok) return XCK_E_IO;
+    *n = (int64_t)b->idx_lin[tid].size(); *voffsets = b->idx_lin[tid].data();
     return XCK_OK;
 }
 

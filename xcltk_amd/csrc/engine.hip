@@ -1040,14 +1040,14 @@ __device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t 
 // per key run: allele code + ordinal of its first read with a base, at the run head; first / one-past-last index of every SNP
 template <class K>
 __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
-                             uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, uint32_t* __restrict__ row_lo, uint32_t* __restrict__ row_hi,
+                             uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, unsigned long long* __restrict__ row_lo, unsigned long long* __restrict__ row_hi,
                              unsigned long long* __restrict__ bloom, unsigned long long bloom_mask) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const K me = k[i];
     const uint32_t row = kl.row(me);
-    if (i == 0 || kl.row(k[i - 1]) != row) row_lo[row] = (uint32_t)i;
-    if (i + 1 == n || kl.row(k[i + 1]) != row) row_hi[row] = (uint32_t)(i + 1);
+    if (i == 0 || kl.row(k[i - 1]) != row) row_lo[row] = (unsigned long long)i;
+    if (i + 1 == n || kl.row(k[i + 1]) != row) row_hi[row] = (unsigned long long)(i + 1);
     if (i > 0 && k[i - 1] == me) { al_out[i] = 0; return; }
     uint64_t best = v[i];
     for (long long j = i + 1; j < n && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
@@ -1067,7 +1067,7 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
 // neighbouring threads search the same few SNPs and stay in L2).
 template <class K>
 __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp,
-                                                 const K* __restrict__ keys, KeyLayout<K> kl, const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ row_hi,
+                                                 const K* __restrict__ keys, KeyLayout<K> kl, const unsigned long long* __restrict__ row_lo, const unsigned long long* __restrict__ row_hi,
                                                  const uint64_t* __restrict__ ord, uint8_t* __restrict__ al,
                                                  const unsigned long long* __restrict__ bloom, unsigned long long bloom_mask, uint32_t n_rows) {
     const unsigned long long n = sp.start[NSHARD];
@@ -1089,11 +1089,11 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
             for (uint32_t srow = max(k1, blk << 5); srow < min(k2, (blk + 1) << 5); srow++) {
                 bloom_slot((unsigned long long)cellumi, 0x80000000u | srow, bloom_mask, word, bits);
                 if ((bloom[word] & bits) != bits) continue;             // ... and none at this SNP
-                uint32_t lo = row_lo[srow], hi = row_hi[srow];
+                unsigned long long lo = row_lo[srow], hi = row_hi[srow];
                 if (lo >= hi) continue;
-                const uint32_t end = hi;
+                const unsigned long long end = hi;
                 const K key = (K(srow) << low) | cellumi;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const unsigned long long mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
                 if (lo < end && keys[lo] == key && ordn < ord[lo]) al[lo] = 0;   // benign race: every writer stores 0
             }
         }
@@ -1180,36 +1180,105 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
     }
 }
 
-// BAF step 3: haplotype set algebra per (row, cell) run, baf/fc/core.py:173-192.
+// BAF step 3: haplotype set algebra per (row, cell) run, baf/fc/core.py:173-192, without any thread walking a (row, cell) run
+// (a SMART-seq cell holds hundreds of thousands of read names in its most expressed gene; one run = one thread would serialise).
+//   k_hap_class: head of every (row, cell, UMI) run: OR of the run's haplotype bits (one entry per SNP the molecule meets: a few)
+//   k_hap_sum  : per 2048-key tile, ONE block scan of four packed counters (REF-hap, ALT-hap, either, other-only keys); a run
+//                that starts in the tile gets its counts up to the tile end, what later tiles hold of it arrives by atomicAdd
+//   k_hap_final: the no_dup_hap arithmetic on the per-run sums -> AD / DP / OTH per run
 template <class K>
-__global__ void k_hap_counts(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, KeyLayout<K> kl,
-                             int no_dup_hap, int32_t* __restrict__ ad, int32_t* __restrict__ dp, int32_t* __restrict__ oth) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_hap_class(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, uint8_t* __restrict__ cls) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    K me = k[i];
-    K rc = kl.rc(me);
-    if (i > 0 && kl.rc(k[i - 1]) == rc) { ad[i] = 0; dp[i] = 0; oth[i] = 0; return; }
-    int32_t ref = 0, alt = 0, uni = 0, ot = 0;
-    K cur = me; uint32_t bits = v[i];
-    for (long long j = i + 1; ; j++) {
-        bool more = j < n;
-        K x = 0;
-        if (more) { x = k[j]; more = kl.rc(x) == rc; }
-        if (!more || x != cur) {
-            if (bits & 1) ref++;
-            if (bits & 2) alt++;
-            if (bits & 3) uni++; else if (bits & 4) ot++;
-            if (!more) break;
-            cur = x; bits = 0;
+    const K me = k[i];
+    if (i > 0 && k[i - 1] == me) { cls[i] = 0; return; }
+    uint32_t bits = v[i];
+    for (long long j = i + 1; j < n && k[j] == me; j++) bits |= v[j];
+    cls[i] = (uint8_t)bits;                                               // 1 REF haplotype, 2 ALT haplotype, 4 other allele; never 0 at a head
+}
+
+__device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long* s_wave, unsigned long long& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < FD_BLOCK / 64; w++) { const unsigned long long t = s_wave[w]; if (w < wave) base += t; total += t; }
+    __syncthreads();
+    return base + inc - v;
+}
+
+template <class K>
+__global__ __launch_bounds__(FD_BLOCK) void k_hap_sum(const K* __restrict__ k, const uint8_t* __restrict__ cls, long long n, KeyLayout<K> kl,
+                                                      const unsigned long long* __restrict__ off, K* __restrict__ run_key, uint32_t* __restrict__ acc, long long stride) {
+    // acc[f * stride + run]: f = 0 REF-hap keys, 1 ALT-hap keys, 2 keys on either haplotype, 3 keys with only another allele; zero on entry
+    __shared__ uint32_t s_wave[FD_BLOCK / 64];
+    __shared__ unsigned long long s_wave64[FD_BLOCK / 64];
+    __shared__ K tile[FD_TILE + 1];                                       // tile[0] = key before the tile (halo)
+    __shared__ unsigned long long s_x[FD_TILE + 1];                       // per head: packed counters before it (4 x 16 bits: a tile holds 2048 keys)
+    __shared__ uint16_t s_he[FD_TILE];
+    const long long base = (long long)blockIdx.x * FD_TILE;
+    const int n_loc = (int)min((long long)FD_TILE, n - base);
+#pragma unroll
+    for (int t = 0; t < FD_ITEMS; t++) { const int e = t * FD_BLOCK + threadIdx.x; if (e < n_loc) tile[1 + e] = k[base + e]; }
+    if (threadIdx.x == 0) tile[0] = base > 0 ? k[base - 1] : K(0);
+    __syncthreads();
+    const int e0 = threadIdx.x * FD_ITEMS;                                // blocked: thread t owns elements [t * FD_ITEMS, (t + 1) * FD_ITEMS)
+    uint32_t hmask = 0; unsigned long long c[FD_ITEMS], sum = 0;
+    K prev = tile[e0];
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        const int e = e0 + q; c[q] = 0;
+        if (e < n_loc) {
+            const K me = tile[1 + e];
+            if (base + e == 0 || kl.rc(me) != kl.rc(prev)) hmask |= 1u << q;
+            const uint32_t bits = cls[base + e];
+            c[q] = (unsigned long long)(bits & 1u) | ((unsigned long long)((bits >> 1) & 1u) << 16) | ((unsigned long long)((bits & 3u) ? 1u : 0u) << 32)
+                 | ((unsigned long long)((!(bits & 3u) && (bits & 4u)) ? 1u : 0u) << 48);
+            sum += c[q];
+            prev = me;
         }
-        bits |= v[j];
     }
-    int32_t d = uni;
+    uint32_t n_heads; unsigned long long tot;
+    uint32_t r = block_excl_scan((uint32_t)__popc(hmask), s_wave, n_heads);
+    unsigned long long xd = block_excl_scan64(sum, s_wave64, tot);
+#pragma unroll
+    for (int q = 0; q < FD_ITEMS; q++) {
+        if (hmask & (1u << q)) { s_x[r] = xd; s_he[r] = (uint16_t)(e0 + q); r++; }
+        xd += c[q];
+    }
+    if (threadIdx.x == 0) s_x[n_heads] = tot;
+    __syncthreads();
+    const unsigned long long out = off[blockIdx.x];
+    auto add = [&](unsigned long long d, unsigned long long x, bool atomic) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) { const uint32_t val = (uint32_t)((x >> (16 * f)) & 0xffffu); if (!val) continue;
+            if (atomic) atomicAdd(&acc[(size_t)f * stride + d], val); else acc[(size_t)f * stride + d] = val; }
+    };
+    for (uint32_t i = threadIdx.x; i < n_heads; i += FD_BLOCK) {
+        const unsigned long long d = out + i;
+        run_key[d] = tile[1 + s_he[i]];
+        add(d, s_x[i + 1] - s_x[i], i + 1 == n_heads);                    // monotone fields: the packed difference needs no borrow; the last run may continue
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long lead = n_heads ? s_x[0] : tot;          // keys of the run that the previous tiles started
+        if (lead && out > 0) add(out - 1, lead, true);
+    }
+}
+
+__global__ void k_hap_final(const uint32_t* __restrict__ acc, long long n_runs_max, const unsigned long long* __restrict__ n_runs, long long stride, int no_dup_hap,
+                            int32_t* __restrict__ ad, int32_t* __restrict__ dp, int32_t* __restrict__ oth) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_runs_max || (unsigned long long)i >= *n_runs) return;     // (ad / dp / oth are zero beyond the runs)
+    int32_t ref = (int32_t)acc[i], alt = (int32_t)acc[stride + i], d = (int32_t)acc[2 * stride + i]; const int32_t ot = (int32_t)acc[3 * stride + i];
     if (ref + alt != d) {
-        if (no_dup_hap) { int32_t share = ref + alt - d; ref -= share; alt -= share; }
+        if (no_dup_hap) { const int32_t share = ref + alt - d; ref -= share; alt -= share; }
         d = ref + alt;
     }
-    if (d + ot <= 0) { ad[i] = 0; dp[i] = 0; oth[i] = 0; return; }
+    if (d + ot <= 0) return;
     ad[i] = alt > 0 ? alt : 0; dp[i] = d > 0 ? d : 0; oth[i] = ot > 0 ? ot : 0;
 }
 
@@ -1810,10 +1879,10 @@ struct Timer {
 
 // One radix sort over key bits [0, top).  (rocPRIM's mid-size merge path is not stable, so the classic
 // "sort the low range, then the high range" trick to skip the all-zero bits between the used UMI bits and
-// the cell field is NOT safe with it - measured on gfx950, tools/scratch/sorttest.hip.)
+// the cell field is NOT safe with it - measured on gfx950, profiles/experiments/sorttest.hip.)
 // Keys-only sort of 64-bit keys: sort kernel at 1024 threads x 8 keys and histogram kernel at 512 x 32 instead of rocPRIM
 // 4.2's tuned default for gfx950 (512 x 12 for both): 7.90 ms instead of 9.42 ms for 380 M keys over 32 bits
-// (tools/scratch/sortcfg.hip, profiles/r01_g_sort_configs.log; 10-bit digits, which would need one pass fewer, are
+// (profiles/experiments/sortcfg.hip, profiles/r01_g_sort_configs.log; 10-bit digits, which would need one pass fewer, are
 // slower: 5.3 ms vs 4.5 ms at 200 M keys).  Everything else keeps the defaults.
 template <class K>
 using KeySortConfig = typename std::conditional<sizeof(K) == 8,
@@ -1938,8 +2007,6 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
         if (sorted_from > 0) {
             HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_GIANT, 0, sizeof(unsigned long long), im->s_comp));
             KeyLayout<unsigned long long> kl8; kl8.ubits = kl.ubits; kl8.cbits = kl.cbits;
-            static bool lds_set = false;
-            if (!lds_set) { HIP_TRY(hipFuncSetAttribute((const void*)k_fold_emit_unsorted, hipFuncAttributeMaxDynamicSharedMemorySize, FU_SLOTS * 8)); lds_set = true; }
             hipLaunchKernelGGL(k_fold_emit_unsorted, dim3(nb), dim3(FU_BLOCK), FU_SLOTS * 8, im->s_comp, (const unsigned long long*)keys, (long long)n, kl8, d_off,
                                d_o, d_o + total, d_o + 2 * total, im->d_ctl + CTL_GIANT, sorted_from);
             HIP_TRY(hipGetLastError());
@@ -1998,7 +2065,6 @@ static int finish_t(EngineImpl* im) {
             im->h_ctl[4], im->h_ctl[5], im->h_ctl[6], im->h_ctl[7], im->h_ctl[8], im->h_ctl[9], im->h_ctl[10]);
 #endif
     if (n == 0) return 0;
-    if (n >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 hits in one finish() is not supported yet"; return XCK_E_CAPACITY; }
     Timer tm{im, im->ev0, im->ev1};
     int rc;
     const int top = im->ubits + im->cbits + im->rbits;
@@ -2024,7 +2090,7 @@ static int finish_t(EngineImpl* im) {
         // 64-bit keys: the radix sort only orders (row, cell) - 4 passes instead of 7 - and the fold tells the UMIs of a run
         // apart with an LDS hash set; a run too long for that (FOLD_GIANT) is redone on fully sorted keys
         static const bool full_sort = getenv("XCK_FULL_SORT") && atoi(getenv("XCK_FULL_SORT"));
-        // (rocPRIM 4.2 returns garbage for begin_bit > 0 with end_bit = 64 - tools/scratch/sortpart.hip - so keys that could not be
+        // (rocPRIM 4.2 returns garbage for begin_bit > 0 with end_bit = 64 - profiles/experiments/sortpart.hip - so keys that could not be
         // squeezed below 63 bits take the classic path)
         const bool partial = sizeof(K) == 8 && !full_sort && top_fc <= 62;
         // whole 8-bit digits from the top: the (row, cell) bits plus whatever UMI bits the last digit reaches for free.  A run
@@ -2048,7 +2114,7 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 8 + std::max<size_t>(n * 8, 8192) + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 16 + std::max<size_t>(n * 8, 8192) + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
         { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
@@ -2060,11 +2126,11 @@ static int finish_t(EngineImpl* im) {
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
         if (sizeof(K) == 8 && split_mode(im)) {
             const size_t ns = std::max<size_t>((size_t)im->n_snps_sorted, 1);
-            uint64_t* ordv = im->ws1.get<uint64_t>(n); uint32_t* row_lo = im->ws1.get<uint32_t>(2 * ns); uint32_t* row_hi = row_lo + ns;
+            uint64_t* ordv = im->ws1.get<uint64_t>(n); unsigned long long* row_lo = im->ws1.get<unsigned long long>(2 * ns); unsigned long long* row_hi = row_lo + ns;
             size_t bw = 1024; while (bw < n / 2) bw <<= 1;                // two entries per run, ~4 entries (8 bits) per 64-bit word
             unsigned long long* bloom = im->ws1.get<unsigned long long>(bw);
             if (!ordv || !row_lo || !bloom) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
-            HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(uint32_t), im->s_comp));
+            HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(unsigned long long), im->s_comp));
             HIP_TRY(hipMemsetAsync(bloom, 0, bw * sizeof(unsigned long long), im->s_comp));
             hipLaunchKernelGGL((k_first_base<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, ordv, row_lo, row_hi,
                                bloom, (unsigned long long)(bw - 1));
@@ -2073,7 +2139,7 @@ static int finish_t(EngineImpl* im) {
                 ShardSpan nsp; nsp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh];
                 hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<size_t>((im->ncursor + 255) / 256, 16384)), dim3(256), 0, im->s_comp,
                                    (const K*)im->d_nkeys, (const uint64_t*)im->d_nvals, (unsigned long long)im->hit_cap, nsp,
-                                   (const K*)alt, kl, (const uint32_t*)row_lo, (const uint32_t*)row_hi, (const uint64_t*)ordv, al,
+                                   (const K*)alt, kl, (const unsigned long long*)row_lo, (const unsigned long long*)row_hi, (const uint64_t*)ordv, al,
                                    (const unsigned long long*)bloom, (unsigned long long)(bw - 1), (uint32_t)ns);
                 HIP_TRY(hipGetLastError());
             }
@@ -2093,11 +2159,10 @@ static int finish_t(EngineImpl* im) {
         HIP_TRY(hipStreamSynchronize(im->s_comp));
         size_t n2 = 0;
         for (int sh = 0; sh < XSHARD; sh++) { xb.base[sh] = n2; n2 += im->h_ctl[CTL_X0 + sh * CTL_STRIDE]; }
-        if (n2 >= (size_t(1) << 32)) { im->eng->err = "more than 2^32 region hits"; return XCK_E_CAPACITY; }
         if (n2) {
             const size_t tmpb2 = sort_tmp_bytes<K, uint8_t>(n2, top);
             const size_t nb2 = (n2 + CP_TILE - 1) / CP_TILE;
-            if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + (1 << 16)))) return rc;
+            if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + 4 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (1 << 16)))) return rc;
             K* k2 = im->ws2.get<K>(n2); K* k2b = im->ws2.get<K>(n2); uint8_t* v2 = im->ws2.get<uint8_t>(n2); uint8_t* v2b = im->ws2.get<uint8_t>(n2);
             void* tmp2 = im->ws2.get<char>(tmpb2); int32_t* dense = im->ws2.get<int32_t>(3 * n2);
             hipLaunchKernelGGL((k_expand<K, true>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
@@ -2105,10 +2170,22 @@ static int finish_t(EngineImpl* im) {
             HIP_TRY(hipGetLastError());
             if ((rc = sort_run<K, uint8_t>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
             const unsigned gs2 = (unsigned)((n2 + 255) / 256);
-            hipLaunchKernelGGL((k_hap_counts<K>), dim3(gs2), dim3(256), 0, im->s_comp, k2b, v2b, (long long)n2, kl, im->no_dup_hap,
-                               dense, dense + n2, dense + 2 * n2);
+            const size_t nt2 = (n2 + FD_TILE - 1) / FD_TILE;
+            uint8_t* cls = v2;                                              // (the unsorted values are dead after the sort)
+            uint32_t* d_blk2 = im->ws2.get<uint32_t>(nt2); unsigned long long* d_off2 = im->ws2.get<unsigned long long>(nt2);
+            uint32_t* acc = im->ws2.get<uint32_t>(4 * n2); K* run_key = k2;  // (so are the unsorted keys)
+            if (!d_blk2 || !d_off2 || !acc) { im->eng->err = "workspace exhausted (haplotype sums)"; return XCK_E_NOMEM; }
+            HIP_TRY(hipMemsetAsync(acc, 0, 4 * n2 * sizeof(uint32_t), im->s_comp));
+            HIP_TRY(hipMemsetAsync(dense, 0, 3 * n2 * sizeof(int32_t), im->s_comp));
+            hipLaunchKernelGGL((k_hap_class<K>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const uint8_t*)v2b, (long long)n2, cls);
+            hipLaunchKernelGGL((k_fold_heads<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (long long)n2, kl, d_blk2);
+            hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk2, (long long)nt2, d_off2, im->d_ctl + CTL_SCRATCH);
+            hipLaunchKernelGGL((k_hap_sum<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (const uint8_t*)cls, (long long)n2, kl,
+                               (const unsigned long long*)d_off2, run_key, acc, (long long)n2);
+            hipLaunchKernelGGL(k_hap_final, dim3(gs2), dim3(256), 0, im->s_comp, (const uint32_t*)acc, (long long)n2, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH),
+                               (long long)n2, im->no_dup_hap, dense, dense + n2, dense + 2 * n2);
             HIP_TRY(hipGetLastError());
-            if ((rc = compact_coo<K>(im, im->ws2, dense, k2b, n2, kl, 1, 3))) return rc;          // AD, DP, OTH together
+            if ((rc = compact_coo<K>(im, im->ws2, dense, run_key, n2, kl, 1, 3))) return rc;          // AD, DP, OTH together (one entry per run; zeros beyond the runs)
         }
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     }
@@ -2222,6 +2299,9 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     im->st.key_bits = im->key_bits; im->st.umi_bits = im->ubits;
     im->max_batch_reads = cfg->max_batch_reads > 0 ? cfg->max_batch_reads : (int64_t)1 << 21;
     int rc = build_tables(im, cfg); if (rc) return rc;
+    // the hash fold needs 64 KB of dynamic LDS: raise the limit on THIS engine's device (a per-process flag would leave every
+    // device but the first at the 64 KB default and race between engines created from different threads)
+    HIP_TRY(hipFuncSetAttribute((const void*)k_fold_emit_unsorted, hipFuncAttributeMaxDynamicSharedMemorySize, FU_SLOTS * 8));
     HIP_TRY(hipStreamCreateWithFlags(&im->s_copy, hipStreamNonBlocking));
     { int lo = 0, hi = 0;                                   // numerically lowest value = highest priority
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));

@@ -45,11 +45,12 @@ class Engine(object):
     def __init__(self, mode, contig_names, regions, n_cells, snps=(), barcodes=None,
                  cell_tag=None, umi_tag=None, device=0, min_mapq=20, min_len=30,
                  incl_flag=0, excl_flag=772, no_orphan=True, min_include=0.9, min_count=1,
-                 min_maf=0, no_dup_hap=True, n_threads=0, flags=0, decode_only=False, excl_pairs=None):
+                 min_maf=0, no_dup_hap=True, n_threads=0, flags=0, decode_only=False, excl_pairs=None, region_mask=None):
         """regions: iterable of (chrom, start1, end1_incl[, name]); snps: iterable of
         (chrom, pos1, ref, alt, ref_hap, alt_hap); chrom names must already be stripped of
         'chr' and present in contig_names.  excl_pairs = (region indices, snp indices): pairs left out of the SNP -> region
-        join (region-wise local phasing, xck_config.excl_*)."""
+        join (region-wise local phasing, xck_config.excl_*).  region_mask (bool per region): regions that are False keep
+        their row index but are not counted by this engine (multi-GPU: another rank owns them)."""
         self.lib = capi.load()
         self.mode = mode
         self.contig_names = list(contig_names)
@@ -63,6 +64,8 @@ class Engine(object):
             self._reg["contig"] = [cidx[r[0]] for r in regions]
             self._reg["start"] = [r[1] for r in regions]
             self._reg["end"] = [r[2] for r in regions]
+            if region_mask is not None:
+                self._reg["contig"][~np.asarray(region_mask, dtype=bool)] = -1
         self._snp = np.zeros(len(snps), dtype=capi.SNP_DTYPE)
         if isinstance(snps, SnpTable):
             if len(snps):
@@ -177,7 +180,9 @@ class Engine(object):
         refs = [self.lib.xck_bam_ref_name(b, i).decode() for i in range(self.lib.xck_bam_n_refs(b))]
         return b, refs
 
-    def _opts(self, refs, sample, max_records=0, contig_mask=None, use_index=False):
+    def _opts(self, refs, sample, max_records=0, contig_mask=None, use_index=False, windows=None):
+        """windows: {engine contig id: (beg0, end0)} - only the records of that contig from the first one overlapping beg0 up to
+        the last one starting before end0 (0 / None = open end) are decoded (needs use_index and a .bai with a linear index)."""
         t2c = resolve_contigs(refs, self.contig_names)
         if contig_mask is not None:                     # multi-GPU: this rank only owns some contigs
             keep = np.asarray(contig_mask, dtype=bool)
@@ -188,6 +193,13 @@ class Engine(object):
         o.tid_to_contig = t2c.ctypes.data_as(C.POINTER(C.c_int32))
         o.max_records = max_records
         o.use_index = 1 if use_index else 0
+        if windows:
+            beg = np.zeros(len(refs), dtype=np.int32); end = np.zeros(len(refs), dtype=np.int32)
+            for tid, c in enumerate(t2c.tolist()):
+                if c >= 0 and c in windows:
+                    beg[tid], end[tid] = int(windows[c][0] or 0), int(windows[c][1] or 0)
+            o.tid_beg = beg.ctypes.data_as(C.POINTER(C.c_int32)); o.tid_end = end.ctypes.data_as(C.POINTER(C.c_int32))
+            o._keep = (beg, end)
         return o, t2c
 
     def contig_record_counts(self, path):
@@ -207,13 +219,30 @@ class Engine(object):
         finally:
             self.lib.xck_bam_close(b)
 
-    def ingest_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False):
+    def contig_byte_profile(self, path, contig):
+        """Compressed file offset of the first record overlapping every 16 kb window of one engine contig (from the .bai linear
+        index; None without one): differences weigh the reads between two positions."""
+        b, refs = self._open(path, 1)
+        try:
+            t2c = resolve_contigs(refs, self.contig_names)
+            tids = [t for t, c in enumerate(t2c.tolist()) if c == contig]
+            if not tids:
+                return None
+            n, ptr = C.c_int64(0), C.POINTER(C.c_uint64)()
+            if self.lib.xck_bam_linear_index(b, tids[0], C.byref(n), C.byref(ptr)) != 0 or n.value == 0:
+                return None
+            v = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+            return (v >> np.uint64(16)).astype(np.int64)
+        finally:
+            self.lib.xck_bam_close(b)
+
+    def ingest_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False, windows=None):
         """Decode one BAM file and run the join kernels on every batch. Returns #records decoded.
         contig_mask (bool per engine contig) restricts the pass to the contigs this rank owns;
         with use_index the .bai is used to inflate only their byte ranges."""
         b, refs = self._open(path, n_threads or self.cfg.n_threads)
         try:
-            o, keep = self._opts(refs, sample, max_records, contig_mask, use_index)
+            o, keep = self._opts(refs, sample, max_records, contig_mask, use_index, windows)
             n = C.c_int64(0)
             self._check(self.lib.xck_ingest_bam(self.h, b, C.byref(o), C.byref(n)), "xck_ingest_bam")
             return int(n.value)
@@ -225,11 +254,11 @@ class Engine(object):
         records (whole decode chunks) and returns (records so far, done)."""
         return BamStream(self, path, sample, n_threads, contig_mask, use_index)
 
-    def decode_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False):
+    def decode_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False, windows=None):
         """Pull-style decode (tests / inspection): yields dicts of numpy copies per batch."""
         b, refs = self._open(path, n_threads or self.cfg.n_threads)
         try:
-            o, keep = self._opts(refs, sample, max_records, contig_mask, use_index)
+            o, keep = self._opts(refs, sample, max_records, contig_mask, use_index, windows)
             bt = capi.Batch()
             while True:
                 rc = self.lib.xck_bam_next_batch(self.h, b, C.byref(o), C.byref(bt))

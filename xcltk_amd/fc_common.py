@@ -305,9 +305,15 @@ def make_engine(conf, mode, regions, snps=(), device=None, **extra):
     else:
         kw.update(min_count=conf.min_count, min_maf=conf.min_maf, no_dup_hap=conf.no_dup_hap)
     kw.update(extra)
-    return Engine(mode, names, regions, len(conf.samples), snps=snps,
-                  barcodes=conf.barcodes if conf.use_barcodes() else None,
-                  cell_tag=conf.cell_tag, umi_tag=conf.umi_tag, device=device, **kw)
+    dist = Dist()
+    if dist.active:                                   # multi-GPU: this rank counts the regions of its contigs (or contig pieces)
+        dist.plan(conf, regions, snps)
+        kw["region_mask"] = dist.region_mask
+    eng = Engine(mode, names, regions, len(conf.samples), snps=snps,
+                 barcodes=conf.barcodes if conf.use_barcodes() else None,
+                 cell_tag=conf.cell_tag, umi_tag=conf.umi_tag, device=device, **kw)
+    eng.dist = dist
+    return eng
 
 
 class Dist(object):
@@ -339,19 +345,53 @@ class Dist(object):
     def active(self):
         return self.world > 1
 
-    def contig_mask(self, eng, conf):
-        """bool per engine contig: True where this rank owns the contig."""
-        from .shard import contig_owner
-        n = len(eng.contig_names)
-        weights = np.zeros(n, dtype=np.float64)
-        for fn in conf.sam_fn_list:
-            c = eng.contig_record_counts(fn)
-            if c is None:                           # no index: every contig weighs the same
-                weights[:] = 1.0
-                break
-            weights += c
-        self.owner = contig_owner(eng.contig_names, weights + 1e-9, self.world)     # contig -> rank, identical on every rank
-        return self.owner == self.rank
+    def plan(self, conf, regions, snps=()):
+        """Who counts what (identical on every rank): contigs by longest-processing-time on the .bai record counts; a contig
+        that outweighs 1 / world of the reads is cut at region boundaries (shard.plan_units).  Sets contig_mask (contigs this
+        rank streams), windows ({contig: (beg0, end0)} for the cut ones), region_mask (regions this rank counts) and
+        row_owner (rank per region, for stitching the gathered blocks)."""
+        from .shard import plan_units
+        names = contig_table(regions, snps)
+        probe = Engine(XCK_MODE_BASEFC, names, [], 1, decode_only=True)
+        try:
+            weights = np.zeros(len(names), dtype=np.float64)
+            for fn in conf.sam_fn_list:
+                c = probe.contig_record_counts(fn)
+                if c is None:                           # no index: every contig weighs the same
+                    weights[:] = 1.0
+                    break
+                weights += c
+            heavy = [c for c in range(len(names)) if weights.sum() > 0 and weights[c] > weights.sum() / self.world * 1.02]
+            profiles = {}
+            for c in heavy:                            # byte profile of the first BAM that has one (cuts are positions, valid for every BAM)
+                for fn in conf.sam_fn_list:
+                    pr = probe.contig_byte_profile(fn, c)
+                    if pr is not None:
+                        profiles[c] = pr
+                        break
+        finally:
+            probe.close()
+        cidx = {n: i for i, n in enumerate(names)}
+        units, owner = plan_units(weights + 1e-9, self.world, regions, cidx, profiles)
+        self.contig_mask = np.zeros(len(names), dtype=bool)
+        self.region_mask = np.zeros(len(regions), dtype=bool)
+        self.row_owner = np.full(len(regions), -1, dtype=np.int32)
+        self.windows = {}
+        for u, r in zip(units, owner.tolist()):
+            self.row_owner[u["regions"]] = r
+            if r != self.rank:
+                continue
+            self.contig_mask[u["contig"]] = True
+            self.region_mask[u["regions"]] = True
+            if u["window"] is not None:
+                if u["contig"] in self.windows:          # two pieces of one contig on this rank: their hull
+                    b0, e0 = self.windows[u["contig"]]
+                    nb, ne = u["window"]
+                    self.windows[u["contig"]] = (min(b0, nb), 0 if (e0 == 0 or ne == 0) else max(e0, ne))
+                else:
+                    self.windows[u["contig"]] = u["window"]
+        # a rank that holds pieces next to whole contigs: whole contigs have no window (decoded entirely)
+        return self
 
     def gather(self, eng, regions):
         """all-gatherv of the per-rank sparse blocks to rank 0, straight from HBM (xck_get_result_device): one
@@ -367,17 +407,15 @@ class Dist(object):
         res = g.wait()
         if self.rank != 0:
             return None
-        cidx = {n: i for i, n in enumerate(eng.contig_names)}
-        row_owner = self.owner[np.array([cidx[r[0]] for r in regions], dtype=np.int64)] if len(regions) else np.zeros(0, dtype=np.int32)
-        return {k: merge_row_blocks([b.cpu().numpy() for b in res[k]], row_owner) for k in res}
+        return {k: merge_row_blocks([b.cpu().numpy() for b in res[k]], self.row_owner) for k in res}
 
 
-def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None):
+def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None, windows=None):
     """One streaming pass over every BAM, in list order (= the reference's fetch order)."""
     t0 = time.time()
     n_tot = 0
     for i, fn in enumerate(conf.sam_fn_list):
-        n = eng.ingest_bam(fn, sample=i, contig_mask=contig_mask, use_index=contig_mask is not None)
+        n = eng.ingest_bam(fn, sample=i, contig_mask=contig_mask, use_index=contig_mask is not None, windows=windows or None)
         n_tot += n
         if conf.debug > 0:
             info("%s %s: %d records" % (log_prefix, fn, n))
@@ -389,9 +427,10 @@ def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None):
 def count_all(eng, conf, log_prefix="[engine]"):
     """Stream every BAM (this rank's contigs when running multi-GPU), fold, gather.
     Returns (coo dict or None on non-zero ranks, Dist)."""
-    dist = Dist()
-    mask = dist.contig_mask(eng, conf) if dist.active else None
-    stream_bams(eng, conf, log_prefix, mask)
+    dist = getattr(eng, "dist", None) or Dist()
+    if dist.active and not hasattr(dist, "row_owner"):
+        raise RuntimeError("multi-GPU run: the engine has to be made by fc_common.make_engine (it plans the shards)")
+    stream_bams(eng, conf, log_prefix, dist.contig_mask if dist.active else None, dist.windows if dist.active else None)
     coo = eng.finish(copy=False)
     if dist.active:
         coo = dist.gather(eng, conf.reg_list)

@@ -48,13 +48,9 @@ def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_lis
     os.makedirs(fc_dir, exist_ok=True)
     if fcc.is_writer_rank():
         fcc.write_samples(os.path.join(fc_dir, "barcodes.tsv"), conf.samples)
-    names = fcc.contig_table(regions, snps)
-    eng = Engine(XCK_MODE_BOTH, names, regions, len(conf.samples), snps=snps,
-                 barcodes=conf.barcodes if conf.use_barcodes() else None, cell_tag=conf.cell_tag,
-                 umi_tag=conf.umi_tag, device=int(os.environ.get("XCK_DEVICE", os.environ.get("LOCAL_RANK", "0"))),
-                 min_mapq=min_mapq, min_len=min_len, incl_flag=incl_flag, excl_flag=conf.excl_flag,
-                 no_orphan=no_orphan, min_include=min_include, min_count=min_count, min_maf=min_maf,
-                 no_dup_hap=no_dup_hap, n_threads=max(0, int(ncores)))
+    conf.min_include = min_include
+    eng = fcc.make_engine(conf, XCK_MODE_BOTH, regions, snps, min_include=min_include, min_count=min_count, min_maf=min_maf,
+                          no_dup_hap=no_dup_hap)
     try:
         coo, dist = fcc.count_all(eng, conf, log_prefix="[fused]")
         if coo is None:

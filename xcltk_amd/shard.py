@@ -30,6 +30,58 @@ def contig_owner(contig_names, weights, world):
     return owner
 
 
+def plan_units(contig_weights, world, regions, contig_index, byte_profiles=None, slack=1.02):
+    """Work units for `world` ranks: whole contigs, except that a contig heavier than 1 / world of all
+    reads is cut at region boundaries into pieces of about equal compressed bytes (= reads; `byte_profiles[c]` = file offset
+    of the first record overlapping every 16 kb window of contig c, from the .bai linear index).  A region belongs to exactly
+    one piece; a piece reads the contig from the first record overlapping its first region start up to the last record that
+    starts before the largest end of its regions, so reads that straddle a cut are seen by both sides.
+    regions: [(chrom, start1, end1_incl, ...)]; contig_index: {chrom: contig id}.
+    -> (units, owner): units = [dict(contig, regions (index array), window (beg0, end0) or None, weight)],
+       owner[unit] = rank (longest-processing-time on the weights)."""
+    w = np.asarray(contig_weights, dtype=np.float64)
+    total = float(w.sum())
+    by_c = {}
+    for g, r in enumerate(regions):
+        c = contig_index.get(r[0])
+        if c is not None:
+            by_c.setdefault(c, []).append(g)
+    units = []
+    for c in range(len(w)):
+        idx = np.array(by_c.get(c, []), dtype=np.int64)
+        prof = None if byte_profiles is None else byte_profiles.get(c)
+        k = int(np.ceil(w[c] / (total / world * slack))) if total > 0 and world > 1 else 1
+        if k <= 1 or prof is None or len(prof) < 2 or len(idx) < 2 or prof[-1] <= prof[0]:
+            units.append(dict(contig=c, regions=idx, window=None, weight=float(w[c])))
+            continue
+        starts = np.array([regions[g][1] for g in idx], dtype=np.int64)
+        ends = np.array([regions[g][2] for g in idx], dtype=np.int64)
+        order = np.argsort(starts, kind="stable")
+        idx, starts, ends = idx[order], starts[order], ends[order]
+        frac = (prof.astype(np.float64) - prof[0]) / float(prof[-1] - prof[0])       # share of the contig's bytes left of every window
+        f_at = lambda p: float(frac[min(max(int(p) >> 14, 0), len(frac) - 1)])
+        cuts = [0]
+        for j in range(1, k):
+            nxt = next((i for i in range(cuts[-1] + 1, len(idx)) if f_at(starts[i] - 1) >= j / k), None)
+            if nxt is None:
+                break
+            cuts.append(nxt)
+        cuts.append(len(idx))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b <= a:
+                continue
+            beg0 = 0 if a == 0 else int(starts[a] - 1)
+            end0 = 0 if b == len(idx) else int(ends[a:b].max())                     # 0 = open end
+            share = (f_at(end0) if end0 else 1.0) - f_at(beg0)
+            units.append(dict(contig=c, regions=idx[a:b], window=(beg0, end0), weight=float(w[c]) * max(share, 1e-6)))
+    bins = lpt_assign([u["weight"] for u in units], world)
+    owner = np.zeros(len(units), dtype=np.int32)
+    for r, items in enumerate(bins):
+        for i in items:
+            owner[i] = r
+    return units, owner
+
+
 def gather_coo(coo, world, device="cpu", group=None):
     """All-gatherv of one sparse block.  coo = (row, col, val) int32 numpy arrays of this
     rank; returns the concatenation over ranks sorted by (row, col) - identical to what a
