@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="records in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--resident-passes", type=int, default=5, help="timed passes of the HBM-resident sub-record (0 = skip it and the roofline)")
+    ap.add_argument("--resident-only", action="store_true", help="run only the HBM-resident sub-record (the command profiles/ traces with rocprofv3: "
+                    "its k_join launches are the 500 M-read launches the roofline is computed from)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -153,6 +155,15 @@ def main():
 
     cores = host_cores()
     threads = args.threads if args.threads > 0 else max(1, cores // world)
+
+    if args.resident_only:                                     # profiling aid, N = 1: no BAM, no files
+        if world != 1:
+            sys.exit("--resident-only is a single-GPU run")
+        regions, snps, names = soa.make_tables(args.genes, args.snps, soa.HG38_LENGTHS, seed=2)
+        resident, roofline = device_resident(args, names, regions, snps, dev_idx, device, log)
+        print(json.dumps(dict(metric="reads/sec, HBM-resident sub-record only (NOT the headline metric)", value=resident["reads_per_s"], unit="reads/s",
+                              n_gpus=1, sub_record_only=True, dtype="int64", data="synthetic", device_resident=resident, roofline=roofline)))
+        return
 
     # ---- inputs: generated by local rank 0 with all of the box's cores, the others wait ----
     if rank == 0:

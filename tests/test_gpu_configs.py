@@ -130,3 +130,15 @@ def test_hot_gene_cell_run_folds_without_run_walks():
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 2, batches, min_len=10)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
     assert st["n_hits"] > 1_000_000 and len(exp["dp"][0]) <= 6           # a million (read, SNP) pairs folded into at most 3 regions x 2 cells
+
+
+@pytest.mark.parametrize("flags", [0, capi.XCK_F_FORCE_KEY128])
+def test_deep_molecule_runs_are_not_walked_by_one_lane(flags):
+    """Three UMIs in two cells over a dense SNP panel: every (SNP, cell, UMI) key holds hundreds to thousands of reads, far
+    beyond what a run head walks itself (RUN_WALK = 64) - k_first_long finishes those runs, one block each.  64-bit keys take
+    the split path (k_first_base), 128-bit keys the single sorted stream (k_first_read)."""
+    from test_gpu_parity import _dense_pileup_case
+    regions, snps, names, batches = _dense_pileup_case(seed=47, n_reads=60000, n_cells=2, n_umis=3, snp_step=11, span=40000, max_batch=20000, gap_max=300)
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 2, batches, flags=flags, min_len=10)
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+    assert st["n_hits"] > 200_000

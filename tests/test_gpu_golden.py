@@ -51,3 +51,27 @@ def test_fused_single_decode_matches_both_references(pair, tmp_path):
     assert _read(os.path.join(out, "basefc")) == _read(exp_fc)
     if baf_name:
         assert _read(os.path.join(out, "baf")) == _read(exp_baf)
+
+
+@pytest.mark.parametrize("name,world", [("well_baf", 1), ("c1_basefc_noumi", 1), ("c1_baf_noumi", 2)])
+def test_key_id_overflow_is_retried_with_128bit_keys(name, world, tmp_path):
+    """Read names used as keys are interned; XCK_TEST_INTERN_LIMIT makes the id space of the 64-bit key layout overflow after
+    40 ids (really: 2^25 or more).  The decoder then stops with XCK_E_CAPACITY and the front-end must count again with
+    128-bit keys - on all ranks of a multi-rank run - and still write the reference's bytes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XCK_TEST_INTERN_LIMIT="40", XCK_DIST_BACKEND="gloo", XCK_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(root, "tests", "dist_worker.py")
+    if world == 1:
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, worker, name, str(tmp_path)]
+    else:
+        from test_gpu_multirank import _free_port
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+               "--master-port", _free_port(), worker, name, str(tmp_path)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert "MULTIRANK_OK " + name in r.stdout, r.stdout[-3000:]
+    assert "counting again with 128-bit keys" in r.stdout, r.stdout[-3000:]

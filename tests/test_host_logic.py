@@ -154,6 +154,12 @@ def test_decoder_rejects_garbage(tmp_path, lib):
     b = C.c_void_p(); err = C.create_string_buffer(256)
     assert lib.xck_bam_open(str(bad).encode(), 1, C.byref(b), err, 256) == -4
     assert b"BGZF" in err.value or b"BAM" in err.value
+    # the reference's pysam would read these two; the decoder names the format instead of reporting a bad gzip magic
+    for name, head, word in (("x.cram", b"CRAM\x03\x00" + bytes(40), b"CRAM"), ("x.sam", b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:1\tLN:1000\n", b"SAM")):
+        f = tmp_path / name
+        f.write_bytes(head)
+        assert lib.xck_bam_open(str(f).encode(), 1, C.byref(b), err, 256) == -4
+        assert word in err.value and b"BAM only" in err.value
     # truncated real file
     src = open(os.path.join(util.GOLDEN, "datasets", "c1", "possorted.bam"), "rb").read()
     tr = tmp_path / "trunc.bam"

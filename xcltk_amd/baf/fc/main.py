@@ -172,9 +172,8 @@ def afc_core(conf):
             snps = [(s[0], s[1], s[2], s[3], int(r), int(a)) for s, r, a in zip(snps, rh.tolist(), ah.tolist())]
         excl = (ex_r, ex_s)
         conf.snp_csp = conf.ref_cells = None
-    eng = fcc.make_engine(conf, XCK_MODE_BAF, regions, snps, excl_pairs=excl)
+    eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BAF, regions, snps, excl_pairs=excl)
     try:
-        coo, dist = fcc.count_all(eng, conf)
         if coo is not None:                               # rank 0 (or the only process) writes
             if conf.output_all_reg:
                 rm = fcc.row_map_all(len(regions))

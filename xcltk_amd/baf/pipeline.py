@@ -31,8 +31,8 @@ def usage(fp=sys.stdout):
     s += "\n"
     s += "Options:\n"
     s += "  --label STR        Task label.\n"
-    s += "  --sam FILE         Comma separated indexed BAM/CRAM file(s).\n"
-    s += "  --samList FILE     A file listing BAM/CRAM files, each per line.\n"
+    s += "  --sam FILE         Comma separated indexed BAM file(s) (CRAM: convert first).\n"
+    s += "  --samList FILE     A file listing BAM files, each per line.\n"
     s += "  --barcode FILE     A plain file listing all effective cell barcodes, for\n"
     s += "                     droplet-based data, e.g., 10x Genomics.\n"
     s += "  --sampleList FILE  A plain file listing sample IDs, one ID per BAM, for\n"

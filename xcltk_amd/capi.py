@@ -18,6 +18,7 @@ XCK_F_FORCE_KEY128 = 1
 XCK_F_VERIFY_CRC = 2
 XCK_F_DECODE_ONLY = 4
 XCK_F_LOW_PRIORITY = 8
+XCK_E_ARG, XCK_E_DEVICE, XCK_E_NOMEM, XCK_E_IO, XCK_E_STATE, XCK_E_CAPACITY = -1, -2, -3, -4, -5, -6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libxck.so")

@@ -75,6 +75,13 @@ void InternTable::Shard::grow() {
     slots.swap(ns);
 }
 
+// test hook: XCK_TEST_INTERN_LIMIT=<n> makes the id space of 64-bit keys overflow after n ids (tests/test_gpu_frontends.py
+// exercises the front-ends' retry with 128-bit keys without 2^25 distinct read names)
+static const uint64_t g_test_intern_limit = [] { const char* e = getenv("XCK_TEST_INTERN_LIMIT"); return e ? (uint64_t)strtoull(e, nullptr, 10) : ~0ull; }();
+static inline uint64_t intern_id_limit(int umi_bits) {
+    return umi_bits >= 64 ? (1ull << 63) - 1 : std::min<uint64_t>((1ull << (umi_bits - 1)) - 1, g_test_intern_limit);
+}
+
 uint64_t InternTable::intern(const char* s, size_t n) {
     const uint64_t h = hash_bytes(s, n);
     Shard& sh = shards_[h & (NSHARD - 1)];
@@ -122,7 +129,7 @@ void InternTable::intern_batch(std::vector<Item>& items, bool* overflow) {
                 if (sl.h == it.h && sl.len1 == it.n + 1 && memcmp(sh.arena.data() + sl.off, it.s, it.n) == 0) { id = ((uint64_t)sl.idx << 6) | shard; break; }
                 k = (k + 1) & mask;
             }
-            const uint64_t lim = it.umi_bits >= 64 ? (1ull << 63) - 1 : (1ull << (it.umi_bits - 1)) - 1;
+            const uint64_t lim = intern_id_limit(it.umi_bits);
             if (id >= lim) { if (overflow) *overflow = true; *it.out = XCK_UMI_NONE; }
             else *it.out = (1ull << (it.umi_bits - 1)) | id;
         }
@@ -157,7 +164,7 @@ uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, boo
     uint64_t direct;
     if (encode_key_direct(s, n, umi_bits, &direct)) return direct;
     uint64_t id = tab.intern(s, n);
-    uint64_t lim = umi_bits >= 64 ? (1ull << 63) - 1 : (1ull << (umi_bits - 1)) - 1;
+    const uint64_t lim = intern_id_limit(umi_bits);
     if (id >= lim) { if (overflow) *overflow = true; return XCK_UMI_NONE; }
     return (1ull << (umi_bits - 1)) | id;
 }
@@ -481,6 +488,9 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
     if (m == MAP_FAILED) return fail("mmap failed", b);
     b->map = (const uint8_t*)m;
     madvise(m, b->fsize, MADV_SEQUENTIAL);
+    // the reference lets pysam detect SAM / BAM / CRAM; this decoder reads BAM only and says so up front
+    if (memcmp(b->map, "CRAM", 4) == 0) return fail("CRAM input is not supported: this decoder reads BAM only (samtools view -b)", b);
+    if (b->map[0] == '@' && b->map[3] == '\t') return fail("SAM text input is not supported: this decoder reads BAM only (samtools view -b)", b);
     SeqReader r; r.b = b;
     if (!r.fill(12)) return fail(r.err, b);
     if (memcmp(r.buf.data(), "BAM\1", 4) != 0) return fail("not a BAM file (bad magic)", b);

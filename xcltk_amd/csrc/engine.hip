@@ -1009,22 +1009,55 @@ __global__ __launch_bounds__(FU_BLOCK) void k_fold_emit_unsorted(const unsigned 
     }
 }
 
+constexpr long long RUN_WALK = 64;     // a run head walks at most this many followers itself; longer runs go to k_first_long
 __device__ __forceinline__ int nib_bucket(int nib) { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4; }
 
 // BAF step 1: per (snp, cell, umi) run keep the value with the smallest ordinal (first read in
 // fetch order, baf/fc/mcount.py:118-119); tally its allele per SNP (mcount.py:140-150).
 template <class K>
 __global__ void k_first_read(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
-                             uint8_t* __restrict__ al_out, uint32_t* __restrict__ tally) {
+                             uint8_t* __restrict__ al_out, uint32_t* __restrict__ tally, unsigned long long* __restrict__ long_runs) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     K me = k[i];
     if (i > 0 && k[i - 1] == me) { al_out[i] = 0; return; }
     uint64_t best = v[i];
-    for (long long j = i + 1; j < n && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
+    long long j = i + 1;
+    for (; j < n && j <= i + RUN_WALK && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
+    if (j < n && j > i + RUN_WALK && k[j] == me) { long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = (unsigned long long)i; return; }   // finished by k_first_long
     uint32_t code = uint32_t(best & ((1u << ALLELE_BITS) - 1));      // nibble + 1, 0 = no base
     al_out[i] = (uint8_t)code;
     if (code) atomicAdd(&tally[(size_t)kl.row(me) * 5 + nib_bucket(int(code) - 1)], 1u);
+}
+
+// A key run longer than RUN_WALK (a molecule with many reads over one SNP: constant UMI tags, UMI-less deep pileups) is not
+// walked by its head lane: the head only queues it, and here ONE BLOCK per run finds the run's end by bisection on the sorted
+// keys and takes the minimum (ordinal, allele) value in parallel.  SPLIT: k_first_base's outputs, else k_first_read's.
+template <class K, bool SPLIT>
+__global__ void __launch_bounds__(256) k_first_long(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
+                                                      const unsigned long long* __restrict__ long_runs, uint8_t* __restrict__ al_out,
+                                                      uint64_t* __restrict__ ord_out, uint32_t* __restrict__ tally) {
+    __shared__ unsigned long long s_min[4];
+    const unsigned long long n_long = long_runs[0];
+    for (unsigned long long r = blockIdx.x; r < n_long; r += gridDim.x) {
+        const long long h = (long long)long_runs[1 + r];
+        const K me = k[h];
+        long long lo = h + 1, hi = n;                                     // first index past the run (every lane bisects: same loads, broadcast by the cache)
+        while (lo < hi) { const long long mid = lo + ((hi - lo) >> 1); if (k[mid] == me) lo = mid + 1; else hi = mid; }
+        unsigned long long best = ~0ull;
+        for (long long j = h + threadIdx.x; j < lo; j += blockDim.x) { const unsigned long long x = v[j]; if (x < best) best = x; }
+        for (int d = 32; d; d >>= 1) { const unsigned long long o = __shfl_xor(best, d); if (o < best) best = o; }
+        if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; w++) if (s_min[w] < best) best = s_min[w];
+            const uint32_t code = uint32_t(best & ((1u << ALLELE_BITS) - 1));
+            al_out[h] = (uint8_t)code;
+            if (SPLIT) ord_out[h] = best >> ALLELE_BITS;
+            else if (code) atomicAdd(&tally[(size_t)kl.row(me) * 5 + nib_bucket(int(code) - 1)], 1u);
+        }
+        __syncthreads();
+    }
 }
 
 // ---- split mode (64-bit keys): the sorted stream holds only hits WITH a base; the hits without one are looked up ----
@@ -1041,7 +1074,7 @@ __device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t 
 template <class K>
 __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
                              uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, unsigned long long* __restrict__ row_lo, unsigned long long* __restrict__ row_hi,
-                             unsigned long long* __restrict__ bloom, unsigned long long bloom_mask) {
+                             unsigned long long* __restrict__ bloom, unsigned long long bloom_mask, unsigned long long* __restrict__ long_runs) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const K me = k[i];
@@ -1050,9 +1083,13 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
     if (i + 1 == n || kl.row(k[i + 1]) != row) row_hi[row] = (unsigned long long)(i + 1);
     if (i > 0 && k[i - 1] == me) { al_out[i] = 0; return; }
     uint64_t best = v[i];
-    for (long long j = i + 1; j < n && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
-    al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));          // nibble + 1 (never 0 here)
-    ord_out[i] = best >> ALLELE_BITS;
+    long long j = i + 1;
+    for (; j < n && j <= i + RUN_WALK && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
+    if (j < n && j > i + RUN_WALK && k[j] == me) long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = (unsigned long long)i;   // al / ord of this head: k_first_long
+    else {
+        al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));      // nibble + 1 (never 0 here)
+        ord_out[i] = best >> ALLELE_BITS;
+    }
     unsigned long long word, bits;
     const unsigned long long cu = (unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1));
     bloom_slot(cu, row >> 5, bloom_mask, word, bits);                 // level 1: (molecule, block of 32 SNPs)
@@ -2114,7 +2151,7 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 16 + std::max<size_t>(n * 8, 8192) + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 16 + std::max<size_t>(n * 8, 8192) + n / 8 + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
         { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
@@ -2124,6 +2161,9 @@ static int finish_t(EngineImpl* im) {
         if ((rc = sort_run<K, uint64_t>(im, tmp, tmpb, alt, keys, valt, im->d_vals, n, top))) return rc;
         std::swap(alt, keys); { uint64_t* t_ = valt; valt = im->d_vals; (void)t_; }   // sorted data now lives in d_keys / d_vals
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
+        unsigned long long* long_runs = im->ws1.get<unsigned long long>(n / (size_t)RUN_WALK + 2);      // [0] = count, then the heads of the runs longer than RUN_WALK
+        if (!long_runs) { im->eng->err = "workspace exhausted (pileup fold)"; return XCK_E_NOMEM; }
+        HIP_TRY(hipMemsetAsync(long_runs, 0, sizeof(unsigned long long), im->s_comp));
         if (sizeof(K) == 8 && split_mode(im)) {
             const size_t ns = std::max<size_t>((size_t)im->n_snps_sorted, 1);
             uint64_t* ordv = im->ws1.get<uint64_t>(n); unsigned long long* row_lo = im->ws1.get<unsigned long long>(2 * ns); unsigned long long* row_hi = row_lo + ns;
@@ -2133,7 +2173,9 @@ static int finish_t(EngineImpl* im) {
             HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(unsigned long long), im->s_comp));
             HIP_TRY(hipMemsetAsync(bloom, 0, bw * sizeof(unsigned long long), im->s_comp));
             hipLaunchKernelGGL((k_first_base<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, ordv, row_lo, row_hi,
-                               bloom, (unsigned long long)(bw - 1));
+                               bloom, (unsigned long long)(bw - 1), long_runs);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((k_first_long<K, true>), dim3(1024), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, (const unsigned long long*)long_runs, al, ordv, im->d_tally);
             HIP_TRY(hipGetLastError());
             if (im->ncursor) {
                 ShardSpan nsp; nsp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh];
@@ -2146,7 +2188,9 @@ static int finish_t(EngineImpl* im) {
             hipLaunchKernelGGL((k_tally<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally);
             HIP_TRY(hipGetLastError());
         } else {
-        hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, im->d_tally);
+        hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, im->d_tally, long_runs);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((k_first_long<K, false>), dim3(1024), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, (const unsigned long long*)long_runs, al, (uint64_t*)nullptr, im->d_tally);
         HIP_TRY(hipGetLastError());
         }
         XBases xb; memset(&xb, 0, sizeof xb);

@@ -20,7 +20,10 @@ from .capi import XCK_MODE_BAF, XCK_MODE_BASEFC
 
 
 class XckError(RuntimeError):
-    pass
+    """Engine / decoder failure; `code` holds the C-ABI error code (include/xck.h XCK_E_*) when there is one."""
+    def __init__(self, msg, code=0):
+        RuntimeError.__init__(self, msg)
+        self.code = code
 
 
 def resolve_contigs(bam_refs, contig_names):
@@ -132,7 +135,7 @@ class Engine(object):
         h = C.c_void_p()
         rc = self.lib.xck_create(C.byref(cfg), C.byref(h))
         if rc != 0:
-            raise XckError("xck_create failed (%d): %s" % (rc, self.lib.xck_last_error(None).decode()))
+            raise XckError("xck_create failed (%d): %s" % (rc, self.lib.xck_last_error(None).decode()), rc)
         self.h = h
         self.umi_bits = self.lib.xck_umi_bits(self.h)
         self._result = None
@@ -157,7 +160,7 @@ class Engine(object):
 
     def _check(self, rc, what):
         if rc != 0:
-            raise XckError("%s failed (%d): %s" % (what, rc, self.lib.xck_last_error(self.h).decode()))
+            raise XckError("%s failed (%d): %s" % (what, rc, self.lib.xck_last_error(self.h).decode()), rc)
 
     # ------------------------------------------------------------------ data path
     def push(self, batch, device_resident=False):
@@ -176,7 +179,7 @@ class Engine(object):
         err = C.create_string_buffer(512)
         rc = self.lib.xck_bam_open(path.encode(), n_threads, C.byref(b), err, 512)
         if rc != 0:
-            raise XckError("xck_bam_open failed (%d): %s" % (rc, err.value.decode()))
+            raise XckError("xck_bam_open failed (%d): %s" % (rc, err.value.decode()), rc)
         refs = [self.lib.xck_bam_ref_name(b, i).decode() for i in range(self.lib.xck_bam_n_refs(b))]
         return b, refs
 

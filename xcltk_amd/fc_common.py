@@ -424,14 +424,46 @@ def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None, windows=None
     return n_tot
 
 
-def count_all(eng, conf, log_prefix="[engine]"):
-    """Stream every BAM (this rank's contigs when running multi-GPU), fold, gather.
-    Returns (coo dict or None on non-zero ranks, Dist)."""
-    dist = getattr(eng, "dist", None) or Dist()
-    if dist.active and not hasattr(dist, "row_owner"):
-        raise RuntimeError("multi-GPU run: the engine has to be made by fc_common.make_engine (it plans the shards)")
-    stream_bams(eng, conf, log_prefix, dist.contig_mask if dist.active else None, dist.windows if dist.active else None)
-    coo = eng.finish(copy=False)
-    if dist.active:
-        coo = dist.gather(eng, conf.reg_list)
-    return coo, dist
+def make_and_count(conf, mode, regions, snps=(), log_prefix="[engine]", **extra):
+    """Build the engine, stream every BAM (this rank's contigs when running multi-GPU), fold, gather.  Keys that are not ACGT strings (IUPAC UMIs, integer tags, read names in UMI-less runs) are
+    interned on the host and take one id each; when the ids outgrow the UMI field of a 64-bit key the decoder stops with
+    XCK_E_CAPACITY - the run is then repeated once with 128-bit keys (XCK_F_FORCE_KEY128), on every rank of a multi-GPU run.
+    Returns (engine - the caller closes it, coo or None, Dist)."""
+    from .capi import XCK_E_CAPACITY, XCK_F_FORCE_KEY128
+    from .engine import XckError
+    flags = int(extra.pop("flags", 0))
+    while True:
+        eng = make_engine(conf, mode, regions, snps, flags=flags, **extra)
+        dist, overflow, failure = eng.dist, 0, None
+        try:
+            stream_bams(eng, conf, log_prefix, dist.contig_mask if dist.active else None, dist.windows if dist.active else None)
+        except XckError as e:
+            failure = e
+            overflow = int(getattr(e, "code", 0) == XCK_E_CAPACITY and not flags & XCK_F_FORCE_KEY128)
+        except BaseException:
+            eng.close()
+            raise
+        if dist.active:                                   # the ranks agree: one overflow sends all of them round again
+            import torch
+            import torch.distributed as td
+            t = torch.tensor([overflow, int(failure is not None)], dtype=torch.int64, device=dist.device)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            overflow, any_failure = int(t[0]), int(t[1])
+            if any_failure and not overflow and failure is None:
+                failure = XckError("another rank failed")
+        if overflow:
+            eng.close()
+            warn("%s key ids exceed the 64-bit key layout; counting again with 128-bit keys." % log_prefix)
+            flags |= XCK_F_FORCE_KEY128
+            continue
+        if failure is not None:
+            eng.close()
+            raise failure
+        try:
+            coo = eng.finish(copy=False)
+            if dist.active:
+                coo = dist.gather(eng, conf.reg_list)
+        except BaseException:
+            eng.close()
+            raise
+        return eng, coo, dist

@@ -49,10 +49,9 @@ def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_lis
     if fcc.is_writer_rank():
         fcc.write_samples(os.path.join(fc_dir, "barcodes.tsv"), conf.samples)
     conf.min_include = min_include
-    eng = fcc.make_engine(conf, XCK_MODE_BOTH, regions, snps, min_include=min_include, min_count=min_count, min_maf=min_maf,
-                          no_dup_hap=no_dup_hap)
+    eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BOTH, regions, snps, log_prefix="[fused]", min_include=min_include,
+                                        min_count=min_count, min_maf=min_maf, no_dup_hap=no_dup_hap)
     try:
-        coo, dist = fcc.count_all(eng, conf, log_prefix="[fused]")
         if coo is None:
             return 0
         n = len(regions)

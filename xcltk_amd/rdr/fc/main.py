@@ -30,7 +30,7 @@ def usage(fp=sys.stdout, conf=None):
     s += "Usage:   %s %s <options>\n" % (APP, COMMAND)
     s += "\n"
     s += "Options:\n"
-    s += "  -s, --sam FILE         Comma separated indexed sam/bam/cram file.\n"
+    s += "  -s, --sam FILE         Comma separated indexed BAM file(s) (SAM / CRAM: convert first).\n"
     s += "  -S, --samList FILE     A list file containing bam files, each per line.\n"
     s += "  -b, --barcode FILE     A plain file listing all effective cell barcode.\n"
     s += "  -R, --region FILE      A TSV file listing target regions. The first 4 columns shoud be:\n"
@@ -162,9 +162,8 @@ def fc_core(conf):
     info("program configuration:")
     conf.show(fp=sys.stderr, prefix="\t")
     regions = conf.reg_list
-    eng = fcc.make_engine(conf, XCK_MODE_BASEFC, regions)
+    eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BASEFC, regions)
     try:
-        coo, dist = fcc.count_all(eng, conf)
         if coo is not None:                               # rank 0 (or the only process) writes
             if conf.output_all_reg:
                 rm = fcc.row_map_all(len(regions))        # row = input line number
