@@ -47,18 +47,22 @@ FILT = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
 
 
 def host_cores():
-    """CPUs this process may use: affinity and cgroup quota (a GPU box shows 256 hardware threads behind a 16-CPU quota)."""
+    """(CPUs' worth of time this process may use, decode threads that spend it): affinity and cgroup quota.  A GPU box shows 256
+    hardware threads behind a 16-CPU quota; there 1.5 threads per quota CPU keep the quota spent (csrc/bam.cpp default_threads)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    threads = n
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
-            n = min(n, max(1, -(-int(q) // int(p))))
+            c = max(1, -(-int(q) // int(p)))
+            if c < n:
+                n, threads = c, min(n, c + c // 2)
     except Exception:
         pass
-    return max(1, n)
+    return max(1, n), max(1, threads)
 
 
 def make_inputs(args, work, threads, log):
@@ -153,8 +157,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    cores = host_cores()
-    threads = args.threads if args.threads > 0 else max(1, cores // world)
+    cores, pool_threads = host_cores()
+    threads = args.threads if args.threads > 0 else max(1, pool_threads // world)
 
     if args.resident_only:                                     # profiling aid, N = 1: no BAM, no files
         if world != 1:

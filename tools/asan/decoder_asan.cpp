@@ -47,7 +47,8 @@ int main(int argc, char** argv) {
             continue;
         }
         for (int mode : {XCK_MODE_BASEFC, XCK_MODE_BAF}) {
-            for (int threads : {1, 3}) {
+            const int t_env = getenv("XCK_ASAN_THREADS") ? atoi(getenv("XCK_ASAN_THREADS")) : 0;      // e.g. 24: the thread count of a run to be re-checked
+            for (int threads : {t_env > 0 ? t_env : 1, 3}) {
                 xck_config cfg; memset(&cfg, 0, sizeof cfg);
                 cfg.struct_size = sizeof cfg; cfg.mode = mode; cfg.n_cells = (int)bp.size(); cfg.barcodes = bp.data();
                 cfg.cell_tag[0] = 'C'; cfg.cell_tag[1] = 'B'; cfg.umi_tag[0] = 'U'; cfg.umi_tag[1] = 'B';

@@ -49,7 +49,11 @@ int default_threads() {
             if (fscanf(f1, "%lld", &quota) != 1) quota = -1; fclose(f1);
             if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &period) != 1) period = 100000; fclose(f2); }
         }
-        if (quota > 0 && period > 0) { const long c = (long)((quota + period - 1) / period); if (c > 0 && c < n) n = c; }
+        // Behind a CPU-time quota smaller than the CPUs the scheduler may use (a GPU box: 256 hardware threads, 16 CPUs' worth of
+        // time), 1.5 threads per quota CPU keep the quota spent while the coordinator, the scanner and the GPU runtime's own
+        // threads take their turns: fused ingest 36 -> 40-42 M reads/s at 24 threads, no further gain at 32
+        // (profiles/r02_b_ingest_thread_scaling_100m.log, r02_d_ingest_thread_scaling_500m.log).
+        if (quota > 0 && period > 0) { const long c = (long)((quota + period - 1) / period); if (c > 0 && c < n) n = std::min(n, c + c / 2); }
         if (const char* e = getenv("XCK_THREADS")) { const int v = atoi(e); if (v > 0) n = v; }
         return (int)std::max(1l, n);
     }();
@@ -216,7 +220,12 @@ struct TaskGroup {
     std::mutex mu; std::condition_variable cv; int pending = 0;
     void add(Pool& p, std::function<void()> f) {
         { std::lock_guard<std::mutex> lk(mu); pending++; }
-        p.submit([this, f] { f(); { std::lock_guard<std::mutex> lk(mu); pending--; } cv.notify_all(); });
+        // The notify happens UNDER the lock: a TaskGroup on the waiter's stack may be destroyed as soon as wait() returns, and
+        // wait() cannot return before this task has released the mutex - after which it touches the group no more.  (Notifying
+        // after the unlock let a waiter that saw pending == 0 leave first; the late pthread_cond_broadcast then wrote into
+        // whatever the coordinator's stack held by then: "free(): invalid pointer", once per ~14 k chunks with more pool threads
+        // than CPUs, tools/stress_e2e.py.)
+        p.submit([this, f] { f(); std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); });
     }
     void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return pending == 0; }); }
 };

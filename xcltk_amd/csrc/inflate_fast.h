@@ -17,8 +17,8 @@ namespace xck {
 static unsigned long long g_prof_build = 0, g_prof_nblocks = 0;
 #endif
 
-struct HuffEnt { uint16_t val; uint8_t len; uint8_t op; };
-// op: 0x00 literal (val = byte) | 0x01 TWO literals (val = first | second << 8, len = both code lengths)
+struct HuffEnt { uint32_t val; uint8_t len; uint8_t op; uint16_t pad; };
+// op: 0x00 literal (val = byte) | 0x01..0x03 TWO..FOUR literals (val = the bytes in output order, len = all code lengths)
 //     0x10+x length/distance base in val with x extra bits | 0x20 end of block
 //     0x40 invalid code | 0x80+s link to a subtable at index val, indexed by the next s bits (len = primary bits)
 
@@ -97,17 +97,22 @@ static inline bool build_table(const uint8_t* lens, int n_sym, int tb, HuffEnt* 
 }
 
 // Literal-heavy streams (BAM qualities / packed bases) are bound by the serial table-lookup chain, one
-// literal per lookup.  Wherever two literal codes fit together in the 11 index bits, fuse them: the entry
-// then yields two bytes per lookup.  Only primary-table single-literal entries are fused.
+// literal per lookup.  Wherever several literal codes fit together in the 11 index bits, fuse them: the entry
+// then yields up to four bytes per lookup (binned base qualities have 1-3 bit codes, two packed bases ~5 bits).
+// Only primary-table single-literal entries are fused.
 static inline void pair_literals(HuffEnt* tab) {
-    HuffEnt orig[1 << LIT_TB];
+    static thread_local HuffEnt orig[1 << LIT_TB];
     memcpy(orig, tab, sizeof orig);
     for (uint32_t i = 0; i < (1u << LIT_TB); i++) {
         const HuffEnt a = orig[i];
         if (a.op != 0 || a.len >= LIT_TB) continue;
-        const HuffEnt b = orig[i >> a.len];                       // upper (unknown) bits read as 0: valid iff b fits the known bits
-        if (b.op != 0 || a.len + b.len > LIT_TB) continue;
-        tab[i].val = (uint16_t)(a.val | (b.val << 8)); tab[i].len = (uint8_t)(a.len + b.len); tab[i].op = 0x01;
+        uint32_t val = a.val; int total = a.len, n = 1;
+        while (n < 4) {
+            const HuffEnt b = orig[i >> total];                   // upper (unknown) bits read as 0: valid iff b fits the known bits
+            if (b.op != 0 || total + b.len > LIT_TB) break;
+            val |= b.val << (8 * n); total += b.len; n++;
+        }
+        tab[i].val = val; tab[i].len = (uint8_t)total; tab[i].op = (uint8_t)(n - 1);
     }
 }
 
@@ -185,16 +190,16 @@ static inline int inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, si
                 HuffEnt e = lit[XCK_BITS(LIT_TB)];
                 if (e.op & 0x80) { XCK_DROP(LIT_TB); e = lit[e.val + XCK_BITS(e.op & 15)]; }
                 XCK_DROP(e.len);
-                if (e.op <= 1) {                                  // one or two literals per lookup; up to four lookups per refill
-                    op[0] = (uint8_t)e.val; op[1] = (uint8_t)(e.val >> 8); op += 1 + e.op;
+                if (e.op <= 3) {                                  // one to four literals per lookup; up to four lookups per refill
+                    memcpy(op, &e.val, 4); op += 1 + e.op;
                     e = lit[XCK_BITS(LIT_TB)];
-                    if (e.op <= 1) {
-                        XCK_DROP(e.len); op[0] = (uint8_t)e.val; op[1] = (uint8_t)(e.val >> 8); op += 1 + e.op;
+                    if (e.op <= 3) {
+                        XCK_DROP(e.len); memcpy(op, &e.val, 4); op += 1 + e.op;
                         e = lit[XCK_BITS(LIT_TB)];
-                        if (e.op <= 1) {
-                            XCK_DROP(e.len); op[0] = (uint8_t)e.val; op[1] = (uint8_t)(e.val >> 8); op += 1 + e.op;
+                        if (e.op <= 3) {
+                            XCK_DROP(e.len); memcpy(op, &e.val, 4); op += 1 + e.op;
                             e = lit[XCK_BITS(LIT_TB)];
-                            if (e.op <= 1) { XCK_DROP(e.len); op[0] = (uint8_t)e.val; op[1] = (uint8_t)(e.val >> 8); op += 1 + e.op; }
+                            if (e.op <= 3) { XCK_DROP(e.len); memcpy(op, &e.val, 4); op += 1 + e.op; }
                         }
                     }
                     continue;
@@ -225,10 +230,9 @@ static inline int inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, si
                 HuffEnt e = lit[XCK_BITS(LIT_TB)];
                 if (e.op & 0x80) { XCK_DROP(LIT_TB); e = lit[e.val + XCK_BITS(e.op & 15)]; }
                 XCK_DROP(e.len);
-                if (e.op <= 1) {
+                if (e.op <= 3) {
                     if ((size_t)(out_end - op) < 1u + e.op) return -17;
-                    *op++ = (uint8_t)e.val;
-                    if (e.op) *op++ = (uint8_t)(e.val >> 8);
+                    for (uint32_t k = 0, v_ = e.val; k <= e.op; k++, v_ >>= 8) *op++ = (uint8_t)v_;
                     continue;
                 }
                 if (e.op == 0x20) break;                          // end of block
