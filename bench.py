@@ -13,8 +13,10 @@ host decode included; every BAM record counts, filtered or not.
 
 N > 1 (one rank per GPU, launched by torch.distributed.run): STRONG scaling of the same file - contigs are assigned to
 ranks by longest-processing-time on the .bai record counts, every rank inflates only the byte ranges of its contigs with
-its share of the host cores, ranks own disjoint matrix rows, and the per-rank sparse blocks (still resident in HBM) are
-gathered on rank 0 by one all-gather of sizes + one padded gather (RCCL over xGMI), which writes the files.
+its share of the host cores, ranks own disjoint matrix rows, and every rank writes the lines of its own rows into the
+four .mtx files at offsets derived from ONE all-reduce of text sizes per file (shard.write_mtx_sharded; the ranks of a
+node share the output directory).  --gather restores the exchange of the sparse blocks instead: one all-gather of sizes +
+one padded gather of the blocks still resident in HBM (RCCL over xGMI) to rank 0, which merges and writes.
 
 Sub-records of the same JSON line:
   roofline         dominant hand-written kernel on the HBM-resident form of the same workload shape (500 M synthetic
@@ -39,7 +41,7 @@ import torch
 
 from xcltk_amd import capi
 from xcltk_amd.engine import Engine
-from xcltk_amd.shard import BlockGatherer, contig_owner, merge_row_blocks
+from xcltk_amd.shard import BlockGatherer, contig_owner, merge_row_blocks, write_mtx_sharded
 from xcltk_amd.synth import soa, soa_torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
@@ -116,6 +118,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=40_000_000, help="records in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--resident-passes", type=int, default=5, help="timed passes of the HBM-resident sub-record (0 = skip it and the roofline)")
+    ap.add_argument("--gather", action="store_true", help="N > 1: gather the per-rank sparse blocks on rank 0 (RCCL) and let it write the files, "
+                    "instead of every rank writing the lines of its own rows (default)")
     ap.add_argument("--resident-only", action="store_true", help="run only the HBM-resident sub-record (the command profiles/ traces with rocprofv3: "
                     "its k_join launches are the 500 M-read launches the roofline is computed from)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
@@ -198,7 +202,7 @@ def main():
     if rank == 0:
         os.makedirs(os.path.join(out_dir, "basefc"), exist_ok=True)
         os.makedirs(os.path.join(out_dir, "baf"), exist_ok=True)
-    gatherer = BlockGatherer(world, rank, device, backend_is_nccl=not shared_gpu) if world > 1 else None
+    gatherer = BlockGatherer(world, rank, device, backend_is_nccl=not shared_gpu) if world > 1 and args.gather else None
 
     # ---- the pass: warmup + steps slices of this rank's records ----
     n_slices = max(1, args.warmup + args.steps)
@@ -219,7 +223,23 @@ def main():
     coo = eng.finish(copy=False)                                # folds on the GPU + copy-out to pinned host memory
     stats = eng.stats()
     marks["finish"] = time.perf_counter() - t0
-    if world > 1:
+    n = len(regions)
+    rm = np.arange(1, n + 1, dtype=np.int32)                   # output_all_reg: row = input line (rdr/fc/config.py:103, baf/pipeline.py:356)
+    files = (("count", os.path.join(out_dir, "basefc", "matrix.mtx")), ("ad", os.path.join(out_dir, "baf", "xcltk.AD.mtx")),
+             ("dp", os.path.join(out_dir, "baf", "xcltk.DP.mtx")), ("oth", os.path.join(out_dir, "baf", "xcltk.OTH.mtx")))
+    nnz = None
+    if world > 1 and not args.gather:
+        # every rank writes the lines of its own rows into the four files (one all-reduce of text sizes per file): no triplets
+        # travel, and the ~10^8 lines are formatted by all ranks' host cores instead of rank 0's
+        row_owner = contig_owner(names, counts.astype(np.float64) + 1e-9, world)[row_contig]
+
+        def all_reduce_sum(x):
+            t_ = torch.from_numpy(np.ascontiguousarray(x)).to(gather_device)
+            dist.all_reduce(t_)
+            return t_.cpu().numpy()
+        nnz = {k: write_mtx_sharded(fn, coo[k], rm, row_owner, n, len(bcs), rank, all_reduce_sum, dist.barrier, eng.lib) for k, fn in files}
+        marks["write"] = time.perf_counter() - t0
+    elif world > 1:
         gatherer.start(eng.result_device())
         blocks = gatherer.wait()                               # rank 0: {name: [per-rank int32 [row|col|val] tensors]}
         marks["gather"] = time.perf_counter() - t0
@@ -227,23 +247,20 @@ def main():
             owner = contig_owner(names, counts.astype(np.float64) + 1e-9, world)
             coo = {k: merge_row_blocks([b.cpu().numpy() for b in blocks[k]], owner[row_contig]) for k in blocks}
             marks["merge"] = time.perf_counter() - t0
-    nnz = None
     if rank == 0:
-        n = len(regions)
-        rm = np.arange(1, n + 1, dtype=np.int32)               # output_all_reg: row = input line (rdr/fc/config.py:103, baf/pipeline.py:356)
         with open(os.path.join(out_dir, "basefc", "features.tsv"), "w") as fp:
             fp.write("".join("%s\t%d\t%d\t%s\n" % r for r in regions))
         with open(os.path.join(out_dir, "basefc", "barcodes.tsv"), "w") as fp:
             fp.write("".join(b + "\n" for b in bcs))
-        eng.write_mtx_arrays(os.path.join(out_dir, "basefc", "matrix.mtx"), coo["count"], rm, n)
         with open(os.path.join(out_dir, "baf", "xcltk.region.tsv"), "w") as fp:
             fp.write("".join("%s\t%d\t%d\t%s\n" % r for r in regions))
         with open(os.path.join(out_dir, "baf", "xcltk.samples.tsv"), "w") as fp:
             fp.write("".join(b + "\n" for b in bcs))
-        for k, fn in (("ad", "xcltk.AD.mtx"), ("dp", "xcltk.DP.mtx"), ("oth", "xcltk.OTH.mtx")):
-            eng.write_mtx_arrays(os.path.join(out_dir, "baf", fn), coo[k], rm, n)
+        if nnz is None:
+            for k, fn in files:
+                eng.write_mtx_arrays(fn, coo[k], rm, n)
+            nnz = {k: int(len(coo[k][0])) for k, _ in files}
         marks["write"] = time.perf_counter() - t0
-        nnz = {k: int(len(coo[k][0])) for k in ("count", "ad", "dp", "oth")}
     barrier()
     dt = time.perf_counter() - t0
     stream.close()

@@ -287,6 +287,12 @@ void xck_free_snp_text(xck_snp_text* t);
  * (0 = region not written). */
 int  xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map,
                    int32_t n_rows_out, int32_t n_cols);
+/* The same file written by several processes (multi-GPU run on one node; no reference counterpart - its workers hand their
+ * triplets to the parent, rdr/fc/main.py:232-262): every process owns some rows.  xck_mtx_part_size gives the bytes and lines
+ * of the "row\tcol\tval\n" text of m (no header); after the sizes have been exchanged, xck_write_mtx_part writes that text at
+ * byte `offset` of `path` (created if needed, never truncated).  The header line is the caller's. */
+int  xck_mtx_part_size(const xck_coo* m, const int32_t* row_map, int64_t* n_bytes, int64_t* n_lines);
+int  xck_write_mtx_part(const char* path, int64_t offset, const xck_coo* m, const int32_t* row_map);
 
 #ifdef __cplusplus
 }

@@ -352,6 +352,42 @@ def test_unmapped_flag_with_cigar_include_test():
     util.assert_coo_equal(got, exp, ["count"])
 
 
+def test_documented_divergences_from_the_reference_are_the_chosen_behaviour():
+    """Two inputs on which this implementation does NOT do what the reference would, asserted here so
+    that the choice cannot drift silently:
+    (1) a read without a CIGAR that reaches the FRACTIONAL include test: the reference compares `None < float` and the whole
+        run dies (rdr/fc/core.py:35,161); engine and oracle drop that read - the result equals the run without it.  With an
+        integer threshold or min_include = 0 the reference has an answer (the read has no aligned base: it fails `>= 1` and
+        passes `0`) and parity holds as everywhere else;
+    (2) a region beyond pysam's MAX_POS (2^29 in some 0.15 builds): the reference's fetch raises -> all-zero row; engine and
+        oracle take any int32 coordinate and count the reads there."""
+    names = ["1"]
+    far = (1 << 29) + 1000
+    regions = [("1", 101, 400, "g"), ("1", far, far + 500, "beyond_max_pos")]
+    M = 0
+    def mk(with_cigarless):
+        pos = [150, 160, far + 10] + ([170] if with_cigarless else [])
+        cig = [[(M, 91)], [(M, 91)], [(M, 91)]] + ([[]] if with_cigarless else [])
+        order = np.argsort(np.array(pos), kind="stable")
+        cw, off = [], [0]
+        for i in order:
+            cw += [(l << 4) | op for op, l in cig[i]]; off.append(len(cw))
+        n = len(pos)
+        d = dict(contig=0, ordinal_base=0, pos=np.array(pos, np.int32)[order], flag=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8),
+                 cell=np.zeros(n, np.int32), umi=((1 << 24) | np.arange(n)).astype(np.uint64)[order], cig_off=np.array(off, np.uint32),
+                 cigar=np.array(cw, np.uint32))
+        return [util.batch_from_dict(d)]
+    for inc in (0.9, 0.5):
+        got, exp, _ = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, mk(True), min_include=inc, min_len=0)
+        util.assert_coo_equal(got, exp, ["count"])
+        got0, _, _ = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, mk(False), min_include=inc, min_len=0)
+        util.assert_coo_equal(got, got0, ["count"])                      # (1): the CIGAR-less read is dropped
+        assert got["count"][0].tolist() == [0, 1] and got["count"][2].tolist() == [2, 1]   # (2): the far region counts its read
+    for inc in (0, 1):                                                   # the reference has an answer here: plain parity
+        got, exp, _ = util.engine_vs_oracle(capi.XCK_MODE_BASEFC, names, regions, [], 1, mk(True), min_include=inc, min_len=0)
+        util.assert_coo_equal(got, exp, ["count"])
+
+
 def test_push_batch_rejects_inconsistent_host_arrays(small):
     """xck_push_batch checks caller-supplied host arrays before a kernel sees them (api.cpp check_host_batch): offsets that run
     backwards, a cell index outside the cell table, a contig outside the configured ones; the handle stays usable."""

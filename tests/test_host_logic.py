@@ -269,6 +269,51 @@ def test_gather_coo_gloo_world2(tmp_path):
     assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout, r.stdout[-2000:]
 
 
+_SHARDED_WRITER_WORKER = r"""
+import os, sys, ctypes as C
+import numpy as np
+import torch, torch.distributed as dist
+root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+from xcltk_amd import capi, shard
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(11)                              # the same matrix on every rank; each rank keeps the rows it owns
+n_rows, n_cols, n = 900, 123, 60000
+row_owner = np.repeat(rng.integers(0, world, 45), 20).astype(np.int32)
+row = rng.integers(0, n_rows, n).astype(np.int32); col = rng.integers(0, n_cols, n).astype(np.int32)
+val = rng.choice(np.array([1, 7, 10, 99, 100, 12345, 2147483647], dtype=np.int32), n).astype(np.int32)
+o = np.lexsort((col, row)); row, col, val = row[o], col[o], val[o]
+rm = np.arange(1, n_rows + 1, dtype=np.int32); rm[::5] = 0; rm[rm > 0] = np.arange(1, int((rm > 0).sum()) + 1)
+def allred(x):
+    t = torch.from_numpy(np.ascontiguousarray(x)); dist.all_reduce(t); return t.numpy()
+sel = row_owner[row] == rank
+lines = shard.write_mtx_sharded(os.path.join(out, "sharded.mtx"), (row[sel], col[sel], val[sel]), rm, row_owner, int(rm.max()), n_cols,
+                                rank, allred, dist.barrier)
+if rank == 0:
+    lib = capi.load()
+    c = capi.Coo(); c.nnz = n; c.row, c.col, c.val = (capi.np_ptr(x, C.c_int32) for x in (row, col, val))
+    assert lib.xck_write_mtx(os.path.join(out, "single.mtx").encode(), C.byref(c), capi.np_ptr(rm, C.c_int32), int(rm.max()), n_cols) == 0
+    a = open(os.path.join(out, "single.mtx"), "rb").read(); b = open(os.path.join(out, "sharded.mtx"), "rb").read()
+    assert a == b and lines == int((rm[row] > 0).sum()), (len(a), len(b), lines)
+    print("SHARDED_WRITE_OK", len(a), lines)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_mtx_written_by_all_ranks_equals_single_writer(tmp_path):
+    """shard.write_mtx_sharded (three gloo ranks, every rank writes the lines of its rows at offsets derived from ONE all-reduce
+    of text sizes) must produce the bytes xck_write_mtx writes for the merged matrix - row map with dropped rows included."""
+    script = tmp_path / "w.py"
+    script.write_text(_SHARDED_WRITER_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT, str(tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert "SHARDED_WRITE_OK" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("ds,mask", [("multibam", [True, False]), ("multibam", [False, True]), ("special", [False, True, False])])
 def test_indexed_contig_subset_decode(ds, mask):
     """use_index + contig_mask (multi-GPU sharding) must yield exactly the records of the owned

@@ -164,64 +164,114 @@ int xck_get_stats(const xck_engine* ce, xck_stats* out) {
     return XCK_OK;
 }
 
-// merge_mtx() header + body, rdr/fc/utils.py:54-93 (byte-identical text)
-int xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map, int32_t n_rows_out, int32_t n_cols) {
-    // Text identical to merge_mtx (rdr/fc/utils.py:54-93).  A 500 M-read run writes ~10^8 lines: the entries are formatted by
-    // a few threads, a wave of 1 M-entry chunks at a time, and the chunks are written in order.
-    if (!path || !m || !row_map) return XCK_E_ARG;
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    if (fd < 0) { set_thread_error(std::string("cannot open ") + path); return XCK_E_IO; }
-    auto put_all = [fd](const char* p, size_t len, off_t at) { while (len) { const ssize_t w = pwrite(fd, p, len, at); if (w < 0) { if (errno == EINTR) continue; return false; }
-                                                                              p += w; len -= (size_t)w; at += w; } return true; };
-    const int64_t n = m->nnz;
-    const int64_t CH = 1 << 20;
-    const int64_t n_chunks = (n + CH - 1) / CH;
-    unsigned nt = (unsigned)default_threads(); if (nt > 16) nt = 16;
-    if (const char* e = getenv("XCK_WRITE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
-    if ((int64_t)nt > n_chunks) nt = (unsigned)std::max<int64_t>(n_chunks, 1);
-    auto for_chunks = [&](int64_t c0, int64_t c1, const std::function<void(int64_t)>& fn) {
+// ---- MatrixMarket text (merge_mtx(), rdr/fc/utils.py:54-93: byte-identical) ----
+// A 500 M-read run writes ~10^8 lines: the entries are formatted by a few threads, a wave of 1 M-entry chunks at a time; the
+// chunks' file offsets follow from their sizes, and the same threads copy their chunks into the file with pwrite.
+namespace {
+const char* const kDigits2 =
+    "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+    "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+// decimal text of an int32-sized number: two digits per step from a table
+inline void put_int(char*& p, int64_t v64) {
+    if (v64 < 0) { *p++ = '-'; v64 = -v64; }
+    uint64_t v = (uint64_t)v64;
+    if (v < 10) { *p++ = char('0' + v); return; }
+    if (v < 100) { memcpy(p, kDigits2 + 2 * v, 2); p += 2; return; }
+    char t[24]; int q = 24;
+    while (v >= 100) { const uint64_t r = v % 100; v /= 100; q -= 2; memcpy(t + q, kDigits2 + 2 * r, 2); }
+    if (v >= 10) { q -= 2; memcpy(t + q, kDigits2 + 2 * v, 2); } else t[--q] = char('0' + v);
+    memcpy(p, t + q, (size_t)(24 - q)); p += 24 - q;
+}
+inline int n_digits(int64_t v) { int d = v < 0 ? 2 : 1; if (v < 0) v = -v; while (v >= 10) { v /= 10; d++; } return d; }
+
+struct MtxBody {
+    const xck_coo* m; const int32_t* row_map; int64_t n, n_chunks; unsigned nt;
+    static constexpr int64_t CH = 1 << 20;
+    MtxBody(const xck_coo* m_, const int32_t* rm) : m(m_), row_map(rm), n(m_->nnz), n_chunks((m_->nnz + CH - 1) / CH) {
+        nt = (unsigned)xck::default_threads(); if (nt > 16) nt = 16;
+        if (const char* e = getenv("XCK_WRITE_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+        if ((int64_t)nt > n_chunks) nt = (unsigned)std::max<int64_t>(n_chunks, 1);
+    }
+    void for_chunks(int64_t c0, int64_t c1, const std::function<void(int64_t)>& fn) const {
         if (nt <= 1 || c1 - c0 <= 1) { for (int64_t c = c0; c < c1; c++) fn(c); return; }
         std::atomic<int64_t> next(c0);
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { for (int64_t c; (c = next.fetch_add(1)) < c1;) fn(c); });
         for (auto& x : th) x.join();
-    };
-    std::vector<int64_t> kept((size_t)n_chunks, 0);
-    for_chunks(0, n_chunks, [&](int64_t c) { int64_t k = 0; const int64_t e = std::min(n, (c + 1) * CH);
-        for (int64_t i = c * CH; i < e; i++) if (row_map[m->row[i]] > 0) k++; kept[(size_t)c] = k; });
-    int64_t nnz = 0; for (int64_t k : kept) nnz += k;
-    char line[96];
-    int k = snprintf(line, sizeof line, "%%%%MatrixMarket matrix coordinate integer general\n%%%%\n%d\t%d\t%lld\n", n_rows_out, n_cols, (long long)nnz);
-    if (!put_all(line, (size_t)k, 0)) { close(fd); return XCK_E_IO; }
-    off_t file_off = (off_t)k;
-    auto put_int = [](char*& p, int64_t v) { char t[24]; int q = 0; if (v == 0) t[q++] = '0'; const bool neg = v < 0; if (neg) v = -v;
-        while (v) { t[q++] = char('0' + v % 10); v /= 10; } if (neg) *p++ = '-'; while (q) *p++ = t[--q]; };
-    // a wave of chunks is formatted in parallel, the chunks' file offsets follow from their sizes, and the same threads then
-    // copy their chunks into the file with pwrite (the copy into the page cache was the serial half of a 1.6 GB output)
-    const int64_t WAVE = std::max<int64_t>(nt * 2, 1);
-    std::vector<std::unique_ptr<char[]>> bufs((size_t)WAVE);           // uninitialised, allocated on first use, reused by every wave
-    std::vector<size_t> used((size_t)WAVE, 0);
-    std::vector<off_t> at((size_t)WAVE, 0);
-    std::atomic<bool> io_ok(true);
-    for (int64_t w0 = 0; w0 < n_chunks; w0 += WAVE) {
-        const int64_t w1 = std::min(n_chunks, w0 + WAVE);
-        for_chunks(w0, w1, [&](int64_t c) {
-            std::unique_ptr<char[]>& b = bufs[(size_t)(c - w0)];
-            if (!b) b.reset(new char[(size_t)CH * 36]);                // 3 ints of <= 11 characters + 3 separators per line
-            char* p = b.get();
-            const int64_t e = std::min(n, (c + 1) * CH);
-            for (int64_t i = c * CH; i < e; i++) {
-                const int32_t r = row_map[m->row[i]];
-                if (r <= 0) continue;
-                put_int(p, r); *p++ = '\t'; put_int(p, (int64_t)m->col[i] + 1); *p++ = '\t'; put_int(p, m->val[i]); *p++ = '\n';
-            }
-            used[(size_t)(c - w0)] = (size_t)(p - b.get());
-        });
-        for (int64_t c = w0; c < w1; c++) { at[(size_t)(c - w0)] = file_off; file_off += (off_t)used[(size_t)(c - w0)]; }
-        for_chunks(w0, w1, [&](int64_t c) { const size_t j = (size_t)(c - w0); if (used[j] && !put_all(bufs[j].get(), used[j], at[j])) io_ok = false; });
-        if (!io_ok) { close(fd); return XCK_E_IO; }
     }
+    // lines (entries whose region is written) and, if asked, the bytes of their text
+    void measure(int64_t* lines, int64_t* bytes) const {
+        std::vector<int64_t> kl((size_t)n_chunks, 0), kb((size_t)n_chunks, 0);
+        for_chunks(0, n_chunks, [&](int64_t c) { int64_t k = 0, by = 0; const int64_t e = std::min(n, (c + 1) * CH);
+            for (int64_t i = c * CH; i < e; i++) { const int32_t r = row_map[m->row[i]]; if (r <= 0) continue; k++;
+                if (bytes) by += n_digits(r) + n_digits((int64_t)m->col[i] + 1) + n_digits(m->val[i]) + 3; }
+            kl[(size_t)c] = k; kb[(size_t)c] = by; });
+        int64_t L = 0, B = 0; for (int64_t c = 0; c < n_chunks; c++) { L += kl[(size_t)c]; B += kb[(size_t)c]; }
+        *lines = L; if (bytes) *bytes = B;
+    }
+    // "row\tcol\tval\n" lines into fd from byte `file_off` on; returns the offset past the last byte, or -1
+    off_t write(int fd, off_t file_off) const {
+        auto put_all = [fd](const char* p, size_t len, off_t at) { while (len) { const ssize_t w = pwrite(fd, p, len, at); if (w < 0) { if (errno == EINTR) continue; return false; }
+                                                                                  p += w; len -= (size_t)w; at += w; } return true; };
+        const int64_t WAVE = std::max<int64_t>(nt * 2, 1);
+        std::vector<std::unique_ptr<char[]>> bufs((size_t)WAVE);       // uninitialised, allocated on first use, reused by every wave
+        std::vector<size_t> used((size_t)WAVE, 0);
+        std::vector<off_t> at((size_t)WAVE, 0);
+        std::atomic<bool> io_ok(true);
+        for (int64_t w0 = 0; w0 < n_chunks; w0 += WAVE) {
+            const int64_t w1 = std::min(n_chunks, w0 + WAVE);
+            for_chunks(w0, w1, [&](int64_t c) {
+                std::unique_ptr<char[]>& b = bufs[(size_t)(c - w0)];
+                if (!b) b.reset(new char[(size_t)CH * 36 + 64]);       // 3 ints of <= 11 characters + 3 separators per line (+ slack for the 16-byte row copy)
+                char* p = b.get();
+                const int64_t e = std::min(n, (c + 1) * CH);
+                char rtxt[16] = {0}; int rlen = 0; int32_t r_prev = -1;   // entries are sorted by row: its text is built once per run
+                for (int64_t i = c * CH; i < e; i++) {
+                    const int32_t r = row_map[m->row[i]];
+                    if (r <= 0) continue;
+                    if (r != r_prev) { char* q = rtxt; put_int(q, r); *q++ = '\t'; rlen = (int)(q - rtxt); r_prev = r; }
+                    memcpy(p, rtxt, 16); p += rlen;                    // (16-byte copy, rlen <= 12 of it kept)
+                    put_int(p, (int64_t)m->col[i] + 1); *p++ = '\t'; put_int(p, m->val[i]); *p++ = '\n';
+                }
+                used[(size_t)(c - w0)] = (size_t)(p - b.get());
+            });
+            for (int64_t c = w0; c < w1; c++) { at[(size_t)(c - w0)] = file_off; file_off += (off_t)used[(size_t)(c - w0)]; }
+            for_chunks(w0, w1, [&](int64_t c) { const size_t j = (size_t)(c - w0); if (used[j] && !put_all(bufs[j].get(), used[j], at[j])) io_ok = false; });
+            if (!io_ok) return (off_t)-1;
+        }
+        return file_off;
+    }
+};
+}  // namespace
+
+int xck_write_mtx(const char* path, const xck_coo* m, const int32_t* row_map, int32_t n_rows_out, int32_t n_cols) {
+    if (!path || !m || !row_map) return XCK_E_ARG;
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { set_thread_error(std::string("cannot open ") + path); return XCK_E_IO; }
+    MtxBody body(m, row_map);
+    int64_t nnz = 0; body.measure(&nnz, nullptr);
+    char line[96];
+    const int k = snprintf(line, sizeof line, "%%%%MatrixMarket matrix coordinate integer general\n%%%%\n%d\t%d\t%lld\n", n_rows_out, n_cols, (long long)nnz);
+    if (pwrite(fd, line, (size_t)k, 0) != (ssize_t)k) { close(fd); return XCK_E_IO; }
+    const off_t end = body.write(fd, (off_t)k);
+    if (end < 0) { close(fd); return XCK_E_IO; }
     if (close(fd) != 0) return XCK_E_IO;
+    return XCK_OK;
+}
+
+// One process's piece of a file that several processes write together (multi-GPU run on one node: every rank owns rows and
+// writes their lines itself; sizes are exchanged first, so every piece knows its offset).
+int xck_mtx_part_size(const xck_coo* m, const int32_t* row_map, int64_t* n_bytes, int64_t* n_lines) {
+    if (!m || !row_map || !n_bytes || !n_lines) return XCK_E_ARG;
+    MtxBody(m, row_map).measure(n_lines, n_bytes);
+    return XCK_OK;
+}
+int xck_write_mtx_part(const char* path, int64_t offset, const xck_coo* m, const int32_t* row_map) {
+    if (!path || !m || !row_map || offset < 0) return XCK_E_ARG;
+    const int fd = open(path, O_WRONLY | O_CREAT, 0666);             // never truncated: other pieces may be there already
+    if (fd < 0) { set_thread_error(std::string("cannot open ") + path); return XCK_E_IO; }
+    const off_t end = MtxBody(m, row_map).write(fd, (off_t)offset);
+    if (close(fd) != 0 || end < 0) return XCK_E_IO;
     return XCK_OK;
 }
 

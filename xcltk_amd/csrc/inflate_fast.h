@@ -185,9 +185,11 @@ static inline int inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, si
             // ---- fast loop: far from both buffer ends, so no per-symbol bounds checks; one branch-free refill per
             //      iteration gives >= 56 bits, enough for 2 literals (<= 15 + 11 bits) or a full match (<= 48 bits)
             bool eob = false;
+            HuffEnt e; bool have = false;                         // have: e was looked up by the previous iteration and not consumed yet
             while (!eob && ip + 8 <= in_end && (size_t)(out_end - op) >= 280) {
                 { uint64_t w_; memcpy(&w_, ip, 8); bb |= w_ << bc; ip += (63 - bc) >> 3; bc |= 56; }
-                HuffEnt e = lit[XCK_BITS(LIT_TB)];
+                if (!have) e = lit[XCK_BITS(LIT_TB)];             // (a refill only adds bits above the ones an earlier lookup used)
+                have = false;
                 if (e.op & 0x80) { XCK_DROP(LIT_TB); e = lit[e.val + XCK_BITS(e.op & 15)]; }
                 XCK_DROP(e.len);
                 if (e.op <= 3) {                                  // one to four literals per lookup; up to four lookups per refill
@@ -198,10 +200,11 @@ static inline int inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, si
                         e = lit[XCK_BITS(LIT_TB)];
                         if (e.op <= 3) {
                             XCK_DROP(e.len); memcpy(op, &e.val, 4); op += 1 + e.op;
-                            e = lit[XCK_BITS(LIT_TB)];
-                            if (e.op <= 3) { XCK_DROP(e.len); memcpy(op, &e.val, 4); op += 1 + e.op; }
+                            e = lit[XCK_BITS(LIT_TB)];            // >= 19 bits are left here: still a lookup on valid bits
+                            if (e.op <= 3) { XCK_DROP(e.len); memcpy(op, &e.val, 4); op += 1 + e.op; continue; }
                         }
                     }
+                    have = true;                                  // the entry that ended the run of literals opens the next iteration
                     continue;
                 }
                 if (e.op == 0x20) { eob = true; break; }
