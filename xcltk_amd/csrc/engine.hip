@@ -5,17 +5,21 @@
 //   xcltk/baf/fc/core.py:70-247  (fc_features -> fc_fet1 -> plp_snp -> MCount/SCount/UCount)
 // with ONE streaming pass over coordinate-sorted record batches:
 //
-//   k_tile_meta : one thread per 1024-read tile: extent, staged index windows (48-byte record).
-//   k_join      : one block per tile; CIGAR run, window CSR and regions / SNPs staged in LDS.
-//                 basefc: read x region interval join + CIGAR-walk include test, accepted keys de-duplicated in an LDS
-//                 hash set.  pileup: read x SNP join with the (read, SNP) pairs dealt evenly over each wave's lanes; hits
-//                 with a base and "gap records" (SNPs inside N / D gaps) leave in two streams.
+//   k_tile_meta : one thread per 1024-read tile: extent, first candidate region (bisection on the running maximum of the
+//                 region ends) or staged SNP windows (48-byte record).
+//   k_join      : one block per tile; CIGAR run and the next regions / SNPs staged in LDS.
+//                 basefc: read x region interval join, region-major and wave-uniform (the 64 reads of a wave walk the same
+//                 candidate list once) + CIGAR-walk include test, accepted keys de-duplicated in an LDS hash set.
+//                 pileup: single-block reads walk the SNPs under them SNP-major; spliced / indel reads are set aside and
+//                 processed together after the sweeps ((read, SNP) pairs dealt evenly over each wave's lanes); hits with
+//                 a base and "gap records" (SNPs inside N / D gaps) leave in two streams.
 //                 Fragments are appended through sharded cursors.
 //   finish      : basefc: radix sort (rocPRIM) over the (row, cell) bits, k_fold_heads / k_fold_emit_unsorted (distinct
 //                 UMIs of a run told apart by an LDS hash set) straight into COO; classic path: full sort + k_fold_emit.
-//                 pileup: sort of the hits with a base, k_first_base (first read per key, Bloom filter), k_claim (gap
-//                 records that hold a key earlier in fetch order), k_tally, k_expand (per-SNP filters, SNP -> region
-//                 fan-out), k_hap_counts (haplotype set algebra), k_cp_* (ordered compaction); 128-bit keys: k_first_read.
+//                 pileup: sort of the hits with a base, k_first_base (first read per key, Bloom filter; k_first_long for
+//                 runs longer than 64), k_claim (gap records that hold a key earlier in fetch order), k_tally, k_expand
+//                 (per-SNP filters, SNP -> region fan-out), k_hap_class / k_hap_sum / k_hap_final (haplotype set algebra
+//                 by block scans), k_cp_* (ordered compaction); 128-bit keys: k_first_read.
 //                 Copy-out on the copy stream (xck_finish_async).
 //
 // Integer / byte work only - HBM-bound, no MFMA.  See DESIGN.md for layouts, byte counts and measurements.
