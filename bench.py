@@ -277,6 +277,8 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    if decoded_all > n_total:                                  # N > 1: ranks walk whole BGZF blocks, so the records of a block that spans
+        timed_all = int(timed_all * (n_total / decoded_all))   # two ranks' contigs are walked twice - count every BAM record once
     value = timed_all / dt
     ms_step = dt / args.steps * 1e3
     mtx_bytes = sum(os.path.getsize(os.path.join(out_dir, d, f)) for d, f in (("basefc", "matrix.mtx"), ("baf", "xcltk.AD.mtx"), ("baf", "xcltk.DP.mtx"), ("baf", "xcltk.OTH.mtx")))

@@ -1,0 +1,59 @@
+"""bench.py's contract with the driver, at a size that runs in seconds: the JSON line carries the keys the driver and the judge read
+(metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype / config.workload / roofline / cpu_baseline), the
+in-run comparison with the oracle holds, and a two-rank run (sharing the one GPU of the test box, gloo) writes byte-identical files
+through both exchange forms (every rank writes its rows; --gather: blocks gathered on rank 0)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZE = ["--reads", "3000000", "--cells", "2000", "--snps", "100000", "--genes", "8000"]
+FILES = ("basefc/matrix.mtx", "basefc/features.tsv", "basefc/barcodes.tsv", "baf/xcltk.AD.mtx", "baf/xcltk.DP.mtx", "baf/xcltk.OTH.mtx",
+         "baf/xcltk.region.tsv", "baf/xcltk.samples.tsv")
+
+
+def _run(args, env, timeout=600):
+    r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def _read(work, n):
+    return {f: open(os.path.join(work, "out_n%d" % n, f), "rb").read() for f in FILES}
+
+
+def test_bench_line_and_two_rank_outputs(tmp_path):
+    from test_gpu_multirank import _free_port
+    work = str(tmp_path / "work")
+    env = dict(os.environ, XCK_BENCH_DIR=work, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-sample", "400000", "--resident-passes", "1"] + SIZE, env)
+    assert d["metric"] == "reads/sec into AD/DP+basefc matrices" and d["unit"] == "reads/s" and d["n_gpus"] == 1
+    assert d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "int64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["steps"] / 1e3 - d["end_to_end"]["seconds"]) < 0.01
+    assert d["end_to_end"]["records_decoded"] == 3000000 and d["end_to_end"]["records_timed"] < 3000000   # the warm-up slice is not counted
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and set(rf["kernels"]) == {"k_join<basefc>", "k_join<pileup>"}
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["gpu_rows_vs_oracle"].startswith("ok")
+    one = _read(work, 1)
+    assert one["basefc/matrix.mtx"].startswith(b"%%MatrixMarket matrix coordinate integer general\n%%\n8000\t2000\t")
+    for extra in ([], ["--gather"]):
+        d2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                   "--master-port", _free_port(), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1"] + SIZE + extra, env)
+        assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["end_to_end"]["records_in_bam"] == 3000000
+        assert 3000000 <= d2["end_to_end"]["records_decoded"] < 3100000 and d2["end_to_end"]["records_timed"] < 3000000   # (blocks shared by two ranks' contigs are walked twice, counted once)
+        assert d2["config"]["nnz"] == d["config"]["nnz"]
+        two = _read(work, 2)
+        for f in FILES:
+            assert two[f] == one[f], "%s differs between N=1 and N=2 (%s)" % (f, extra or "sharded write")
+        os.remove(os.path.join(work, "out_n2", "basefc", "matrix.mtx"))
