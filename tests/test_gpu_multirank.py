@@ -1,5 +1,5 @@
-"""Contig-sharded multi-rank run of the real front-ends (two ranks sharing the one GPU of the
-test box, gloo for the exchange): rank 0's gathered output must equal the reference output."""
+"""Contig-sharded multi-rank runs of the real front-ends (ranks sharing the one GPU of the test box over gloo; one GPU per rank over
+RCCL where several are visible): the output files must equal the reference's, through both exchange forms."""
 import os
 import subprocess
 import sys
@@ -22,16 +22,21 @@ def _n_gpus():
     return torch.cuda.device_count()                    # (counting devices does not initialise the GPU in this process)
 
 
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("gloo", 4), ("nccl", 2)])
+@pytest.mark.parametrize("backend,world,exchange", [("gloo", 2, "sharded"), ("gloo", 2, "gather"), ("gloo", 4, "sharded"), ("nccl", 2, "sharded"), ("nccl", 2, "gather")])
 @pytest.mark.parametrize("name", ["multibam_basefc", "multibam_baf", "special_baf", "c1_basefc_default", "phasing_baf_refcells"])
-def test_ranks_match_reference(name, backend, world, tmp_path):
-    """gloo: the ranks share the one GPU of the test box and exchange host tensors; nccl: one GPU per rank, the per-rank
-    sparse blocks travel GPU to GPU over RCCL (runs only where at least two GPUs are visible - the driver's multi-GPU node)."""
+def test_ranks_match_reference(name, backend, world, exchange, tmp_path):
+    """gloo: the ranks share the one GPU of the test box; nccl: one GPU per rank, collectives over RCCL (runs only where at least
+    two GPUs are visible - the driver's multi-GPU node).  exchange "sharded" (default of the front-ends): every rank writes the lines
+    of its own rows into the output files, the only collectives are all-reduces of text sizes / row presence; "gather"
+    (XCK_DIST_GATHER=1): the per-rank sparse blocks travel to rank 0 (GPU to GPU with nccl), which merges and writes."""
     if backend == "nccl" and _n_gpus() < world:
         pytest.skip("the RCCL exchange needs %d visible GPUs" % world)
     if world == 4 and name not in ("multibam_basefc", "special_baf"):
         pytest.skip("world size 4 is rehearsed on two cases")
-    env = dict(os.environ, XCK_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if exchange == "gather" and name not in ("multibam_baf", "c1_basefc_default", "phasing_baf_refcells"):
+        pytest.skip("the gather form is rehearsed on three cases")
+    env = dict(os.environ, XCK_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               XCK_DIST_GATHER="1" if exchange == "gather" else "0")
     if backend == "gloo":
         env["XCK_DEVICE"] = "0"
     else:
@@ -43,7 +48,7 @@ def test_ranks_match_reference(name, backend, world, tmp_path):
     if "MULTIRANK_OK " + name not in r.stdout:
         out_dir = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "multirank_fail_%s.log" % name), "w") as fp:
+        with open(os.path.join(out_dir, "multirank_fail_%s_%s.log" % (name, exchange)), "w") as fp:
             fp.write(r.stdout)
     tb = [ln for ln in r.stdout.splitlines() if "Error" in ln or "error" in ln or "File \"/" in ln]
     assert "MULTIRANK_OK " + name in r.stdout, "\n".join(tb[-40:])

@@ -174,16 +174,15 @@ def afc_core(conf):
         conf.snp_csp = conf.ref_cells = None
     eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BAF, regions, snps, excl_pairs=excl)
     try:
-        if coo is not None:                               # rank 0 (or the only process) writes
-            if conf.output_all_reg:
-                rm = fcc.row_map_all(len(regions))
-            else:      # only regions that wrote a DP or OTH line keep a row (baf/fc/core.py:101-113)
-                rm = fcc.row_map_from_rows(len(regions), coo["dp"][0], coo["oth"][0])
+        if coo is not None:                               # the only process / rank 0 after a gather / every rank (sharded output)
+            # only regions that wrote a DP or OTH line keep a row (baf/fc/core.py:101-113)
+            rm = fcc.output_row_map(dist, len(regions), conf.output_all_reg, coo["dp"][0], coo["oth"][0])
             n_rows = int(rm.max()) if len(rm) else 0
-            fcc.write_region_tsv(conf.out_region_fn, regions, rm)
-            eng.write_mtx_arrays(conf.out_ad_fn, coo["ad"], rm, n_rows)
-            eng.write_mtx_arrays(conf.out_dp_fn, coo["dp"], rm, n_rows)
-            eng.write_mtx_arrays(conf.out_oth_fn, coo["oth"], rm, n_rows)
+            if fcc.is_writer_rank():
+                fcc.write_region_tsv(conf.out_region_fn, regions, rm)
+            fcc.write_mtx(eng, dist, conf.out_ad_fn, coo["ad"], rm, n_rows)
+            fcc.write_mtx(eng, dist, conf.out_dp_fn, coo["dp"], rm, n_rows)
+            fcc.write_mtx(eng, dist, conf.out_oth_fn, coo["oth"], rm, n_rows)
         if conf.debug > 0:
             info("engine stats: %s" % eng.stats())
     finally:

@@ -124,7 +124,7 @@ def pileup(sam_fn=None, sam_list_fn=None, barcode_fn=None, sample_id_fn=None, sa
     regions = [(format_chrom(c), p, p, "%s_%d" % (c, p)) for c, p, _, _ in cand]
     snps = [(format_chrom(c), p, r, a, 0, 1) for c, p, r, a in cand]
     conf.reg_list = regions
-    eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BAF, regions, snps, log_prefix="[pileup]")
+    eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BAF, regions, snps, log_prefix="[pileup]", gather=True)   # rank 0 writes the directory
     try:
         if coo is not None:                                       # the matrices are views of the engine's pinned buffers: keep copies past close()
             coo = {k: tuple(np.array(a) for a in v) for k, v in coo.items()}

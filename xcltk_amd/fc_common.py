@@ -292,6 +292,32 @@ def write_samples(path, samples):
         fp.write("".join(smp + "\n" for smp in samples))
 
 
+def output_row_map(dist, n, all_reg, *row_arrays):
+    """Output row of every region (0 = no row).  With sharded output the regions that wrote a line are known only jointly:
+    one all-reduce of a presence vector (collective call)."""
+    if all_reg:
+        return row_map_all(n)
+    if dist is not None and dist.active and dist.sharded_output:
+        keep = np.zeros(n, dtype=np.int32)
+        for r in row_arrays:
+            keep[r] = 1
+        keep = dist.all_reduce_np(keep, "max") > 0
+        rm = np.zeros(n, dtype=np.int32)
+        rm[keep] = np.arange(1, int(keep.sum()) + 1, dtype=np.int32)
+        return rm
+    return row_map_from_rows(n, *row_arrays)
+
+
+def write_mtx(eng, dist, path, coo_k, rm, n_rows_out):
+    """One matrix file: written by this process, or - sharded output - by all ranks together, each the lines of its own rows
+    (shard.write_mtx_sharded; collective call)."""
+    if dist is not None and dist.active and dist.sharded_output:
+        from .shard import write_mtx_sharded
+        write_mtx_sharded(path, coo_k, rm, dist.row_owner, n_rows_out, eng.n_cells, dist.rank, dist.all_reduce_np, dist.barrier, eng.lib)
+    else:
+        eng.write_mtx_arrays(path, coo_k, rm, n_rows_out)
+
+
 # ----------------------------------------------------------------------------- engine driver
 def make_engine(conf, mode, regions, snps=(), device=None, **extra):
     """Build the per-GPU engine from a resolved Config."""
@@ -319,8 +345,10 @@ def make_engine(conf, mode, regions, snps=(), device=None, **extra):
 class Dist(object):
     """Multi-GPU context (one process per GPU).  With WORLD_SIZE > 1 every
     rank builds the full tables, streams only the contigs it owns (LPT on .bai record counts,
-    contig lengths as fallback) and the per-rank sparse blocks are concatenated on rank 0 by one
-    all-gatherv (RCCL over xGMI with the nccl backend; gloo when XCK_DIST_BACKEND=gloo)."""
+    contig lengths as fallback; an over-weight contig is cut at region boundaries).  The results meet in one of two ways:
+    every rank writes the lines of its own rows into the shared output files (default: one all-reduce of text sizes per
+    file), or - XCK_DIST_GATHER=1 - the per-rank sparse blocks are concatenated on rank 0 by one all-gatherv.  RCCL over
+    xGMI with the nccl backend; gloo when XCK_DIST_BACKEND=gloo."""
 
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -328,6 +356,9 @@ class Dist(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = None
         self.device = "cpu"
+        # how the ranks' results meet: every rank writes the lines of its own rows into the shared output files (default; the
+        # ranks of one node see the same directory), or XCK_DIST_GATHER=1: the sparse blocks are gathered on rank 0, which writes
+        self.sharded_output = False
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -340,6 +371,7 @@ class Dist(object):
                     dist.init_process_group(self.backend)
             if self.backend == "nccl":
                 self.device = "cuda:%d" % self.local_rank
+            self.sharded_output = os.environ.get("XCK_DIST_GATHER", "0") in ("", "0")
 
     @property
     def active(self):
@@ -393,6 +425,18 @@ class Dist(object):
         # a rank that holds pieces next to whole contigs: whole contigs have no window (decoded entirely)
         return self
 
+    # -- the collectives the sharded writer needs (tiny tensors; RCCL with the nccl backend, gloo in the shared-GPU tests)
+    def all_reduce_np(self, x, op="sum"):
+        import torch
+        import torch.distributed as td
+        t = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        td.all_reduce(t, op=td.ReduceOp.MAX if op == "max" else td.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def barrier(self):
+        import torch.distributed as td
+        td.barrier()
+
     def gather(self, eng, regions):
         """all-gatherv of the per-rank sparse blocks to rank 0, straight from HBM (xck_get_result_device): one
         all-gather of sizes + one padded gather (RCCL over xGMI; host tensors over gloo).  Ranks own whole contigs,
@@ -424,10 +468,13 @@ def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None, windows=None
     return n_tot
 
 
-def make_and_count(conf, mode, regions, snps=(), log_prefix="[engine]", **extra):
+def make_and_count(conf, mode, regions, snps=(), log_prefix="[engine]", gather=None, **extra):
     """Build the engine, stream every BAM (this rank's contigs when running multi-GPU), fold, gather.  Keys that are not ACGT strings (IUPAC UMIs, integer tags, read names in UMI-less runs) are
     interned on the host and take one id each; when the ids outgrow the UMI field of a 64-bit key the decoder stops with
     XCK_E_CAPACITY - the run is then repeated once with 128-bit keys (XCK_F_FORCE_KEY128), on every rank of a multi-GPU run.
+    Multi-GPU: by default every rank gets ITS OWN rows back (dist.sharded_output) and the ranks write the files together
+    (output_row_map / write_mtx below are then collective calls); gather=True, or XCK_DIST_GATHER=1, gathers the blocks on
+    rank 0 instead (coo is None on the other ranks).
     Returns (engine - the caller closes it, coo or None, Dist)."""
     from .capi import XCK_E_CAPACITY, XCK_F_FORCE_KEY128
     from .engine import XckError
@@ -461,8 +508,10 @@ def make_and_count(conf, mode, regions, snps=(), log_prefix="[engine]", **extra)
             raise failure
         try:
             coo = eng.finish(copy=False)
-            if dist.active:
-                coo = dist.gather(eng, conf.reg_list)
+            if gather is not None:
+                dist.sharded_output = dist.active and not gather
+            if dist.active and not dist.sharded_output:
+                coo = dist.gather(eng, conf.reg_list)              # rank 0: merged matrices; other ranks: None
         except BaseException:
             eng.close()
             raise

@@ -54,16 +54,18 @@ def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_lis
     try:
         if coo is None:
             return 0
-        n = len(regions)
-        rm = fcc.row_map_all(n) if rdr_output_all_reg else fcc.row_map_from_rows(n, coo["count"][0])
-        fcc.write_region_tsv(os.path.join(fc_dir, "features.tsv"), regions, rm)
-        eng.write_mtx_arrays(os.path.join(fc_dir, "matrix.mtx"), coo["count"], rm, int(rm.max()) if n else 0)
-        rm = fcc.row_map_all(n) if baf_output_all_reg else fcc.row_map_from_rows(n, coo["dp"][0], coo["oth"][0])
+        n = len(regions)                                  # (sharded output: every rank is here and the calls below are collective)
+        rm = fcc.output_row_map(dist, n, rdr_output_all_reg, coo["count"][0])
+        if fcc.is_writer_rank():
+            fcc.write_region_tsv(os.path.join(fc_dir, "features.tsv"), regions, rm)
+        fcc.write_mtx(eng, dist, os.path.join(fc_dir, "matrix.mtx"), coo["count"], rm, int(rm.max()) if n else 0)
+        rm = fcc.output_row_map(dist, n, baf_output_all_reg, coo["dp"][0], coo["oth"][0])
         nr = int(rm.max()) if n else 0
-        fcc.write_region_tsv(conf.out_region_fn, regions, rm)
-        eng.write_mtx_arrays(conf.out_ad_fn, coo["ad"], rm, nr)
-        eng.write_mtx_arrays(conf.out_dp_fn, coo["dp"], rm, nr)
-        eng.write_mtx_arrays(conf.out_oth_fn, coo["oth"], rm, nr)
+        if fcc.is_writer_rank():
+            fcc.write_region_tsv(conf.out_region_fn, regions, rm)
+        fcc.write_mtx(eng, dist, conf.out_ad_fn, coo["ad"], rm, nr)
+        fcc.write_mtx(eng, dist, conf.out_dp_fn, coo["dp"], rm, nr)
+        fcc.write_mtx(eng, dist, conf.out_oth_fn, coo["oth"], rm, nr)
     finally:
         eng.close()
     info("fused basefc + baf done in %.2fs" % (time.time() - t0))

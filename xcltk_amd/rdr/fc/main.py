@@ -164,13 +164,11 @@ def fc_core(conf):
     regions = conf.reg_list
     eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BASEFC, regions)
     try:
-        if coo is not None:                               # rank 0 (or the only process) writes
-            if conf.output_all_reg:
-                rm = fcc.row_map_all(len(regions))        # row = input line number
-            else:
-                rm = fcc.row_map_from_rows(len(regions), coo["count"][0])
-            fcc.write_region_tsv(conf.out_region_fn, regions, rm)
-            eng.write_mtx_arrays(conf.out_mtx_fn, coo["count"], rm, int(rm.max()) if len(rm) else 0)
+        if coo is not None:                               # the only process / rank 0 after a gather / every rank (sharded output)
+            rm = fcc.output_row_map(dist, len(regions), conf.output_all_reg, coo["count"][0])   # all_reg: row = input line number
+            if fcc.is_writer_rank():
+                fcc.write_region_tsv(conf.out_region_fn, regions, rm)
+            fcc.write_mtx(eng, dist, conf.out_mtx_fn, coo["count"], rm, int(rm.max()) if len(rm) else 0)
         if conf.debug > 0:
             info("engine stats: %s" % eng.stats())
     finally:
