@@ -539,7 +539,10 @@ void xck_bam_close(xck_bam* b) {
     if (!b) return;
     delete b->scanner; b->scanner = nullptr;
     for (auto& c : b->ch) c.tg.wait();
-    for (auto& so : b->soa) if (so.fence) fence_wait(so.fence);            // no H2D copy may still read a block that is parked or freed
+    // no H2D copy may still read a block that is parked or freed - and a parked block must not keep its event: the copy stream
+    // it was recorded on dies with the engine's staging, and waiting on such an event later fails (hipErrorStreamCaptureUnsupported
+    // on ROCm 7: the next reader's first launch check then reported that stale error; tests/test_gpu_random_e2e.py seed 9)
+    for (auto& so : b->soa) if (so.fence) { fence_wait(so.fence); fence_destroy(so.fence); so.fence = nullptr; }
     if (getenv("XCK_DEBUG_TIMING") && b->tm.chunks) {
         const DecodeTimes& t = b->tm; const double ms = 1e-6;
         fprintf(stderr, "[xck] ingest %s: %lld records, %llu chunks (%llu stitched serially), %.0f ms since open, %d threads | pool CPU ms: inflate %.0f walk %.0f parse %.0f | "

@@ -43,10 +43,16 @@ typedef unsigned __int128 u128;
 constexpr int WSS = XCK_WS_SNP;        // window shift of the SNP index (window -> first SNP)
 constexpr int JOIN_BLOCK = 256;
 
+// hipGetLastError() after a launch also returns (and clears) an error that some EARLIER, unchecked runtime call of this thread
+// left behind; the launch sites clear it first, and XCK_DEBUG_TIMING reports what was there.
+static inline void clear_stale_error(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] %s: cleared a stale HIP error left by an earlier call: %s [%d]\n", where, hipGetErrorString(e), (int)e);
+}
 #define HIP_TRY(expr)                                                                      \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                   \
-        char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr,              \
-                               hipGetErrorString(e_), __FILE__, __LINE__);                 \
+        char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s [%d] (%s:%d)", #expr,         \
+                               hipGetErrorString(e_), (int)e_, __FILE__, __LINE__);        \
         im->eng->err = b_; return XCK_E_DEVICE; } } while (0)
 
 
@@ -1698,6 +1704,7 @@ static int launch_join_t(EngineImpl* im) {
     a.keys = (K*)im->d_keys; a.vals = im->d_vals; a.cap = im->hit_cap; a.ctl = im->d_ctl;
     a.nkeys = (K*)im->d_nkeys; a.nvals = im->d_nvals;
     dim3 grid(tiles), block(JOIN_BLOCK);
+    clear_stale_error("launch_join");
     HIP_TRY(hipEventRecord(im->ev0, im->s_comp));
     const dim3 mgrid((tiles + 255) / 256), mblock(256);
     if (im->mode == XCK_MODE_BASEFC) {
@@ -2095,6 +2102,7 @@ static int pack_shards(EngineImpl* im, K* dst_keys, uint64_t* dst_vals) {
 
 template <class K>
 static int finish_t(EngineImpl* im) {
+    clear_stale_error("finish");
     KeyLayout<K> kl; kl.ubits = im->ubits; kl.cbits = im->cbits;
     const size_t n = im->cursor;
     for (int m = 0; m < 4; m++) { im->res_nnz[m] = 0; im->d_res[m] = nullptr; }
