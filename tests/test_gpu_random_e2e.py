@@ -20,7 +20,7 @@ def _cmp_dirs(a, b):
         assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
 
 
-_SEEDS = list(range(1, 9)) if not os.environ.get("XCK_E2E_SEEDS") else list(range(1, 1 + int(os.environ["XCK_E2E_SEEDS"])))   # bigger one-off sweeps
+_SEEDS = list(range(1, 13)) if not os.environ.get("XCK_E2E_SEEDS") else list(range(1, 1 + int(os.environ["XCK_E2E_SEEDS"])))   # bigger one-off sweeps
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
