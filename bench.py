@@ -26,7 +26,6 @@ Sub-records of the same JSON line:
                    contigs of the SAME BAM, and the GPU rows of those contigs compared with it bit for bit.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import subprocess

@@ -17,14 +17,12 @@ Output (`<out_dir>/raw` = every candidate SNP with at least one counted UMI, `<o
 cellSNP.base.vcf.gz (bgzip; INFO = AD=..;DP=..;OTH=..), cellSNP.samples.tsv, cellSNP.tag.{AD,DP,OTH}.mtx (SNP x cell).
 """
 import os
-from logging import error, info
-from logging import warning as warn
+from logging import info
 
 import numpy as np
 
 from .. import fc_common as fcc
 from ..capi import XCK_MODE_BAF
-from ..engine import Engine, XckError
 from ..utils.grange import format_chrom
 from ..utils.zfile import ZF_F_BGZIP, zopen
 

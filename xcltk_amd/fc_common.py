@@ -15,7 +15,7 @@ from logging import warning as warn
 
 import numpy as np
 
-from .capi import XCK_MODE_BAF, XCK_MODE_BASEFC
+from .capi import XCK_MODE_BASEFC
 from .engine import Engine
 from .snptable import SnpTable
 from .utils.grange import format_chrom

@@ -8,7 +8,6 @@ the separate commands write: <out_dir>/basefc/{features.tsv,barcodes.tsv,matrix.
 <out_dir>/baf/xcltk.{region.tsv,samples.tsv,AD.mtx,DP.mtx,OTH.mtx}.
 """
 import os
-import sys
 import time
 from logging import error, info
 
@@ -16,7 +15,6 @@ from . import fc_common as fcc
 from .baf.fc.config import Config as BafConfig
 from .baf.fc.main import prepare_config as baf_prepare
 from .capi import XCK_MODE_BOTH
-from .engine import Engine
 
 
 def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_list_fn=None,
