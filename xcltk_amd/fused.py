@@ -15,6 +15,7 @@ from . import fc_common as fcc
 from .baf.fc.config import Config as BafConfig
 from .baf.fc.main import prepare_config as baf_prepare
 from .capi import XCK_MODE_BOTH
+from .engine import XckError
 
 
 def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_list_fn=None,
@@ -47,8 +48,12 @@ def fused_wrapper(sam_fn, barcode_fn, region_fn, phased_snp_fn, out_dir, sam_lis
     if fcc.is_writer_rank():
         fcc.write_samples(os.path.join(fc_dir, "barcodes.tsv"), conf.samples)
     conf.min_include = min_include
-    eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BOTH, regions, snps, log_prefix="[fused]", min_include=min_include,
-                                        min_count=min_count, min_maf=min_maf, no_dup_hap=no_dup_hap)
+    try:
+        eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BOTH, regions, snps, log_prefix="[fused]", min_include=min_include,
+                                            min_count=min_count, min_maf=min_maf, no_dup_hap=no_dup_hap)
+    except XckError as e:                                # truncated / non-BAM input, no GPU, ...: logged, -1 like the reference's errors
+        error(str(e))
+        return -1
     try:
         if coo is None:
             return 0
