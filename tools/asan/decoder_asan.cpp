@@ -21,6 +21,7 @@ int  engine_result_device(xck_engine*, xck_result*) { return XCK_E_ARG; }
 int  engine_reset(xck_engine*) { return XCK_E_ARG; }
 int  engine_stats(const xck_engine*, xck_stats*) { return XCK_E_ARG; }
 int  engine_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }
+int  engine_numa_node(const xck_engine*) { return -1; }
 int  engine_push_block(xck_engine*, const void*, size_t, const xck_batch*, int, void**) { return XCK_E_ARG; }
 void engine_release_staging(xck_engine*) {}
 void fence_wait(void*) {}

@@ -204,6 +204,7 @@ public:
     ~Pool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
     void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); } cv_.notify_one(); }
     int size() const { return (int)th_.size(); }
+    void set_affinity(const cpu_set_t& set) { for (auto& t : th_) pthread_setaffinity_np(t.native_handle(), sizeof set, &set); }
 private:
     void run() {
         for (;;) {
@@ -425,6 +426,7 @@ struct xck_bam {
     int64_t n_records = 0;             // records walked so far (all, including unused contigs)
     bool done = false;
     size_t chunk_target = 48u << 20;   // uncompressed bytes per chunk
+    bool affinity_changed = false; cpu_set_t old_affinity;   // NUMA binding of the calling thread (restored at close)
     DecodeTimes tm;
     std::string err;
 };
@@ -543,6 +545,7 @@ void xck_bam_close(xck_bam* b) {
     // it was recorded on dies with the engine's staging, and waiting on such an event later fails (hipErrorStreamCaptureUnsupported
     // on ROCm 7: the next reader's first launch check then reported that stale error; tests/test_gpu_random_e2e.py seed 9)
     for (auto& so : b->soa) if (so.fence) { fence_wait(so.fence); fence_destroy(so.fence); so.fence = nullptr; }
+    if (b->affinity_changed) { pthread_setaffinity_np(pthread_self(), sizeof b->old_affinity, &b->old_affinity); b->affinity_changed = false; }
     if (getenv("XCK_DEBUG_TIMING") && b->tm.chunks) {
         const DecodeTimes& t = b->tm; const double ms = 1e-6;
         fprintf(stderr, "[xck] ingest %s: %lld records, %llu chunks (%llu stitched serially), %.0f ms since open, %d threads | pool CPU ms: inflate %.0f walk %.0f parse %.0f | "
@@ -691,6 +694,50 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMa
     }
 }
 
+// ---- NUMA: the decoder stays on ONE socket ---------------------------------------------------------------------------
+// A GPU box has two sockets behind a CPU-time quota; left alone, the scheduler spreads the pool over both and every chunk's
+// inflated bytes, records and SoA block cross the socket link: 35 M reads/s unpinned against 40.5-41.8 M with the process held
+// on either socket (24 threads, same box, same call: profiles/r02_v_numa_affinity.log).  At the first decode call the pool, the
+// scanner and the calling thread (whose first touch places the inflate buffers) are bound to the CPUs of the GPU's NUMA node
+// (decode-only handle: the node the caller runs on); the caller's mask is restored by xck_bam_close.  XCK_NUMA=0 turns it off.
+static bool read_cpulist(const char* path, cpu_set_t* out) {
+    FILE* f = fopen(path, "r"); if (!f) return false;
+    char buf[4096]; const size_t n = fread(buf, 1, sizeof buf - 1, f); fclose(f); buf[n] = 0;
+    CPU_ZERO(out); int any = 0;
+    for (char* p = buf; *p;) {
+        while (*p == ',' || *p == ' ' || *p == '\n') p++;
+        if (!*p) break;
+        char* q; long a = strtol(p, &q, 10); if (q == p) break; long z = a; p = q;
+        if (*p == '-') { p++; z = strtol(p, &q, 10); if (q == p) break; p = q; }
+        for (long c = a; c <= z && c < CPU_SETSIZE; c++) { CPU_SET((int)c, out); any = 1; }
+    }
+    return any != 0;
+}
+static int node_of_cpu(int cpu, cpu_set_t* node_set) {
+    for (int node = 0; node < 64; node++) {
+        char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        cpu_set_t s; if (!read_cpulist(path, &s)) { if (node > 8) break; continue; }
+        if (cpu >= 0 && CPU_ISSET(cpu, &s)) { *node_set = s; return node; }
+    }
+    return -1;
+}
+static void bind_to_numa_node(xck_engine* e, xck_bam* b) {
+    if (const char* v = getenv("XCK_NUMA")) if (atoi(v) == 0) return;
+    if (!b->pool || b->n_threads < 2) return;
+    cpu_set_t node_set; CPU_ZERO(&node_set);
+    int node = e && e->n_impl > 0 ? xck::engine_numa_node(e) : -1;
+    if (node >= 0) { char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node); if (!read_cpulist(path, &node_set)) node = -1; }
+    if (node < 0) node = node_of_cpu(sched_getcpu(), &node_set);
+    if (node < 0) return;
+    cpu_set_t cur; CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof cur, &cur) != 0) return;
+    cpu_set_t both; CPU_AND(&both, &cur, &node_set);
+    if (CPU_COUNT(&both) < 2 || CPU_COUNT(&both) == CPU_COUNT(&cur)) return;     // not allowed there, or there is only this node
+    if (pthread_setaffinity_np(pthread_self(), sizeof both, &both) != 0) return;
+    b->old_affinity = cur; b->affinity_changed = true;
+    b->pool->set_affinity(both);
+}
+
 // locate a 2-character aux tag; returns pointer to the type byte or nullptr
 static inline const uint8_t* aux_skip(const uint8_t* p, const uint8_t* e) {       // p at type byte; returns next tag or nullptr
     if (p >= e) return nullptr;
@@ -815,6 +862,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads)
         if (!e->dec.use_barcodes && !e->dec.use_umi) e->intern.clear();
         set_ranges(b, o);
+        bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
         std::vector<ScanRange> rg;
         if (b->use_ranges) for (auto& r : b->ranges) rg.push_back({r.first >> 16, (uint32_t)(r.first & 0xffff), r.second >> 16});
         else rg.push_back({b->next_coff, b->first_skip, ~0ull});

@@ -2330,6 +2330,17 @@ int engine_stats(const xck_engine* e, xck_stats* out) {
     return 0;
 }
 
+int engine_numa_node(const xck_engine* e) {
+    const EngineImpl* im = e && e->n_impl > 0 ? (const EngineImpl*)e->impls[0] : nullptr;
+    if (!im) return -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, im->device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    char path[160]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r"); if (!f) return -1;
+    int node = -1; if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f);
+    return node;
+}
 int engine_umi_bits(const xck_engine* e) { const EngineImpl* im = (const EngineImpl*)e->impl; return im ? im->ubits : 0; }
 
 int engine_create(const xck_config* cfg, xck_engine* e) {

@@ -119,6 +119,7 @@ int  engine_result_device(xck_engine* e, xck_result* out);
 int  engine_reset(xck_engine* e);
 int  engine_stats(const xck_engine* e, xck_stats* out);
 int  engine_umi_bits(const xck_engine* e);
+int  engine_numa_node(const xck_engine* e);   // NUMA node of the handle's GPU (sysfs, by PCI bus id); -1 = unknown
 // One decoded chunk (all SoA columns in one pinned host block of `bytes` bytes at host_base; the batches point into it): ONE
 // asynchronous H2D copy into a device staging slot shared by the handle's pipelines, then the join kernel(s) on the batches.
 // *fence (created on first use) is recorded behind the copy: fence_wait() before the host block is overwritten.
