@@ -29,7 +29,7 @@ for i in range(n_bams):
     fn = work + "/cell_%03d_%d.bam" % (i, per)
     if not os.path.isfile(fn):
         subprocess.check_call([os.path.join(ROOT, "xcltk_amd", "csrc", "xck_synth_bam"), fn, work + "/contigs.tsv", work + "/regions.tsv",
-                               work + "/barcodes.tsv", str(per), str(100 + i), str(threads), "6"], env=env)
+                               work + "/barcodes.tsv", str(per), str(100 + i), str(threads), os.environ.get("XCK_E2E_LEVEL", "6")], env=env)
     bams.append(fn)
 with open(work + "/bams.txt", "w") as fp:
     fp.write("".join(b + "\n" for b in bams))
