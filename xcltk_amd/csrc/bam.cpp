@@ -152,14 +152,11 @@ void InternTable::clear() {
 static bool encode_key_direct(const char* s, size_t n, int umi_bits, uint64_t* out) {
     if (n == 0) { *out = XCK_UMI_NONE; return true; }
     if (2 * (int)n + 1 <= umi_bits - 1) {
-        uint64_t v = 1; bool ok = true;
-        for (size_t i = 0; i < n; i++) {
-            uint64_t c;
-            switch (s[i]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = 4; }
-            if (c > 3) { ok = false; break; }
-            v = (v << 2) | c;
-        }
-        if (ok) { *out = v; return true; }
+        // A C G T -> 0 1 2 3, anything else 4: one table look-up per character, no branch inside the loop
+        static const struct Lut { uint8_t t[256]; Lut() { memset(t, 4, sizeof t); t[(uint8_t)'A'] = 0; t[(uint8_t)'C'] = 1; t[(uint8_t)'G'] = 2; t[(uint8_t)'T'] = 3; } } lut;
+        uint64_t v = 1; unsigned bad = 0;
+        for (size_t i = 0; i < n; i++) { const unsigned c = lut.t[(uint8_t)s[i]]; bad |= c; v = (v << 2) | (c & 3u); }
+        if (!(bad & 4u)) { *out = v; return true; }
     }
     return false;
 }
@@ -173,23 +170,35 @@ uint64_t encode_key(const char* s, size_t n, int umi_bits, InternTable& tab, boo
     return (1ull << (umi_bits - 1)) | id;
 }
 
+// Barcode -> column: open addressing over slots that hold the full 64-bit hash, the column and the barcode's own bytes (up to
+// 18, the length of a 10x barcode), so a hit costs ONE cache line and still compares the exact string; longer barcodes compare against
+// the string list.  (Slots -> std::string -> heap was three dependent misses per read.)
 void DecodeCfg::build_barcodes(const char* const* names, int n) {
     barcodes.clear();
     for (int i = 0; i < n; i++) barcodes.emplace_back(names[i]);
     size_t cap = 16; while (cap < (size_t)n * 2) cap <<= 1;
-    bc_slots.assign(cap, -1); bc_mask = cap - 1;
+    BcSlot empty; memset(&empty, 0, sizeof empty); empty.idx = -1;
+    bc_slots.assign(cap, empty); bc_mask = cap - 1;
     for (int i = 0; i < n; i++) {
-        uint64_t h = hash_bytes(barcodes[i].data(), barcodes[i].size()) & bc_mask;
-        while (bc_slots[h] >= 0) h = (h + 1) & bc_mask;
-        bc_slots[h] = i;
+        const std::string& b = barcodes[i];
+        const uint64_t hh = hash_bytes(b.data(), b.size());
+        uint64_t h = hh & bc_mask;
+        while (bc_slots[h].idx >= 0) h = (h + 1) & bc_mask;
+        BcSlot& sl = bc_slots[h];
+        sl.h = hh; sl.idx = i; sl.len = (uint16_t)std::min<size_t>(b.size(), 0xFFFF);
+        memcpy(sl.key, b.data(), std::min<size_t>(b.size(), sizeof sl.key));
     }
 }
 int32_t DecodeCfg::lookup_cell(const char* s, size_t n) const {
     if (bc_slots.empty()) return -1;
-    uint64_t h = hash_bytes(s, n) & bc_mask;
-    while (bc_slots[h] >= 0) {
-        const std::string& b = barcodes[bc_slots[h]];
-        if (b.size() == n && memcmp(b.data(), s, n) == 0) return bc_slots[h];
+    const uint64_t hh = hash_bytes(s, n);
+    uint64_t h = hh & bc_mask;
+    while (bc_slots[h].idx >= 0) {
+        const BcSlot& sl = bc_slots[h];
+        if (sl.h == hh && sl.len == (n > 0xFFFF ? 0xFFFF : (uint16_t)n)) {
+            if (n <= sizeof sl.key) { if (memcmp(sl.key, s, n) == 0) return sl.idx; }
+            else { const std::string& b = barcodes[sl.idx]; if (b.size() == n && memcmp(b.data(), s, n) == 0) return sl.idx; }
+        }
         h = (h + 1) & bc_mask;
     }
     return -1;
@@ -746,7 +755,7 @@ static inline const uint8_t* aux_skip(const uint8_t* p, const uint8_t* e) {     
         case 'A': case 'c': case 'C': p += 1; break;
         case 's': case 'S': p += 2; break;
         case 'i': case 'I': case 'f': p += 4; break;
-        case 'Z': case 'H': while (p < e && *p) p++; p++; break;
+        case 'Z': case 'H': { const void* z = memchr(p, 0, (size_t)(e - p)); if (!z) return nullptr; p = (const uint8_t*)z + 1; break; }
         case 'B': { if (p + 5 > e) return nullptr; uint8_t st = *p; uint32_t n = le32(p + 1); p += 5;
                     size_t sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; p += (size_t)n * sz; break; }
         default: return nullptr;

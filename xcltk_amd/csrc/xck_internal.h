@@ -55,8 +55,9 @@ struct DecodeCfg {
     int  n_threads = 0;
     int64_t max_batch_reads = 0;
     // barcode hash (open addressing over the barcode strings)
+    struct BcSlot { uint64_t h; int32_t idx; uint16_t len; char key[18]; };   // 32 bytes: hash, column (-1 = empty), the barcode itself
     std::vector<std::string> barcodes;
-    std::vector<int32_t> bc_slots;       // size pow2, -1 empty
+    std::vector<BcSlot> bc_slots;        // size pow2
     uint64_t bc_mask = 0;
     int32_t lookup_cell(const char* s, size_t n) const;
     void build_barcodes(const char* const* names, int n);
