@@ -303,7 +303,7 @@ def main():
     cfg_name = {(500_000_000, 10000, 1_000_000): "configs[2]", (50_000_000, 5000, 100_000): "configs[1]"}.get((args.reads, args.cells, args.snps), "configs[2] shape at a custom size")
     line = dict(metric="reads/sec into AD/DP+basefc matrices", value=round(value, 1), unit="reads/s",
                 n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3),
-                higher_is_better=True, scaling="strong" if world > 1 else "weak", vs_baseline=None, dtype="int64", data="synthetic",
+                higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int64", data="synthetic",
                 config=dict(workload="BASELINE.json %s: ONE synthetic 10x BAM of %d records (%.1f GB BGZF, page cache), %d barcodes, %d het SNPs, %d genes, "
                                      "24 hg38 contigs; end to end BAM -> basefc matrix.mtx + AD/DP/OTH.mtx from one decode; a step = 1/%d of the file's records, "
                                      "the last step also folds and writes" % (cfg_name, n_total, bam_bytes / 1e9, len(bcs), len(snps), len(regions), n_slices),

@@ -37,6 +37,7 @@ def test_bench_line_and_two_rank_outputs(tmp_path):
     d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-sample", "400000", "--resident-passes", "1"] + SIZE, env)
     assert d["metric"] == "reads/sec into AD/DP+basefc matrices" and d["unit"] == "reads/s" and d["n_gpus"] == 1
     assert d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "strong"                               # the same file at every N: total work fixed
     assert d["dtype"] == "int64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["steps"] / 1e3 - d["end_to_end"]["seconds"]) < 0.01
     assert d["end_to_end"]["records_decoded"] == 3000000 and d["end_to_end"]["records_timed"] < 3000000   # the warm-up slice is not counted
