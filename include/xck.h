@@ -207,6 +207,9 @@ int  xck_reset(xck_engine* e);
 int  xck_get_stats(const xck_engine* e, xck_stats* out);
 
 /* -- host ingest (replaces pysam.AlignmentFile + fetch(): own BGZF/BAM reader) --------------- */
+/* n_threads = 0: the process's CPU share (affinity and cgroup quota; 1.5 threads per CPU behind a quota).  BAM only: CRAM / SAM text
+ * are named in `err`.  On a multi-socket host the reader binds its threads - and, from the first xck_ingest_bam / xck_bam_next_batch
+ * call until xck_bam_close, the CALLING thread - to the NUMA node of the engine's GPU (XCK_NUMA=0 in the environment turns that off). */
 int  xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size_t errlen);
 void xck_bam_close(xck_bam* b);
 int  xck_bam_n_refs(const xck_bam* b);
