@@ -233,15 +233,34 @@ def ds_phasing(d):
     with open(os.path.join(d, "ref_cells.tsv"), "w") as fp:
         fp.write("".join(c + "\n" for c in ref_cells))
     # the pileup directory in cellsnp-lite's layout (SNP x cell .mtx, 1-based, coordinate integer general)
-    with gzip.open(os.path.join(d, "cellsnp", "cellSNP.base.vcf.gz"), "wt") as fp:
-        fp.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
-        for j, p in enumerate(snp_pos):
-            fp.write("chr1\t%d\t.\t%s\t%s\t.\tPASS\tAD=%d;DP=%d;OTH=%d\n" % (p, ref[j], alt[j], AD[j].sum(), DP[j].sum(), OTH[j].sum()))
+    def write_vcf_gz(path, lines):                                # (mtime 0: the same bytes on every run)
+        import io
+        with open(path, "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as gz:
+            gz.write(("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n" + "".join(lines)).encode())
+    write_vcf_gz(os.path.join(d, "cellsnp", "cellSNP.base.vcf.gz"),
+                 ["chr1\t%d\t.\t%s\t%s\t.\tPASS\tAD=%d;DP=%d;OTH=%d\n" % (p, ref[j], alt[j], AD[j].sum(), DP[j].sum(), OTH[j].sum()) for j, p in enumerate(snp_pos)])
     with open(os.path.join(d, "cellsnp", "cellSNP.samples.tsv"), "w") as fp:
         fp.write("".join(c + "\n" for c in cells))
     for name, M in (("AD", AD), ("DP", DP), ("OTH", OTH)):
         rr, cc = np.nonzero(M)
         with open(os.path.join(d, "cellsnp", "cellSNP.tag.%s.mtx" % name), "w") as fp:
+            fp.write("%%%%MatrixMarket matrix coordinate integer general\n%%\n%d\t%d\t%d\n" % (n_snp, n_cell, len(rr)))
+            fp.write("".join("%d\t%d\t%d\n" % (r + 1, c + 1, M[r, c]) for r, c in zip(rr, cc)))
+    # a pileup without one SNP of region long_c (and with one SNP outside every region, so that it still lists at least as many
+    # SNPs as the phased list: baf/fc/main.py:431 asserts that): a region with FEWER pileup columns than phased SNPs does not
+    # stop the reference - zip() pairs the columns with the first SNPs of the list and drops the rest of the list from that
+    # region (baf/fc/phasing.py:47)
+    os.makedirs(os.path.join(d, "cellsnp_short"), exist_ok=True)
+    drop = [j for j, p in enumerate(snp_pos) if 715000 <= p <= 875000][4]
+    keep_j = [j for j in range(n_snp) if j != drop]
+    write_vcf_gz(os.path.join(d, "cellsnp_short", "cellSNP.base.vcf.gz"),
+                 ["chr1\t%d\t.\t%s\t%s\t.\tPASS\tAD=%d;DP=%d;OTH=%d\n" % (snp_pos[j], ref[j], alt[j], AD[j].sum(), DP[j].sum(), OTH[j].sum()) for j in keep_j]
+                 + ["chr1\t895000\t.\tA\tC\t.\tPASS\tAD=0;DP=0;OTH=0\n"])
+    with open(os.path.join(d, "cellsnp_short", "cellSNP.samples.tsv"), "w") as fp:
+        fp.write("".join(c + "\n" for c in cells))
+    for name, M in (("AD", AD[keep_j]), ("DP", DP[keep_j]), ("OTH", OTH[keep_j])):
+        rr, cc = np.nonzero(M)
+        with open(os.path.join(d, "cellsnp_short", "cellSNP.tag.%s.mtx" % name), "w") as fp:
             fp.write("%%%%MatrixMarket matrix coordinate integer general\n%%\n%d\t%d\t%d\n" % (n_snp, n_cell, len(rr)))
             fp.write("".join("%d\t%d\t%d\n" % (r + 1, c + 1, M[r, c]) for r, c in zip(rr, cc)))
     return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
@@ -307,6 +326,7 @@ CASES = [
     baf("phasing", "phasing_baf_refcells", cellsnp_dir="$D/cellsnp", ref_cell_fn="$D/ref_cells.tsv", **_baf10x("phasing")),
     baf("phasing", "phasing_baf_allreg", cellsnp_dir="$D/cellsnp", output_all_reg=True, no_dup_hap=False, **_baf10x("phasing")),
     baf("phasing", "phasing_baf_off", output_all_reg=True, **_baf10x("phasing")),
+    baf("phasing", "phasing_baf_short_pileup", cellsnp_dir="$D/cellsnp_short", output_all_reg=True, **_baf10x("phasing")),
 ]
 
 
@@ -326,7 +346,7 @@ def main():
         if os.path.isdir(d):
             shutil.rmtree(d)
         info = fn(d)
-        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv", "cellsnp", "ref_cells.tsv"}
+        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv", "cellsnp", "cellsnp_short", "ref_cells.tsv"}
         keep_only(d, keep)
         info["md5"] = {os.path.relpath(os.path.join(dp, f), d): md5(os.path.join(dp, f)) for dp, _, fs in sorted(os.walk(d)) for f in sorted(fs)}
         meta[name] = info

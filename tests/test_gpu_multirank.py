@@ -52,3 +52,15 @@ def test_ranks_match_reference(name, backend, world, exchange, tmp_path):
             fp.write(r.stdout)
     tb = [ln for ln in r.stdout.splitlines() if "Error" in ln or "error" in ln or "File \"/" in ln]
     assert "MULTIRANK_OK " + name in r.stdout, "\n".join(tb[-40:])
+
+
+def test_pipeline_pileup_then_counting_two_ranks(tmp_path):
+    """`xcltk baf --snpvcf ... --phasedSNP ...` on two ranks (gloo, shared GPU): rank 0 writes the pileup directory of step 1, both
+    ranks read it in step 3 - after waiting for the writer (xcltk_amd/baf/genotype.py pileup(): status all-reduce)."""
+    env = dict(os.environ, XCK_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", XCK_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(),
+                        os.path.join(ROOT, "tests", "dist_worker.py"), "pipeline_steps_1_3", str(tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    tb = [ln for ln in r.stdout.splitlines() if "Error" in ln or "error" in ln or "File \"/" in ln]
+    assert "MULTIRANK_OK pipeline_steps_1_3" in r.stdout, "\n".join(tb[-40:])

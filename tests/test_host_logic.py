@@ -239,36 +239,6 @@ def test_lpt_assign_balances():
     assert set(contig_owner(["a"] * 24, HG38_LENGTHS, 8).tolist()) == set(range(8))
 
 
-_GLOO_WORKER = r'''
-import os, sys
-sys.path.insert(0, sys.argv[1])
-import numpy as np, torch, torch.distributed as dist
-from xcltk_amd.shard import gather_coo
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-rng = np.random.default_rng(5)
-row = np.sort(rng.integers(0, 1000, 500)).astype(np.int32); col = rng.integers(0, 50, 500).astype(np.int32)
-key = np.unique(row.astype(np.int64) * 100 + col); row = (key // 100).astype(np.int32); col = (key % 100).astype(np.int32)
-val = (row * 7 + col + 1).astype(np.int32)
-mine = (row % world) == rank                       # ranks own disjoint rows
-got = gather_coo((row[mine], col[mine], val[mine]), world)
-empty = gather_coo((row[:0], col[:0], val[:0]), world)
-ok = np.array_equal(got[0], row) and np.array_equal(got[1], col) and np.array_equal(got[2], val) and len(empty[0]) == 0
-print("RANK%d %s" % (rank, "OK" if ok else "BAD"))
-dist.destroy_process_group()
-'''
-
-
-def test_gather_coo_gloo_world2(tmp_path):
-    script = tmp_path / "w.py"
-    script.write_text(_GLOO_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script), ROOT],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
-    assert "RANK0 OK" in r.stdout and "RANK1 OK" in r.stdout, r.stdout[-2000:]
-
-
 _SHARDED_WRITER_WORKER = r"""
 import os, sys, ctypes as C
 import numpy as np

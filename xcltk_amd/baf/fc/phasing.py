@@ -72,10 +72,16 @@ def local_phasing(regions, snps, csp, ref_cells=None, debug_level=0):
             continue
         cols = np.flatnonzero((c_chrom == ch) & (csp.pos >= start) & (csp.pos < end + 1))
         AD, DP = AD_all[:, cols].toarray(), DP_all[:, cols].toarray()
-        if AD.shape[1] != len(lst):
-            # the reference pairs the pileup's columns with the region's SNP list by position in the list and asserts
-            # equal lengths afterwards (baf/fc/phasing.py:47,68): a pileup that does not hold exactly the phased SNPs fails
+        if AD.shape[1] > len(lst):
+            # more pileup columns than phased SNPs in the region: the reference pairs columns and SNPs by position in the list
+            # (baf/fc/phasing.py:47) and then fails on the mismatched shapes (:51-52)
             raise ValueError("region '%s': %d SNPs in the phased list but %d in the cellsnp pileup" % (name, len(lst), AD.shape[1]))
+        if AD.shape[1] < len(lst):
+            # fewer columns: zip() pairs them with the FIRST SNPs of the list and the rest of the list leaves this region
+            # (baf/fc/phasing.py:47; golden case phasing_baf_short_pileup)
+            for j in lst[AD.shape[1]:].tolist():
+                excl_region.append(g); excl_snp.append(j)
+            lst = lst[:AD.shape[1]]
         kept, flip = reg_local_phasing(ref_hap[lst], AD, DP, s_pos[lst])
         for j in lst[~kept].tolist():                                   # dropped from THIS region's list, whatever the phasing says
             excl_region.append(g); excl_snp.append(j)

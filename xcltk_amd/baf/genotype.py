@@ -128,8 +128,25 @@ def pileup(sam_fn=None, sam_list_fn=None, barcode_fn=None, sample_id_fn=None, sa
             coo = {k: tuple(np.array(a) for a in v) for k, v in coo.items()}
     finally:
         eng.close()
-    if coo is None:                                               # non-writer rank of a multi-GPU run
-        return None, 0, 0
+    # Multi-GPU: only rank 0 holds the gathered matrices and writes the directory; every other rank WAITS for it (step 3 of
+    # the pipeline reads this directory on every rank) and learns whether the writer failed, so that all ranks leave together.
+    result, failure = (None, 0, 0), None
+    if coo is not None:
+        try:
+            result = _write_pileup_dirs(out_dir, cand, conf.samples, coo, min_count, min_maf)
+        except (ValueError, IOError, OSError) as e:
+            failure = e
+    if dist.active:
+        failed = int(dist.all_reduce_np(np.array([int(failure is not None)], dtype=np.int64), op="max")[0])   # also the barrier
+        if failed and failure is None:
+            failure = ValueError("the pileup directory could not be written on rank 0")
+    if failure is not None:
+        raise failure
+    return result
+
+
+def _write_pileup_dirs(out_dir, cand, samples, coo, min_count, min_maf):
+    """raw/ (every covered SNP) and the filtered directory, from the gathered AD / DP / OTH matrices (writer rank)."""
     raw_dir = os.path.join(out_dir, "raw")
     covered = np.zeros(len(cand), dtype=bool)
     covered[coo["dp"][0]] = True
@@ -138,6 +155,5 @@ def pileup(sam_fn=None, sam_list_fn=None, barcode_fn=None, sample_id_fn=None, sa
     remap = np.full(len(cand), -1, dtype=np.int64)
     remap[idx] = np.arange(len(idx))
     mats = {k: (remap[np.asarray(coo[m][0], dtype=np.int64)], coo[m][1], coo[m][2]) for k, m in (("AD", "ad"), ("DP", "dp"), ("OTH", "oth"))}
-    write_cellsnp_dir(raw_dir, [cand[i] for i in idx.tolist()], conf.samples, mats)
-    out_vcf, p_raw, p_new = filter_snps(raw_dir, out_dir, min_count, min_maf)
-    return out_vcf, p_raw, p_new
+    write_cellsnp_dir(raw_dir, [cand[i] for i in idx.tolist()], samples, mats)
+    return filter_snps(raw_dir, out_dir, min_count, min_maf)

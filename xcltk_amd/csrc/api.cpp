@@ -3,6 +3,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -80,6 +81,10 @@ int xck_create(const xck_config* cfg_in, xck_engine** out) {
 
 void xck_destroy(xck_engine* e) {
     if (!e) return;
+    for (int k = 0; k < 3; k++) {                                        // staging ring of xck_push_batch
+        if (e->push_ring.fence[k]) { fence_wait(e->push_ring.fence[k]); fence_destroy(e->push_ring.fence[k]); }
+        if (e->push_ring.blk[k]) pinned_free(e->push_ring.blk[k]);
+    }
     for (int k = 0; k < e->n_impl; k++) { e->impl = e->impls[k]; engine_destroy(e); }
     if (e->stager) engine_release_staging(e);
     delete e;
@@ -104,10 +109,78 @@ static int check_host_batch(xck_engine* e, const xck_batch* b) {
     return XCK_OK;
 }
 extern "C++" { namespace xck { int push_trusted(xck_engine* e, const xck_batch* b) { FOR_IMPLS(e, engine_push(e, b, false)); return XCK_OK; } } }
+
+// xck_push_batch, one-copy form: the caller's nine arrays are packed into ONE engine-owned pinned block (ring of three), which
+// crosses PCIe with ONE hipMemcpyAsync into a device staging slot shared by the handle's pipelines (engine_push_block - the path
+// the BAM decoder uses).  The call returns as soon as the arrays are packed: the caller may reuse them, and the DMA of this
+// batch overlaps the packing of the next one (the block's fence, an event, is waited for only when the ring comes round).
+// Large batches are packed by a few threads.  Arrays that ARE pinned (hipHostMalloc / hipHostRegister) keep the direct form
+// (engine_push: DMA straight from the caller's memory, no host copy) unless XCK_PUSH_STAGE=1.
+static bool caller_arrays_pinned(const xck_batch* b, bool seq) {
+    const void* cols[] = { b->pos, b->flag, b->mapq, b->cell, b->umi, b->cig_off, b->cigar, seq ? b->seq_off : nullptr, seq ? b->seq : nullptr };
+    for (const void* p : cols) {
+        if (!p) continue;
+        hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // plain pageable memory
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+static int push_staged(xck_engine* e, const xck_batch* b) {
+    if (e->n_impl <= 0) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
+    const bool seq = (e->mode & XCK_MODE_BAF) != 0;
+    const size_t n = (size_t)b->n_reads;
+    const uint32_t c_lo = b->cig_off[0], s_lo = seq ? b->seq_off[0] : 0;
+    const size_t n_cig = b->cig_off[n] - c_lo, n_seq = seq ? b->seq_off[n] - s_lo : 0;
+    struct Seg { const void* src; size_t bytes, off; } seg[9] = {
+        { b->pos, n * 4, 0 }, { b->flag, n * 2, 0 }, { b->mapq, n, 0 }, { b->cell, n * 4, 0 }, { b->umi, n * 8, 0 }, { b->cig_off, (n + 1) * 4, 0 },
+        { b->cigar ? b->cigar + c_lo : nullptr, n_cig * 4, 0 }, { seq ? b->seq_off : nullptr, seq ? (n + 1) * 4 : 0, 0 }, { seq && b->seq ? b->seq + s_lo : nullptr, n_seq, 0 } };
+    size_t total = 0;
+    for (auto& g : seg) { g.off = total; total += (g.bytes + 255) & ~size_t(255); }
+    xck_engine::PushRing& ring = e->push_ring;
+    const int k = ring.next; ring.next = (ring.next + 1) % 3;
+    if (ring.fence[k]) fence_wait(ring.fence[k]);                        // the DMA that last read this block
+    if (total > ring.cap[k]) {
+        if (ring.blk[k]) pinned_free(ring.blk[k]);
+        ring.cap[k] = 0;
+        const size_t c = total + total / 4 + (1 << 16);
+        ring.blk[k] = pinned_alloc(c);
+        if (!ring.blk[k]) { e->err = "out of pinned host memory (xck_push_batch staging)"; return XCK_E_NOMEM; }
+        ring.cap[k] = c;
+    }
+    char* base = (char*)ring.blk[k];
+    // pack: the byte range [0, total) of the block is cut into equal parts, one per thread
+    auto pack = [&](size_t lo, size_t hi) {
+        for (const auto& g : seg) {
+            if (!g.bytes || !g.src) continue;
+            const size_t a = std::max(lo, g.off), z = std::min(hi, g.off + g.bytes);
+            if (a < z) memcpy(base + a, (const char*)g.src + (a - g.off), z - a);
+        }
+    };
+    const int nt = total < (size_t(4) << 20) ? 1 : std::min(4, std::max(1, default_threads()));
+    if (nt == 1) pack(0, total);
+    else {
+        std::vector<std::thread> th;
+        const size_t step = ((total + nt - 1) / nt + 63) & ~size_t(63);
+        for (int t = 1; t < nt; t++) th.emplace_back(pack, std::min(total, step * t), std::min(total, step * (t + 1)));
+        pack(0, std::min(total, step));
+        for (auto& t : th) t.join();
+    }
+    xck_batch sb = *b;
+    sb.pos = (const int32_t*)(base + seg[0].off); sb.flag = (const uint16_t*)(base + seg[1].off); sb.mapq = (const uint8_t*)(base + seg[2].off);
+    sb.cell = (const int32_t*)(base + seg[3].off); sb.umi = (const uint64_t*)(base + seg[4].off); sb.cig_off = (const uint32_t*)(base + seg[5].off);
+    sb.cigar = (const uint32_t*)(base + seg[6].off) - c_lo;               // rebased: never read below c_lo
+    sb.seq_off = seq ? (const uint32_t*)(base + seg[7].off) : nullptr;
+    sb.seq = seq ? (const uint8_t*)(base + seg[8].off) - s_lo : nullptr;
+    return engine_push_block(e, base, total, &sb, 1, &ring.fence[k]);
+}
 int xck_push_batch(xck_engine* e, const xck_batch* b) {
     if (!e || !b) return XCK_E_ARG;
     if (int rc = check_host_batch(e, b)) return rc;
-    return push_trusted(e, b);
+    if (b->n_reads <= 0 || b->contig < 0 || e->n_impl <= 0) return push_trusted(e, b);     // nothing to copy / decode-only: engine_push reports
+    static const int force = getenv("XCK_PUSH_STAGE") ? atoi(getenv("XCK_PUSH_STAGE")) : -1;
+    const bool stage = force >= 0 ? force != 0 : !caller_arrays_pinned(b, (e->mode & XCK_MODE_BAF) != 0);
+    return stage ? push_staged(e, b) : push_trusted(e, b);
 }
 int xck_push_batch_device(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; FOR_IMPLS(e, engine_push(e, b, true)); return XCK_OK; }
 int xck_flush(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_flush(e)); return XCK_OK; }

@@ -228,6 +228,9 @@ private:
 
 struct TaskGroup {
     std::mutex mu; std::condition_variable cv; int pending = 0;
+    std::atomic<int> thrown{0};          // a task body threw: 1 = std::bad_alloc, 2 = anything else (checked by the waiter: an exception
+                                         // that leaves a pool thread would otherwise end the process through std::terminate)
+    int take_thrown() { return thrown.exchange(0); }
     void add(Pool& p, std::function<void()> f) {
         { std::lock_guard<std::mutex> lk(mu); pending++; }
         // The notify happens UNDER the lock: a TaskGroup on the waiter's stack may be destroyed as soon as wait() returns, and
@@ -235,7 +238,9 @@ struct TaskGroup {
         // after the unlock let a waiter that saw pending == 0 leave first; the late pthread_cond_broadcast then wrote into
         // whatever the coordinator's stack held by then: "free(): invalid pointer", once per ~14 k chunks with more pool threads
         // than CPUs, tools/stress_e2e.py.)
-        p.submit([this, f] { f(); std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); });
+        p.submit([this, f] {
+            try { f(); } catch (const std::bad_alloc&) { thrown.store(1); } catch (...) { thrown.store(2); }
+            std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); });
     }
     void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return pending == 0; }); }
 };
@@ -342,8 +347,12 @@ struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
 // beyond the end of the position window of their reference (xck_ingest_opts.tid_end)
 struct ContigMap {
     const int32_t* t2c = nullptr; const int32_t* t_end = nullptr; int n_refs = 0;
+    int32_t only_tid = -1;               // position windows: the chunk belongs to the index range of ONE reference; the tail block of that
+                                         // range also holds the first records of the next reference, which that reference's own range
+                                         // delivers again - they are dropped here, so no record reaches the consumer twice
     inline int32_t operator()(int32_t tid, int32_t pos) const {
         if (tid < 0 || tid >= n_refs || !t2c) return -1;
+        if (only_tid >= 0 && tid != only_tid) return -1;
         if (t_end && t_end[tid] > 0 && pos >= t_end[tid]) return -1;
         return t2c[tid];
     }
@@ -384,6 +393,11 @@ private:
         return true;
     }
     void run() {
+        // (the scanner's only allocations are the block lists: out of memory ends the stream with a failed plan, not the process)
+        try { scan(); }
+        catch (...) { ChunkPlan f; f.failed = true; f.err = "out of host memory (BGZF scanner)"; f.blocks.clear(); if (put(std::move(f))) { ChunkPlan z; z.end = true; put(std::move(z)); } }
+    }
+    void scan() {
         for (size_t ri = 0; ri < ranges_.size(); ri++) {
             const ScanRange& rg = ranges_[ri];
             uint64_t coff = rg.coff; bool first = true, ended = false;
@@ -413,6 +427,7 @@ private:
 };
 
 constexpr int N_CHUNK = 3, N_SOA = 3;
+struct CallerBinding;
 struct xck_bam {
     std::string path; int fd = -1; const uint8_t* map = nullptr; uint64_t fsize = 0;
     std::vector<std::string> ref_names; std::vector<int64_t> ref_lens;
@@ -424,6 +439,7 @@ struct xck_bam {
     uint32_t first_skip = 0;           // bytes of the first block that precede the first record
     uint32_t stitch_skip = 0;          // same for the chunk being stitched
     Scanner* scanner = nullptr; bool scan_end = false;
+    std::vector<int32_t> range_tid;                       // per_tid_ranges: reference of every range
     bool per_tid_ranges = false; int skip_range = -1;   // position windows: one range per reference; a range is dropped once a record starts beyond its window
     Pool* pool = nullptr; int n_threads = 1;
     Chunk ch[N_CHUNK]; int head = 0, n_sched = 0;      // ring: ch[head] is decoded next, n_sched chunks are inflating / inflated
@@ -435,7 +451,11 @@ struct xck_bam {
     int64_t n_records = 0;             // records walked so far (all, including unused contigs)
     bool done = false;
     size_t chunk_target = 48u << 20;   // uncompressed bytes per chunk
-    bool affinity_changed = false; cpu_set_t old_affinity;   // NUMA binding of the calling thread (restored at close)
+    // NUMA binding (bind_to_numa_node): the pool and the scanner sit on the node of the handle's GPU while the reader is open; the
+    // CALLING thread (it runs the coordinator, and its first touch places the inflate buffers) only for the duration of a decode
+    // call (CallerBinding) - between calls, and on whatever thread closes the reader, the caller's own mask is untouched
+    bool numa_bound = false, threads_auto = false; cpu_set_t numa_set, old_affinity;
+    struct CallerBinding* cur_binding = nullptr;
     DecodeTimes tm;
     std::string err;
 };
@@ -528,6 +548,7 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
     // first alignment record: inside the last inflated block at offset (r.pos - r.blk_start), or at the next block
     if (r.pos == r.buf.size()) { b->next_coff = r.coff; b->first_skip = 0; }
     else { b->next_coff = r.blk_coff; b->first_skip = (uint32_t)(r.pos - r.blk_start); }
+    b->threads_auto = n_threads <= 0;
     if (n_threads <= 0) n_threads = default_threads();
     b->n_threads = n_threads;
     b->tm.t_open = std::chrono::steady_clock::now();
@@ -554,7 +575,7 @@ void xck_bam_close(xck_bam* b) {
     // it was recorded on dies with the engine's staging, and waiting on such an event later fails (hipErrorStreamCaptureUnsupported
     // on ROCm 7: the next reader's first launch check then reported that stale error; tests/test_gpu_random_e2e.py seed 9)
     for (auto& so : b->soa) if (so.fence) { fence_wait(so.fence); fence_destroy(so.fence); so.fence = nullptr; }
-    if (b->affinity_changed) { pthread_setaffinity_np(pthread_self(), sizeof b->old_affinity, &b->old_affinity); b->affinity_changed = false; }
+    if (b->numa_bound && b->pool) b->pool->set_affinity(b->old_affinity);   // a parked pool goes back to the full mask
     if (getenv("XCK_DEBUG_TIMING") && b->tm.chunks) {
         const DecodeTimes& t = b->tm; const double ms = 1e-6;
         fprintf(stderr, "[xck] ingest %s: %lld records, %llu chunks (%llu stitched serially), %.0f ms since open, %d threads | pool CPU ms: inflate %.0f walk %.0f parse %.0f | "
@@ -626,7 +647,8 @@ static void set_ranges(xck_bam* b, const xck_ingest_opts* o) {
     load_index(b);
     if (!b->idx_ok) return;                                            // no usable index: decode everything
     const bool has_win = o->struct_size >= offsetof(xck_ingest_opts, tid_end) + sizeof(void*) && (o->tid_beg || o->tid_end);
-    std::vector<std::pair<uint64_t, uint64_t>> rg;
+    struct Rg { uint64_t first, second; int32_t tid; bool operator<(const Rg& o) const { return first != o.first ? first < o.first : second < o.second; } };
+    std::vector<Rg> rg;
     for (size_t t = 0; t < b->ref_names.size(); t++) {
         if (!(o->tid_to_contig[t] >= 0 && b->idx_beg[t] != ~0ull && b->idx_end[t] > b->idx_beg[t])) continue;
         uint64_t beg = b->idx_beg[t];
@@ -636,17 +658,18 @@ static void set_ranges(xck_bam* b, const xck_ingest_opts* o) {
             if (w >= lin.size()) continue;                               // nothing overlaps that far right
             if (lin[w] > beg) beg = lin[w];
         }
-        if (beg < b->idx_end[t]) rg.push_back({beg, b->idx_end[t]});
+        if (beg < b->idx_end[t]) rg.push_back({beg, b->idx_end[t], (int32_t)t});
     }
     std::sort(rg.begin(), rg.end());
     b->per_tid_ranges = has_win;
-    for (auto& x : rg) { if (!has_win && !b->ranges.empty() && (x.first >> 16) <= (b->ranges.back().second >> 16) + 1) b->ranges.back().second = std::max(b->ranges.back().second, x.second); else b->ranges.push_back(x); }
+    for (auto& x : rg) { if (!has_win && !b->ranges.empty() && (x.first >> 16) <= (b->ranges.back().second >> 16) + 1) b->ranges.back().second = std::max(b->ranges.back().second, x.second);
+                         else { b->ranges.push_back({x.first, x.second}); b->range_tid.push_back(x.tid); } }
     b->use_ranges = true;
 }
 
 // take the next plan from the scanner and start inflating it into c (asynchronous); tid_to_contig lets the walk tasks
 // prepare the output layout of their own records
-static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMap cm, bool want_seq) {
+static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMap cm_in, bool want_seq) {
     c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0;
     if (b->scan_end) return;
     ChunkPlan pl = b->scanner->next();
@@ -669,6 +692,7 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMa
         wp.spec_start = wp.u_begin + (pi == 0 ? skip0 : 0); wp.stop = wp.spec_start; wp.recs.clear();
         wp.n_out = wp.n_cig = wp.n_seq = 0; wp.runs.clear();
         Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp; DecodeTimes* tmp_ = &b->tm;
+        ContigMap cm = cm_in; cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
         c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp, tmp_, cm, want_seq] {
             if (!t_zs.ok) { cp->failed = true; return; }
             const auto t_a = std::chrono::steady_clock::now();
@@ -730,6 +754,16 @@ static int node_of_cpu(int cpu, cpu_set_t* node_set) {
     }
     return -1;
 }
+struct CallerBinding {
+    xck_bam* b; cpu_set_t saved; bool active = false;
+    explicit CallerBinding(xck_bam* b_) : b(b_) { if (b) { b->cur_binding = this; enter(); } }
+    void enter() {
+        if (!b || !b->numa_bound || active) return;
+        if (sched_getaffinity(0, sizeof saved, &saved) != 0) return;
+        if (pthread_setaffinity_np(pthread_self(), sizeof b->numa_set, &b->numa_set) == 0) active = true;
+    }
+    ~CallerBinding() { if (active) pthread_setaffinity_np(pthread_self(), sizeof saved, &saved); if (b) b->cur_binding = nullptr; }
+};
 static void bind_to_numa_node(xck_engine* e, xck_bam* b) {
     if (const char* v = getenv("XCK_NUMA")) if (atoi(v) == 0) return;
     if (!b->pool || b->n_threads < 2) return;
@@ -742,9 +776,11 @@ static void bind_to_numa_node(xck_engine* e, xck_bam* b) {
     if (sched_getaffinity(0, sizeof cur, &cur) != 0) return;
     cpu_set_t both; CPU_AND(&both, &cur, &node_set);
     if (CPU_COUNT(&both) < 2 || CPU_COUNT(&both) == CPU_COUNT(&cur)) return;     // not allowed there, or there is only this node
-    if (pthread_setaffinity_np(pthread_self(), sizeof both, &both) != 0) return;
-    b->old_affinity = cur; b->affinity_changed = true;
+    // a thread count that was derived from the CPUs of the WHOLE machine (no quota, two sockets) is cut to the node's CPUs
+    if (b->threads_auto && b->n_threads > CPU_COUNT(&both)) { delete b->pool; b->n_threads = CPU_COUNT(&both); b->pool = new Pool(b->n_threads); }
+    b->old_affinity = cur; b->numa_set = both; b->numa_bound = true;
     b->pool->set_affinity(both);
+    if (b->cur_binding) b->cur_binding->enter();                     // the rest of this decode call (the scanner thread made next inherits it)
 }
 
 // locate a 2-character aux tag; returns pointer to the type byte or nullptr
@@ -892,7 +928,9 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         return 0;
     }
     Chunk& c = b->ch[b->head];
+    cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
     c.tg.wait();
+    if (const int th = c.tg.take_thrown()) { b->err = th == 1 ? "out of host memory (BGZF inflate / record walk)" : "C++ exception in a decoder task"; return th == 1 ? XCK_E_NOMEM : XCK_E_IO; }
     if (b->skip_range >= 0 && c.range_id == b->skip_range && !c.failed) {   // rest of a reference whose position window is behind us
         b->head = (b->head + 1) % N_CHUNK; b->n_sched--;
         b->carry.clear();
@@ -955,7 +993,8 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         { TaskGroup tg; const int32_t smp = o->sample;
           for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
               tg.add(*b->pool, [b, e, smp, wpp, cm, &flags] { parse_part(b, e, smp, wpp, cm, &flags); }); }
-          tg.wait(); }
+          tg.wait();
+          if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
         phase(b->tm.wait_parse);
         limit = (int64_t)n_rec;
     } else {
@@ -1033,9 +1072,12 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     { TaskGroup tg; const int64_t per = std::max<int64_t>(4096, (limit + b->n_threads * 4 - 1) / (b->n_threads * 4));
       for (int64_t r0 = 0; r0 < limit; r0 += per) { int64_t r1 = std::min(limit, r0 + per); int32_t smp = o->sample;
           tg.add(*b->pool, [b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }); }
-      tg.wait(); }
+      tg.wait();
+      if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
     phase(b->tm.wait_parse);
     }
+    if (flags.load() & 4) { b->err = "out of host memory (record parse)"; return XCK_E_NOMEM; }
+    if (flags.load() & 8) { b->err = "C++ exception in a parse task"; return XCK_E_IO; }
     if (flags.load() & 1) { b->err = "corrupt BAM record (fields exceed block_size)"; return XCK_E_IO; }
     if (flags.load() & 2) { b->err = "too many distinct non-ACGT keys for the key width"; return XCK_E_CAPACITY; }
     if (b->per_tid_ranges && cm.t_end) {                               // last record of the chunk starts beyond its reference's window: drop the rest
@@ -1073,6 +1115,7 @@ int xck_bam_linear_index(xck_bam* b, int tid, int64_t* n, const uint64_t** voffs
 
 static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) {
     if (!e || !b || !o || !out) return XCK_E_ARG;
+    CallerBinding on_node(b);
     while (b->pending.empty()) {
         if (b->done) return 0;
         int rc = decode_next_chunk(e, b, o);
@@ -1091,6 +1134,7 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
 
 static int ingest_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) {
     if (!e || !b || !o) return XCK_E_ARG;
+    CallerBinding on_node(b);
     const int64_t pause = o->struct_size >= offsetof(xck_ingest_opts, pause_records) + sizeof(int64_t) ? o->pause_records : 0;
     const int64_t start = b->n_records;
     std::vector<xck_batch> bts;

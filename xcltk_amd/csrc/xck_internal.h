@@ -102,6 +102,7 @@ struct xck_engine {
     void* impls[2] = {nullptr, nullptr}; // fused handle (XCK_MODE_BOTH): [0] basefc pipeline, [1] pileup pipeline
     int n_impl = 0;
     void* stager = nullptr;              // xck::Stager (engine.hip): device staging slots of engine_push_block
+    struct PushRing { void* blk[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}; void* fence[3] = {nullptr, nullptr, nullptr}; int next = 0; } push_ring;   // pinned blocks of xck_push_batch's one-copy form (api.cpp)
     int mode = 0;
     int umi_bits = 64;
     int32_t n_cells = 0, n_contigs = 0;  // bounds that caller-supplied batches are checked against (xck_push_batch)

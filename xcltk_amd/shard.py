@@ -83,28 +83,6 @@ def plan_units(contig_weights, world, regions, contig_index, byte_profiles=None,
     return units, owner
 
 
-def gather_coo(coo, world, device="cpu", group=None):
-    """All-gatherv of one sparse block.  coo = (row, col, val) int32 numpy arrays of this
-    rank; returns the concatenation over ranks sorted by (row, col) - identical to what a
-    single process would have produced because ranks own disjoint rows."""
-    import torch
-    import torch.distributed as dist
-    n = torch.tensor([len(coo[0])], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    buf = torch.zeros((3, mx), dtype=torch.int32, device=device)
-    if len(coo[0]):
-        buf[:, :len(coo[0])] = torch.from_numpy(np.stack([np.asarray(c, dtype=np.int32) for c in coo])).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    cat = torch.cat([o[:, :s] for o, s in zip(out, sizes)], dim=1)
-    key = cat[0].to(torch.int64) * (1 << 31) + cat[1].to(torch.int64)
-    cat = cat[:, torch.argsort(key)].cpu().numpy()
-    return cat[0].copy(), cat[1].copy(), cat[2].copy()
-
-
 def merge_row_blocks(blocks, row_owner):
     """Concatenate per-rank sparse blocks into one (row, col, val) sorted by (row, col) without sorting.
     blocks[r] = int32 array [row | col | val] (3 * nnz_r) of rank r, itself sorted by (row, col) and holding only rows
