@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert {n for n, _, _ in capi.SYMBOLS} == declared
-    assert lib.xck_abi_version() == 2 and b"gfx950" in lib.xck_version()
+    assert lib.xck_abi_version() == 3 and b"gfx950" in lib.xck_version()
 
 
 def test_struct_layouts_match_header_sizes(lib):

@@ -91,7 +91,8 @@ class Stats(C.Structure):
     _fields_ = [("n_batches", C.c_int64), ("n_reads", C.c_int64), ("n_hits", C.c_int64),
                 ("n_hits_unique", C.c_int64), ("ms_h2d", C.c_double), ("ms_device", C.c_double),
                 ("ms_join", C.c_double), ("ms_sort", C.c_double), ("ms_d2h", C.c_double),
-                ("algo_bytes_join", C.c_int64), ("n_join_launches", C.c_int64), ("key_bits", C.c_int32), ("umi_bits", C.c_int32)]
+                ("algo_bytes_join", C.c_int64), ("n_join_launches", C.c_int64), ("key_bits", C.c_int32), ("umi_bits", C.c_int32),
+                ("fold_path", C.c_int32), ("fold_fallbacks", C.c_int32)]
 
 
 class IngestOpts(C.Structure):
@@ -189,7 +190,7 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.xck_abi_version() != 2:
+    if lib.xck_abi_version() != 3:
         raise XckLibraryError("ABI mismatch")
     if path is None:
         _lib = lib

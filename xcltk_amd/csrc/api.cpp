@@ -110,22 +110,15 @@ static int check_host_batch(xck_engine* e, const xck_batch* b) {
 }
 extern "C++" { namespace xck { int push_trusted(xck_engine* e, const xck_batch* b) { FOR_IMPLS(e, engine_push(e, b, false)); return XCK_OK; } } }
 
-// xck_push_batch, one-copy form: the caller's nine arrays are packed into ONE engine-owned pinned block (ring of three), which
-// crosses PCIe with ONE hipMemcpyAsync into a device staging slot shared by the handle's pipelines (engine_push_block - the path
-// the BAM decoder uses).  The call returns as soon as the arrays are packed: the caller may reuse them, and the DMA of this
-// batch overlaps the packing of the next one (the block's fence, an event, is waited for only when the ring comes round).
-// Large batches are packed by a few threads.  Arrays that ARE pinned (hipHostMalloc / hipHostRegister) keep the direct form
-// (engine_push: DMA straight from the caller's memory, no host copy) unless XCK_PUSH_STAGE=1.
-static bool caller_arrays_pinned(const xck_batch* b, bool seq) {
-    const void* cols[] = { b->pos, b->flag, b->mapq, b->cell, b->umi, b->cig_off, b->cigar, seq ? b->seq_off : nullptr, seq ? b->seq : nullptr };
-    for (const void* p : cols) {
-        if (!p) continue;
-        hipPointerAttribute_t at; memset(&at, 0, sizeof at);
-        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // plain pageable memory
-        if (at.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-}
+// xck_push_batch, one-copy form for SMALL batches: the caller's nine arrays are packed into ONE engine-owned pinned block (ring of
+// three), which crosses PCIe with ONE hipMemcpyAsync into a device staging slot shared by the handle's pipelines
+// (engine_push_block - the path the BAM decoder uses).  The call returns as soon as the arrays are packed: the caller may reuse
+// them, and the DMA of this batch overlaps the packing of the next one (the block's fence, an event, is waited for only when
+// the ring comes round).  Measured on the MI355X box (tools/h2d_bench.py, profiles/r03_a_h2d_*): for batches of 4 M reads the
+// direct form (engine_push: nine DMA copies straight from the caller's arrays + one wait) moves 0.86-1.05 G reads/s whether the
+// arrays are pinned or plain numpy memory, the packed form 0.6 G reads/s (a host memcpy is slower than the DMA it saves) - so
+// the packed form is used where the nine calls and the wait dominate: below XCK_PUSH_STAGE_BYTES (default 2 MB) per batch.
+// XCK_PUSH_STAGE=0 / 1 forces one form.
 static int push_staged(xck_engine* e, const xck_batch* b) {
     if (e->n_impl <= 0) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     const bool seq = (e->mode & XCK_MODE_BAF) != 0;
@@ -179,7 +172,10 @@ int xck_push_batch(xck_engine* e, const xck_batch* b) {
     if (int rc = check_host_batch(e, b)) return rc;
     if (b->n_reads <= 0 || b->contig < 0 || e->n_impl <= 0) return push_trusted(e, b);     // nothing to copy / decode-only: engine_push reports
     static const int force = getenv("XCK_PUSH_STAGE") ? atoi(getenv("XCK_PUSH_STAGE")) : -1;
-    const bool stage = force >= 0 ? force != 0 : !caller_arrays_pinned(b, (e->mode & XCK_MODE_BAF) != 0);
+    static const long long small = getenv("XCK_PUSH_STAGE_BYTES") ? atoll(getenv("XCK_PUSH_STAGE_BYTES")) : (2ll << 20);
+    const size_t n = (size_t)b->n_reads;
+    const size_t bytes = n * 27 + (size_t)(b->cig_off[n] - b->cig_off[0]) * 4 + ((e->mode & XCK_MODE_BAF) ? n * 4 + (b->seq_off[n] - b->seq_off[0]) : 0);
+    const bool stage = force >= 0 ? force != 0 : (long long)bytes < small;
     return stage ? push_staged(e, b) : push_trusted(e, b);
 }
 int xck_push_batch_device(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; FOR_IMPLS(e, engine_push(e, b, true)); return XCK_OK; }

@@ -1485,6 +1485,7 @@ struct EngineImpl {
     unsigned long long cur_before[NSHARD] = {0}, acc_before[NSHARD] = {0};
     unsigned long long cursor = 0;             // sum of cur[]; hit_cap is the capacity of ONE shard
     int fold_extra_digits = 0;                 // basefc hash fold: extra radix digits that earlier finishes needed (giant runs)
+    int fold_path = 0, fold_fallbacks = 0;     // xck_stats: which basefc fold ran last (1 partition, 2 radix sort), hand-overs so far
     // fused launch queue
     std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
     std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
@@ -2100,6 +2101,8 @@ static int pack_shards(EngineImpl* im, K* dst_keys, uint64_t* dst_vals) {
     return 0;
 }
 
+#include "fold_partition.h"
+
 template <class K>
 static int finish_t(EngineImpl* im) {
     clear_stale_error("finish");
@@ -2121,6 +2124,26 @@ static int finish_t(EngineImpl* im) {
     const size_t nb = (n + CP_TILE - 1) / CP_TILE;
     K* keys = (K*)im->d_keys;
     if (im->mode == XCK_MODE_BASEFC) {
+        // 64-bit keys: the partition fold (fold_partition.h - no sort); it hands back PF_FALLBACK for the inputs it cannot place
+        // (one (row, cell) with more keys than a work item holds, ...), and the radix-sort fold below then takes over
+        if constexpr (sizeof(K) == 8) {
+            const bool want_sort = getenv("XCK_FOLD") && !strcmp(getenv("XCK_FOLD"), "sort");   // (read per finish: the tests switch it)
+            if (!want_sort) {
+                if ((rc = tm.start())) return rc;
+                KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
+                rc = fold_partition(im, kl8, n);
+                if (rc == 0) {
+                    im->fold_path = 1;
+                    if ((rc = tm.stop(&im->st.ms_sort))) return rc;
+                    HIP_TRY(hipStreamSynchronize(im->s_comp));
+                    return 0;
+                }
+                if (rc != PF_FALLBACK) return rc;
+                im->fold_fallbacks++;
+                if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: handing over to the radix-sort fold\n");
+            }
+        }
+        im->fold_path = 2;
         const size_t tmpb = sort_tmp_bytes<K, rocprim::empty_type>(n, top);
         if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + tmpb + nb * 12 + n * 12 + (1 << 20)))) return rc;
         K* alt = im->ws1.get<K>(n); void* tmp = im->ws1.get<char>(tmpb);
@@ -2327,6 +2350,7 @@ int engine_stats(const xck_engine* e, xck_stats* out) {
     if (!im) return XCK_E_STATE;
     *out = im->st; out->key_bits = im->key_bits; out->umi_bits = im->ubits;
     out->n_join_launches = im->n_join_launches;
+    out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks;
     return 0;
 }
 
@@ -2369,6 +2393,7 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     // the hash fold needs 64 KB of dynamic LDS: raise the limit on THIS engine's device (a per-process flag would leave every
     // device but the first at the 64 KB default and race between engines created from different threads)
     HIP_TRY(hipFuncSetAttribute((const void*)k_fold_emit_unsorted, hipFuncAttributeMaxDynamicSharedMemorySize, FU_SLOTS * 8));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_pf_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, pf_bucket_lds(PF_SB_MAX)));
     HIP_TRY(hipStreamCreateWithFlags(&im->s_copy, hipStreamNonBlocking));
     { int lo = 0, hi = 0;                                   // numerically lowest value = highest priority
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));

@@ -1,0 +1,657 @@
+// fold_partition.h - basefc fold WITHOUT a sort (64-bit keys): adaptive two-level partition + one LDS pass per bucket.
+// Included by engine.hip inside namespace xck (it uses EngineImpl, Arena, KeyLayout, set_slot, copy_out, res_reserve).
+//
+// Replaces, for the count matrix, what the reference does with one Python set per (region, cell):
+//   xcltk/rdr/fc/mcount.py:34-54 (MCount.add_read: set insert, len() at the end), rdr/fc/core.py:166-178.
+//
+// The keys (row | cell | umi) leave k_join in 16 shard slices, in tile order of a coordinate-sorted file: at any place of the
+// stream only a handful of rows are active.  A radix sort throws that away (4 onesweep passes over (row, cell): 24 GB for
+// the 3 GB of keys of configs[2]).  Here:
+//
+//   row geometry   k_pf_rowhist counts keys per row on a SAMPLE of the stream (every stride-th chunk), k_pf_rowplan gives every row
+//                  G_r = 2^l cell groups so that a group holds about C / 2 keys (a cold gene: one group; a hot one: up to 2^lgG_max).
+//                  A uniform G does not work: where genes are cold a chunk of the stream touches hundreds of rows, and G groups
+//                  each would leave one key per (chunk, group) - nothing to aggregate, every write on its own (first version:
+//                  8 ms per pass over the keys instead of 0.7).
+//   level-1 cells  z = zbase[row] + (cell >> sg_row).  k_pf_hist<1> counts the keys per z (a chunk of the stream touches few z,
+//                  so a block aggregates in an LDS table and flushes ~100 atomics), a scan turns the counts into offsets,
+//                  k_pf_part<1> moves every key to its z (again one LDS table per chunk: a run of keys per (chunk, z), one
+//                  returning atomic per run).
+//   work items     consecutive z are merged into work items of at most CAP = 2C keys that stay inside one block of 2^sb
+//                  (row, cell) pairs ("span"): z starts a new item when its first key opens a new page of C keys, when the
+//                  span changes, or when it (or its predecessor) holds more than C keys on its own (k_pf_plan / k_pf_emit).
+//   level 2        a z with more than CAP keys (a hot gene: thousands of keys per cell) is "big": its keys are partitioned
+//                  once more by the low cell bits (k_pf_hist<2> / k_pf_part<2>, the same kernels on the level-1 output),
+//                  and its sub-cells are merged into work items by the same page rule.
+//   k_pf_bucket    one block per work item: distinct (row, cell, umi) by an LDS hash set, the (row, cell) pairs present by an
+//                  LDS bitmap over the span whose prefix popcounts ARE the output order, counts by LDS atomics on the rank.
+//   k_pf_write     the per-item results (cell-in-span << 16 | count) -> COO [row | col | val] at the scanned offsets.
+//
+// Anything this cannot place (a single (row, cell) with more than CAP keys, > 2^32 keys, 128-bit keys, a cell field too
+// wide for the span) returns PF_FALLBACK and the caller takes the radix-sort path, which handles every input.
+//
+// Traffic at configs[2] (n = 380 M keys = 3.04 GB, 98 M non-zeros): hist 3.0 + part 6.1 + level 2 (~40 % of the keys)
+// 1.2 + 2.4 + bucket 3.0 + 0.4 + write 0.4 + 1.2 = 17.7 GB (radix path: ~39 GB).  DESIGN.md section 3.2.
+#pragma once
+
+constexpr int PF_FALLBACK = 1;
+constexpr int PF_C_MAX = 1024;                         // page size C (keys); a work item holds at most CAP = 2C keys
+constexpr int PF_CAP_MAX = 2 * PF_C_MAX;
+constexpr int PF_SLOTS = 4096;                         // LDS set of k_pf_bucket: 32 KB, load <= 0.5
+constexpr int PF_THREADS = 512, PF_KPT = PF_CAP_MAX / PF_THREADS;
+constexpr int PF_SB_MAX = 16, PF_BM_WORDS_MAX = (1 << PF_SB_MAX) / 32;   // bitmap over the span: at most 65536 (row, cell) pairs
+constexpr int PT_THREADS = 512, PT_KPT = 8, PT_CHUNK = PT_THREADS * PT_KPT;
+constexpr int PT_TAB_LG = 11, PT_TAB = 1 << PT_TAB_LG; // LDS aggregation table of the histogram / partition kernels
+constexpr uint32_t PF_BIG = 0x80000000u;               // WorkItem.span: the item is a big z (its keys are handled by level 2)
+
+struct PartGeom {
+    int ubits, cbits;                                  // key layout
+    int sb;                                            // span bits: a work item stays inside one aligned block of 2^sb (row, cell) pairs
+    int lgC;                                           // page size C = 1 << lgC
+    uint32_t n_cells;
+    const uint32_t* rowtab;                            // per row: (first level-1 cell of the row << 5) | sg;  z = base + (cell >> sg)
+};
+struct WorkItem { uint32_t off, span, aux, pad; };     // first key, (row, cell) >> sb of every key in it, level 1: big index / level 2: parent big z,
+                                                       // level 2: (row, cell) & mask of the item's first sub-cell | PF_CONT
+constexpr uint32_t PF_CONT = 0x80000000u;              // WorkItem.pad: that (row, cell) already has keys in earlier items of the same big z
+
+// where the chunks of a histogram / partition launch come from
+struct ShardChunks { unsigned long long cap; uint32_t cnt[NSHARD]; uint32_t chunk0[NSHARD + 1]; };   // level 1: the 16 shard slices of the hit buffer
+struct BigChunks { const uint32_t* off; const uint32_t* cnt; const uint32_t* chunk0; const uint32_t* z2base; const uint32_t* sg; const uint32_t* eb; uint32_t n_big; };   // level 2: the big z of the level-1 output
+
+struct AggTab { uint32_t tag[PT_TAB]; uint32_t cnt[PT_TAB]; uint32_t base[PT_TAB]; };
+__device__ __forceinline__ int agg_find(AggTab& t, uint32_t z) {
+    uint32_t h = (z * 0x9E3779B1u) >> (32 - PT_TAB_LG);
+#pragma unroll 1
+    for (int p = 0; p < 24; p++) {
+        const uint32_t prev = atomicCAS(&t.tag[h], 0xffffffffu, z);
+        if (prev == 0xffffffffu || prev == z) return (int)h;
+        h = (h + 1) & (PT_TAB - 1);
+    }
+    return -1;                                         // table crowded (unsorted input): the key is handled on its own
+}
+
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan_t(uint32_t v, uint32_t* s_wave, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) { const uint32_t t = s_wave[w]; if (w < wave) base += t; total += t; }
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ---- device-wide exclusive scan of uint32 (in place), three launches --------------------------------------------------
+constexpr int SC_T = 256, SC_I = 16, SC_TILE = SC_T * SC_I;
+__global__ __launch_bounds__(SC_T) void k_scan_reduce(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t s_w[SC_T / 64];
+    const size_t base = (size_t)blockIdx.x * SC_TILE;
+    uint32_t s = 0;
+#pragma unroll
+    for (int t = 0; t < SC_I; t++) { const size_t i = base + (size_t)t * SC_T + threadIdx.x; if (i < n) s += in[i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t* __restrict__ bsum, size_t nb, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (size_t b0 = 0; b0 < nb; b0 += 1024) {
+        const size_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? bsum[i] : 0u;
+        uint32_t inc = v;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        uint32_t wb = 0, tot = 0;
+#pragma unroll
+        for (int x = 0; x < 16; x++) { if (x < w) wb += s_w[x]; tot += s_w[x]; }
+        const uint32_t carry = s_carry;
+        if (i < nb) bsum[i] = carry + wb + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
+__global__ __launch_bounds__(SC_T) void k_scan_apply(uint32_t* __restrict__ data, size_t n, const uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t s_w[SC_T / 64];
+    const size_t i0 = (size_t)blockIdx.x * SC_TILE + (size_t)threadIdx.x * SC_I;       // blocked: a thread owns SC_I consecutive elements
+    uint32_t v[SC_I], s = 0;
+#pragma unroll
+    for (int t = 0; t < SC_I; t++) { v[t] = i0 + t < n ? data[i0 + t] : 0u; s += v[t]; }
+    uint32_t total;
+    uint32_t run = bsum[blockIdx.x] + block_excl_scan_t<SC_T>(s, s_w, total);
+#pragma unroll
+    for (int t = 0; t < SC_I; t++) { if (i0 + t < n) data[i0 + t] = run; run += v[t]; }
+}
+
+// ---- histogram / partition over the level cells ------------------------------------------------------------------------
+// chunk of a block: level 1 = PT_CHUNK consecutive keys of one shard slice, level 2 = PT_CHUNK consecutive keys of one big z
+struct ChunkLoc { unsigned long long base; uint32_t n, zbase, sub_mask; int eb, tb; };
+__device__ __forceinline__ ChunkLoc pf_locate1(const ShardChunks& sc, uint32_t chunk, uint32_t chunk_keys = PT_CHUNK) {
+    int sh = 0;
+#pragma unroll
+    for (int q = 1; q < NSHARD; q++) sh += (chunk >= sc.chunk0[q]) ? 1 : 0;
+    const uint32_t c = chunk - sc.chunk0[sh];
+    ChunkLoc L; L.base = (unsigned long long)sh * sc.cap + (unsigned long long)c * chunk_keys;
+    L.n = min(chunk_keys, sc.cnt[sh] - c * chunk_keys); L.zbase = 0; L.sub_mask = 0; L.eb = 0; L.tb = 0;
+    return L;
+}
+__device__ __forceinline__ ChunkLoc pf_locate2(const BigChunks& bc, uint32_t chunk, uint32_t* s_b) {
+    if (threadIdx.x == 0) {                            // the big z that owns the chunk: last b with chunk0[b] <= chunk
+        uint32_t lo = 0, hi = bc.n_big;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (bc.chunk0[mid] <= chunk) lo = mid; else hi = mid; }
+        *s_b = lo;
+    }
+    __syncthreads();
+    const uint32_t b = *s_b;
+    const uint32_t c = chunk - bc.chunk0[b];
+    ChunkLoc L; L.base = (unsigned long long)bc.off[b] + (unsigned long long)c * PT_CHUNK;
+    L.n = min((uint32_t)PT_CHUNK, bc.cnt[b] - c * PT_CHUNK); L.zbase = bc.z2base[b]; L.sub_mask = (1u << bc.sg[b]) - 1u; L.eb = (int)(bc.eb[b] & 31u); L.tb = (int)(bc.eb[b] >> 5);
+    return L;
+}
+template <int LEVEL>
+__device__ __forceinline__ uint32_t pf_cell(unsigned long long key, const PartGeom& g, const ChunkLoc& L) {
+    const unsigned long long rc = key >> g.ubits;
+    if (LEVEL == 1) {
+        const uint32_t t = g.rowtab[(uint32_t)(rc >> g.cbits)];
+        return (t >> 5) + (((uint32_t)rc & ((1u << g.cbits) - 1u)) >> (t & 31u));
+    }
+    // level 2: sub-cell = (low cell bits >> tb, eb bits of a UMI hash).  tb > 0: groups of 2^tb cells (a big z whose cells are
+    // shallow); eb > 0 (then tb = 0): one (row, cell) deeper than a work item is cut into 2^eb parts, whose distinct-key counts add
+    // up (the parts are disjoint key sets)
+    const unsigned long long umi = key & ((1ull << g.ubits) - 1ull);
+    const uint32_t h = (uint32_t)(umi ^ (umi >> 13) ^ (umi >> 27));
+    return L.zbase + (((((uint32_t)rc & L.sub_mask) >> L.tb) << L.eb) | (h & ((1u << L.eb) - 1u)));
+}
+
+// keys per row on a SAMPLE of the stream: pieces of 64 keys, one out of `stride`, so that every fragment a join tile flushed (hundreds
+// of keys) is met a few times - sampling whole chunks missed most rows of a few thousand keys (they live in 3 - 4 fragments) and
+// grossly over-counted the others.  Decides the cell groups per row, nothing else.  A block covers PT_CHUNK * stride stream keys.
+constexpr int PF_PIECE = 64;
+__global__ __launch_bounds__(PT_THREADS) void k_pf_rowhist(const unsigned long long* __restrict__ keys, ShardChunks sc, uint32_t stride, int row_shift, uint32_t* __restrict__ rowcnt) {
+    __shared__ AggTab t;
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
+    const ChunkLoc L = pf_locate1(sc, blockIdx.x, PT_CHUNK * stride);
+    unsigned long long k[PT_KPT]; bool ok[PT_KPT];
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {
+        const uint32_t i = q * PT_THREADS + threadIdx.x;
+        const uint32_t j = (i / PF_PIECE) * (PF_PIECE * stride) + (i % PF_PIECE);      // piece i / 64 of the block's sample, key i % 64 in it
+        ok[q] = j < L.n; k[q] = ok[q] ? keys[L.base + j] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {
+        if (!ok[q]) continue;
+        const uint32_t row = (uint32_t)(k[q] >> row_shift);
+        const int slot = agg_find(t, row);
+        if (slot >= 0) atomicAdd(&t.cnt[slot], 1u); else atomicAdd(&rowcnt[row], 1u);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) atomicAdd(&rowcnt[t.tag[s]], t.cnt[s]);
+}
+// gsz[row] = cell groups of the row: the smallest 2^l (lg_min <= l <= lg_max) that brings the estimated keys per group to C / 2
+__global__ void k_pf_rowplan(const uint32_t* __restrict__ rowcnt, uint32_t n_rows, uint32_t stride, int lg_min, int lg_max, int lgC, uint32_t* __restrict__ gsz) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    if (r == n_rows) { gsz[r] = 0; return; }
+    const unsigned long long est = (unsigned long long)rowcnt[r] * stride;
+    int l = lg_min;
+    while (l < lg_max && (est >> l) > (1ull << lgC) / 2) l++;
+    gsz[r] = 1u << l;
+}
+// zb = exclusive scan of gsz (n_rows + 1 entries): rowtab[row] = zb << 5 | sg, zrow[z] = row of cell z
+__global__ void k_pf_rowtab(const uint32_t* __restrict__ zb, uint32_t n_rows, int cbits, uint32_t* __restrict__ rowtab, uint32_t* __restrict__ zrow) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t base = zb[r], G = zb[r + 1] - base;
+    const int lg = 31 - __builtin_clz(G);
+    rowtab[r] = (base << 5) | (uint32_t)(cbits - lg);
+    for (uint32_t q = 0; q < G; q++) zrow[base + q] = r;
+}
+
+// Level 1 keeps 2^pl copies of every counter / cursor (copy = block index mod 2^pl; the copies of a cell are adjacent, so the scan
+// lays a cell's keys out copy after copy): the chunks of a hot gene - thousands in flight - otherwise queue on the same ~150
+// addresses, and device-scope atomics on one address serialise at well under 2 per microsecond (first version: 5.4 ms for the
+// histogram, 5.9 ms for the partition; the level-2 kernels, same code without the contention, ran at 3.9 TB/s).
+template <int LEVEL>
+__global__ __launch_bounds__(PT_THREADS) void k_pf_hist(const unsigned long long* __restrict__ keys, ShardChunks sc, BigChunks bc, PartGeom g, int pl, uint32_t* __restrict__ hist) {
+    __shared__ AggTab t;
+    __shared__ uint32_t s_b;
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
+    const uint32_t copy = blockIdx.x & ((1u << pl) - 1u);
+    const ChunkLoc L = LEVEL == 1 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
+    unsigned long long k[PT_KPT];
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) { const uint32_t i = q * PT_THREADS + threadIdx.x; k[q] = i < L.n ? keys[L.base + i] : 0ull; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {
+        if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n) continue;
+        const uint32_t z = pf_cell<LEVEL>(k[q], g, L);
+        const int slot = agg_find(t, z);
+        if (slot >= 0) atomicAdd(&t.cnt[slot], 1u); else atomicAdd(&hist[(z << pl) | copy], 1u);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) atomicAdd(&hist[(t.tag[s] << pl) | copy], t.cnt[s]);
+}
+
+// cursor[z << pl | copy] = first free index of that copy of z in the output (starts at the exclusive scan of the histogram)
+template <int LEVEL>
+__global__ __launch_bounds__(PT_THREADS) void k_pf_part(const unsigned long long* __restrict__ keys, ShardChunks sc, BigChunks bc, PartGeom g, int pl,
+                                                        uint32_t* __restrict__ cursor, unsigned long long* __restrict__ out) {
+    __shared__ AggTab t;
+    __shared__ uint32_t s_b;
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
+    const uint32_t copy = blockIdx.x & ((1u << pl) - 1u);
+    const ChunkLoc L = LEVEL == 1 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
+    unsigned long long k[PT_KPT];
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) { const uint32_t i = q * PT_THREADS + threadIdx.x; k[q] = i < L.n ? keys[L.base + i] : 0ull; }
+    __syncthreads();
+    int slot[PT_KPT]; uint32_t rank[PT_KPT], zz[PT_KPT];
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {
+        slot[q] = -2; rank[q] = 0; zz[q] = 0;
+        if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n) continue;
+        zz[q] = pf_cell<LEVEL>(k[q], g, L);
+        slot[q] = agg_find(t, zz[q]);
+        if (slot[q] >= 0) rank[q] = atomicAdd(&t.cnt[slot[q]], 1u);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) t.base[s] = atomicAdd(&cursor[(t.tag[s] << pl) | copy], t.cnt[s]);   // one run per (chunk, cell)
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {
+        if (slot[q] == -2) continue;
+        const uint32_t dst = slot[q] >= 0 ? t.base[slot[q]] + rank[q] : atomicAdd(&cursor[(zz[q] << pl) | copy], 1u);
+        out[dst] = k[q];
+    }
+}
+
+// ---- work items --------------------------------------------------------------------------------------------------------
+// S = exclusive scan of the histogram, Z + 1 entries (S[Z] = number of keys).  Flags per cell z: fs = "starts a work item",
+// level 1 also fb = "big" (more than CAP keys: goes through level 2), fc = its number of level-2 chunks, fz = its sub-cells.
+// ctr: [3] += keys in big cells, [5] = 1 when some cell cannot be placed (PF_FALLBACK)
+struct BigArrays { uint32_t* off; uint32_t* cnt; uint32_t* chunk0; uint32_t* wi; uint32_t* span; uint32_t* first2; uint32_t* z2base; uint32_t* sg; uint32_t* eb; uint32_t* rcl0; };
+// Level-2 geometry of a big z with c keys over `cells` existing cells (of the 2^sg the z spans; the last group of a row is only
+// partly filled).  depth = keys per cell if the cells were even.  Shallow cells: groups of 2^tb cells of about C / 2 keys; cells
+// deeper than C / 2: tb = 0 and 2^eb UMI-hash parts per cell, at most 2^16 sub-cells per big z.  Returns eb | tb << 5;
+// sub-cells = 2^(sg - tb + eb).  (A cell that is 4x deeper than its neighbours can still exceed a work item: k_pf_plan2 reports it.)
+__device__ __forceinline__ uint32_t pf_sub_geom(uint32_t c, int sg, int lgC, uint32_t cells) {
+    const uint32_t half = max(1u, (1u << lgC) / 2), depth = (c + cells - 1) / cells;
+    if (depth <= half) { int tb = 0; while (tb < sg && (depth << (tb + 1)) <= half) tb++; return (uint32_t)tb << 5; }
+    int eb = 0;
+    while (sg + eb < 16 && ((depth + (1u << eb) - 1) >> eb) > half) eb++;
+    return (uint32_t)eb;
+}
+__device__ __forceinline__ uint32_t pf_sub_cells(uint32_t geom, int sg) { return 1u << (sg - (int)(geom >> 5) + (int)(geom & 31u)); }
+__device__ __forceinline__ uint32_t pf_span1(uint32_t z, const PartGeom& g, const uint32_t* __restrict__ zrow, int* sg_out) {
+    const uint32_t row = zrow[z], t = g.rowtab[row];
+    const int sg = (int)(t & 31u);
+    if (sg_out) *sg_out = sg;
+    return (uint32_t)((((unsigned long long)row << g.cbits) | ((unsigned long long)(z - (t >> 5)) << sg)) >> g.sb);
+}
+// cells that exist in level-1 cell z (the row's last group may reach beyond n_cells)
+__device__ __forceinline__ uint32_t pf_cells_in(uint32_t z, const PartGeom& g, const uint32_t* __restrict__ zrow) {
+    const uint32_t t = g.rowtab[zrow[z]];
+    const int sg = (int)(t & 31u);
+    const unsigned long long lo = (unsigned long long)(z - (t >> 5)) << sg;
+    if (lo >= g.n_cells) return 1u;
+    return (uint32_t)min((unsigned long long)g.n_cells - lo, 1ull << sg);
+}
+__global__ void k_pf_plan1(const uint32_t* __restrict__ Sp, int pl, uint32_t Z, PartGeom g, const uint32_t* __restrict__ zrow,
+                           uint32_t* __restrict__ fs, uint32_t* __restrict__ fb, uint32_t* __restrict__ fc, uint32_t* __restrict__ fz, uint32_t* __restrict__ ctr) {
+    const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z > Z) return;
+    if (z == Z) { fs[z] = 0; fb[z] = 0; fc[z] = 0; fz[z] = 0; return; }                 // sentinel: the scans then end with the totals
+    const uint32_t C = 1u << g.lgC, CAP = 2u << g.lgC;
+    const uint32_t s = Sp[(size_t)z << pl], c = Sp[(size_t)(z + 1) << pl] - s, sp = z ? Sp[(size_t)(z - 1) << pl] : 0u, cp = z ? s - sp : 0u;
+    int sg;
+    const uint32_t span = pf_span1(z, g, zrow, &sg), spanp = z ? pf_span1(z - 1, g, zrow, nullptr) : 0u;
+    const bool start = z == 0 || (s >> g.lgC) != (sp >> g.lgC) || c > C || cp > C || span != spanp;
+    const bool big = c > CAP;
+    fs[z] = start ? 1u : 0u; fb[z] = big ? 1u : 0u; fc[z] = big ? (c + PT_CHUNK - 1) / PT_CHUNK : 0u; fz[z] = big ? pf_sub_cells(pf_sub_geom(c, sg, g.lgC, pf_cells_in(z, g, zrow)), sg) : 0u;
+    if (big) atomicAdd(&ctr[3], c);
+}
+// id / bid / ch0 / zb2 = exclusive scans of fs / fb / fc / fz (Z + 1 entries each)
+__global__ void k_pf_emit1(const uint32_t* __restrict__ Sp, int pl, uint32_t Z, PartGeom g, const uint32_t* __restrict__ zrow, const uint32_t* __restrict__ id, const uint32_t* __restrict__ bid,
+                           const uint32_t* __restrict__ ch0, const uint32_t* __restrict__ zb2, WorkItem* __restrict__ wi, BigArrays big) {
+    const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    if (z == 0) {                                                                      // sentinels
+        wi[id[Z]].off = Sp[(size_t)Z << pl]; wi[id[Z]].span = 0; wi[id[Z]].aux = 0xffffffffu;
+        big.chunk0[bid[Z]] = ch0[Z]; big.off[bid[Z]] = Sp[(size_t)Z << pl]; big.cnt[bid[Z]] = 0; big.z2base[bid[Z]] = zb2[Z]; big.sg[bid[Z]] = 0; big.eb[bid[Z]] = 0; big.rcl0[bid[Z]] = 0;
+    }
+    if (id[z + 1] == id[z]) return;                                                    // not a start
+    int sg;
+    WorkItem w; w.off = Sp[(size_t)z << pl]; w.pad = 0; w.aux = 0xffffffffu; w.span = pf_span1(z, g, zrow, &sg);
+    if (bid[z + 1] != bid[z]) {
+        const uint32_t b = bid[z];
+        big.off[b] = Sp[(size_t)z << pl]; big.cnt[b] = Sp[(size_t)(z + 1) << pl] - Sp[(size_t)z << pl]; big.chunk0[b] = ch0[z]; big.wi[b] = id[z]; big.span[b] = w.span; big.z2base[b] = zb2[z]; big.sg[b] = (uint32_t)sg;
+        big.eb[b] = pf_sub_geom(Sp[(size_t)(z + 1) << pl] - Sp[(size_t)z << pl], sg, g.lgC, pf_cells_in(z, g, zrow));
+        { const uint32_t row = zrow[z], t = g.rowtab[row];                             // (row, cell) of the big z's first cell, inside its span
+          big.rcl0[b] = (uint32_t)((((unsigned long long)row << g.cbits) | ((unsigned long long)(z - (t >> 5)) << sg)) & ((1ull << g.sb) - 1ull)); }
+        w.span |= PF_BIG; w.aux = b;
+    }
+    wi[id[z]] = w;
+}
+// level 2: cells z2 = z2base[b] + sub-cell; the big z of a cell by bisection
+__device__ __forceinline__ uint32_t pf_big_of(const uint32_t* __restrict__ z2base, uint32_t n_big, uint32_t z2) {
+    uint32_t lo = 0, hi = n_big;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (z2base[mid] <= z2) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void k_pf_plan2(const uint32_t* __restrict__ S, uint32_t Z, PartGeom g, const uint32_t* __restrict__ z2base, uint32_t n_big, uint32_t* __restrict__ fs, uint32_t* __restrict__ ctr) {
+    const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z > Z) return;
+    if (z == Z) { fs[z] = 0; return; }
+    const uint32_t C = 1u << g.lgC, CAP = 2u << g.lgC;
+    const uint32_t s = S[z], c = S[z + 1] - s, sp = z ? S[z - 1] : 0u, cp = z ? s - sp : 0u;
+    const bool first = z2base[pf_big_of(z2base, n_big, z)] == z;                          // first sub-cell of a big z
+    fs[z] = (z == 0 || first || (s >> g.lgC) != (sp >> g.lgC) || c > C || cp > C) ? 1u : 0u;
+    if (c > CAP) { ctr[5] = 1u; atomicMax(&ctr[10], c); }                                // a sub-cell the geometry could not bring under CAP
+}
+__global__ void k_pf_emit2(const uint32_t* __restrict__ S, uint32_t Z, const uint32_t* __restrict__ id, uint32_t n_big, WorkItem* __restrict__ wi, BigArrays big) {
+    const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    if (z == 0) { wi[id[Z]].off = S[Z]; wi[id[Z]].span = 0; wi[id[Z]].aux = 0xffffffffu; big.first2[n_big] = id[Z]; }
+    if (id[z + 1] == id[z]) return;
+    const uint32_t b = pf_big_of(big.z2base, n_big, z);
+    WorkItem w; w.off = S[z]; w.span = big.span[b]; w.aux = b;
+    // the (row, cell) of the item's first sub-cell, and whether earlier parts of that cell (earlier items) hold keys: its count then
+    // continues the entry those items produced (k_pf_bucket decides, k_pf_write adds)
+    const uint32_t local = z - big.z2base[b], eb = big.eb[b] & 31u, tb = big.eb[b] >> 5, cell0 = big.z2base[b] + ((local >> eb) << eb);
+    w.pad = (big.rcl0[b] + ((local >> eb) << tb)) | ((S[z] - S[cell0]) ? PF_CONT : 0u);
+    if (big.z2base[b] == z) big.first2[b] = id[z];
+    wi[id[z]] = w;
+}
+
+// ---- one block per work item ------------------------------------------------------------------------------------------------
+// res[off + i] = (low sb bits of (row, cell)) << 16 | distinct keys, i < nnz, in (row, cell) order; nnz_out[w] = nnz
+__global__ __launch_bounds__(PF_THREADS) void k_pf_bucket(const unsigned long long* __restrict__ keys, const WorkItem* __restrict__ wi, int ubits, int sb,
+                                                          uint32_t* __restrict__ res, uint32_t* __restrict__ nnz_out, uint32_t* __restrict__ cont_out, uint32_t* __restrict__ ctr) {
+    // nnz_out[w] = entries that open a new (row, cell); cont_out[w] (level 2) = 1 when the item's first entry continues the last entry
+    // of the items before it (a (row, cell) cut into UMI-hash parts that fell into several items)
+    extern __shared__ unsigned long long pf_smem[];
+    unsigned long long* set = pf_smem;                                     // phase 1: PF_SLOTS slots
+    uint32_t* cnt32 = reinterpret_cast<uint32_t*>(pf_smem);                // later (the set is dead): PF_CAP_MAX 16-bit counters
+    uint32_t* stage = cnt32 + PF_CAP_MAX / 2;                              //        the item's output, PF_CAP_MAX entries
+    uint32_t* wpre = stage + PF_CAP_MAX;                                   //        prefix popcount of every bitmap word (<= 2048 words)
+    uint32_t* bm = reinterpret_cast<uint32_t*>(pf_smem + PF_SLOTS);        // 2^sb bits
+    static_assert(PF_CAP_MAX * 2 + PF_CAP_MAX * 4 + PF_BM_WORDS_MAX * 4 <= PF_SLOTS * 8, "the late arrays alias the set");
+    __shared__ uint32_t s_wave[PF_THREADS / 64];
+    const int tid = threadIdx.x;
+    const WorkItem me = wi[blockIdx.x];
+    const uint32_t off = me.off, n = wi[blockIdx.x + 1].off - off;
+    if (me.span & PF_BIG) return;                                          // level 1: its keys went through level 2 (k_pf_bignnz fills nnz_out)
+    if (n == 0) { if (tid == 0) { nnz_out[blockIdx.x] = 0; if (cont_out) cont_out[blockIdx.x] = 0; } return; }
+    if (n > (uint32_t)PF_CAP_MAX) { if (tid == 0) { ctr[7] = 1u; nnz_out[blockIdx.x] = 0; if (cont_out) cont_out[blockIdx.x] = 0; } return; }   // cannot happen (k_pf_plan); never index out of the LDS arrays
+    const uint32_t bmask = (1u << sb) - 1u;
+    const int n_words = 1 << (sb - 5);
+    unsigned long long k[PF_KPT];
+#pragma unroll
+    for (int q = 0; q < PF_KPT; q++) { const uint32_t i = q * PF_THREADS + tid; k[q] = i < n ? keys[off + i] : ~0ull; }
+    for (int s = tid; s < PF_SLOTS; s += PF_THREADS) set[s] = ~0ull;
+    for (int s = tid; s < n_words; s += PF_THREADS) bm[s] = 0u;
+    __syncthreads();
+    uint32_t win = 0;                                                      // bit q: this thread's key q is the first occurrence of its (row, cell, umi)
+#pragma unroll
+    for (int q = 0; q < PF_KPT; q++) {
+        if ((uint32_t)(q * PF_THREADS + tid) >= n) continue;
+        const unsigned long long key = k[q];
+        const uint32_t rcl = (uint32_t)(key >> ubits) & bmask;
+        atomicOr(&bm[rcl >> 5], 1u << (rcl & 31));
+        uint32_t slot = set_slot<PF_SLOTS>(key);
+        for (;;) {                                                         // load <= 0.5: ends
+            const unsigned long long prev = atomicCAS(&set[slot], ~0ull, key);
+            if (prev == ~0ull) { win |= 1u << q; break; }
+            if (prev == key) break;
+            slot = (slot + 1) & (PF_SLOTS - 1);
+        }
+    }
+    __syncthreads();                                                       // set dead from here on: cnt32 / stage / wpre alias it
+    // bitmap words, blocked over the threads (wpt consecutive words each; sb >= 14 with 512 threads: 1 - 4 words)
+    const int wpt = (n_words + PF_THREADS - 1) / PF_THREADS;
+    const int w0 = tid * wpt;
+    uint32_t pc = 0;
+    for (int i = 0; i < wpt; i++) if (w0 + i < n_words) pc += (uint32_t)__popc(bm[w0 + i]);
+    uint32_t nnz;
+    uint32_t run = block_excl_scan_t<PF_THREADS>(pc, s_wave, nnz);
+    for (int i = 0; i < wpt; i++) if (w0 + i < n_words) { wpre[w0 + i] = run; run += (uint32_t)__popc(bm[w0 + i]); }
+    for (int s = tid; s < PF_CAP_MAX / 2; s += PF_THREADS) cnt32[s] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PF_KPT; q++) {
+        if (!(win & (1u << q))) continue;
+        const uint32_t rcl = (uint32_t)(k[q] >> ubits) & bmask;
+        const uint32_t rank = wpre[rcl >> 5] + (uint32_t)__popc(bm[rcl >> 5] & ((1u << (rcl & 31)) - 1u));
+        atomicAdd(&cnt32[rank >> 1], 1u << ((rank & 1u) * 16));
+    }
+    __syncthreads();
+    for (int i = 0; i < wpt; i++) {
+        if (w0 + i >= n_words) break;
+        uint32_t bits = bm[w0 + i];
+        run = wpre[w0 + i];
+        while (bits) {
+            const uint32_t b = (uint32_t)__builtin_ctz(bits); bits &= bits - 1u;
+            const uint32_t c = (cnt32[run >> 1] >> ((run & 1u) * 16)) & 0xffffu;
+            stage[run] = ((uint32_t)((w0 + i) * 32 + b) << 16) | c;
+            run++;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nnz; i += PF_THREADS) res[off + i] = stage[i];
+    if (tid == 0) {
+        const uint32_t cont = (cont_out && (me.pad & PF_CONT) && (stage[0] >> 16) == (me.pad & bmask)) ? 1u : 0u;
+        nnz_out[blockIdx.x] = nnz - cont;
+        if (cont_out) cont_out[blockIdx.x] = cont;
+    }
+}
+
+// non-zeros of a big z = those of its level-2 work items; O2 = exclusive scan of the level-2 counts
+__global__ void k_pf_bignnz(uint32_t n_big, BigArrays big, const uint32_t* __restrict__ O2, uint32_t* __restrict__ nnz1) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_big) return;
+    nnz1[big.wi[b]] = O2[big.first2[b + 1]] - O2[big.first2[b]];
+}
+
+// LIST 1: work items of level 1 (the big ones are skipped), LIST 2: work items of the big z
+template <int LIST>
+__global__ __launch_bounds__(128) void k_pf_write(const WorkItem* __restrict__ wi, const uint32_t* __restrict__ res, const uint32_t* __restrict__ O1, const uint32_t* __restrict__ O2,
+                                                  const uint32_t* __restrict__ cont2, BigArrays big, int cbits, int sb, unsigned long long total, int32_t* __restrict__ out) {
+    // LIST 2: val[] is zero on entry and every count is ADDED: an item's first entry may continue the last entry of earlier items
+    const WorkItem me = wi[blockIdx.x];
+    uint32_t dst, n, cont = 0;
+    if (LIST == 1) { if (me.span & PF_BIG) return; dst = O1[blockIdx.x]; n = O1[blockIdx.x + 1] - dst; }
+    else { const uint32_t b = me.aux; cont = cont2[blockIdx.x]; dst = O1[big.wi[b]] + O2[blockIdx.x] - O2[big.first2[b]] - cont; n = O2[blockIdx.x + 1] - O2[blockIdx.x] + cont; }
+    const unsigned long long hi = (unsigned long long)(me.span & ~PF_BIG) << sb;
+    const unsigned long long cmask = (1ull << cbits) - 1;
+    for (uint32_t i = threadIdx.x; i < n; i += 128) {
+        const uint32_t v = res[me.off + i];
+        const unsigned long long rc = hi | (v >> 16);
+        if (LIST == 1) { out[dst + i] = (int32_t)(rc >> cbits); out[total + dst + i] = (int32_t)(rc & cmask); out[2 * total + dst + i] = (int32_t)(v & 0xffffu); }
+        else {
+            if (!(cont && i == 0)) { out[dst + i] = (int32_t)(rc >> cbits); out[total + dst + i] = (int32_t)(rc & cmask); }   // (the continued entry's row / col: written by the item that opened it)
+            atomicAdd(&out[2 * total + dst + i], (int32_t)(v & 0xffffu));
+        }
+    }
+}
+
+__global__ void k_pf_publish(const uint32_t* __restrict__ src, unsigned long long* __restrict__ host_alias, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) host_alias[i] = src[i];
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------
+static int pf_scan(EngineImpl* im, uint32_t* data, size_t n, uint32_t* bsum, uint32_t* total_out) {       // in place, exclusive
+    const size_t nb = (n + SC_TILE - 1) / SC_TILE;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SC_T), 0, im->s_comp, (const uint32_t*)data, n, bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, im->s_comp, bsum, nb, total_out);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SC_T), 0, im->s_comp, data, n, (const uint32_t*)bsum);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+static inline int pf_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline int pf_bucket_lds(int sb) { return PF_SLOTS * 8 + (1 << sb) / 8; }
+
+// basefc fold of the n keys in the shard slices of im->d_keys -> result matrix 0.  0 = done, PF_FALLBACK = take the radix path
+// (the shard slices are then untouched), < 0 = error.
+static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size_t n) {
+    typedef unsigned long long K;
+    if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;                   // 32-bit offsets
+    int lgC = 0;
+    { const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }   // (test knob: small pages reach every path with small inputs)
+    PartGeom g; g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.n_cells = (uint32_t)im->n_cells;
+    g.sb = std::min(PF_SB_MAX, std::max(kl.cbits, 11));                                    // 14 cell bits: one row per span, a 2 KB bitmap
+    const int lg_min = std::max(0, kl.cbits - g.sb);                                      // a level-1 cell never straddles two spans
+    const int lg_max = std::max(lg_min, std::min(pf_env_int("XCK_FOLD_LGG", 8), kl.cbits));
+    const uint32_t n_rows = (uint32_t)im->n_regions;
+    ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
+    for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
+    const unsigned n_chunks1 = sc.chunk0[NSHARD];
+    const uint32_t stride = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n_chunks1 / 4096));          // the row sample: one piece of 64 keys in `stride`, >= 16 M keys
+    ShardChunks scs = sc;                                                                  // its blocks: PT_CHUNK * stride stream keys each
+    for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((im->cur[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
+    const unsigned n_sample = scs.chunk0[NSHARD];
+    const size_t z_cap = ((size_t)n_rows << lg_min) + 4 * ((n + (size_t)NSHARD * stride * PT_CHUNK) >> lgC) + 64;   // sum of 2^l over the rows (k_pf_rowplan)
+    if (z_cap > (size_t(1) << 24)) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: level-1 cell bound %zu\n", z_cap); return PF_FALLBACK; }
+    const size_t zs_cap = z_cap + 1, rs = (size_t)n_rows + 1;
+    const size_t sb1 = (std::max(zs_cap, rs) + SC_TILE - 1) / SC_TILE + 8;
+    int rc;
+    // ---- workspace 1: level-1 output, row geometry, histogram / flags over the cells
+    const int pl = std::max(0, std::min(pf_env_int("XCK_FOLD_COPIES_LG", 4), 6));            // 2^pl copies of the level-1 counters / cursors
+    const size_t ss_cap = (z_cap << pl) + 1;
+    const size_t sbs = (ss_cap + SC_TILE - 1) / SC_TILE + 8;
+    if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + 3 * (rs * 4 + 256) + 5 * (zs_cap * 4 + 256) + ss_cap * 4 + (sb1 + sbs) * 4 + 64 * 4 + (1 << 16)))) return rc;
+    K* A = im->ws1.get<K>(n);
+    uint32_t* rowcnt = im->ws1.get<uint32_t>(rs); uint32_t* zb = im->ws1.get<uint32_t>(rs); uint32_t* rowtab = im->ws1.get<uint32_t>(rs);
+    uint32_t* S1 = im->ws1.get<uint32_t>(ss_cap); uint32_t* fs = im->ws1.get<uint32_t>(zs_cap); uint32_t* fb = im->ws1.get<uint32_t>(zs_cap);
+    uint32_t* fc = im->ws1.get<uint32_t>(zs_cap); uint32_t* fz = im->ws1.get<uint32_t>(zs_cap); uint32_t* zrow = im->ws1.get<uint32_t>(zs_cap);
+    uint32_t* bsum = im->ws1.get<uint32_t>(sb1 + sbs); uint32_t* ctr = im->ws1.get<uint32_t>(64);
+    if (!A || !rowcnt || !zb || !rowtab || !S1 || !fs || !fb || !fc || !fz || !zrow || !bsum || !ctr) { im->eng->err = "workspace exhausted (partition fold)"; return XCK_E_NOMEM; }
+    g.rowtab = rowtab;
+    unsigned long long* h_ctr = im->h_ctl + CTL_X0; unsigned long long* d_hctr = im->d_hctl + CTL_X0;   // (the k_expand words: unused in basefc mode)
+    BigChunks bc0; memset(&bc0, 0, sizeof bc0);
+    const unsigned gr = (unsigned)((rs + 255) / 256);
+    // ---- row geometry from a sample of the stream
+    HIP_TRY(hipMemsetAsync(rowcnt, 0, rs * 4, im->s_comp));
+    HIP_TRY(hipMemsetAsync(ctr, 0, 64 * 4, im->s_comp));
+    hipLaunchKernelGGL(k_pf_rowhist, dim3(n_sample), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, scs, stride, kl.ubits + kl.cbits, rowcnt);
+    hipLaunchKernelGGL(k_pf_rowplan, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)rowcnt, n_rows, stride, lg_min, lg_max, lgC, zb);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pf_scan(im, zb, rs, bsum, ctr + 8))) return rc;                              // ctr[8] = level-1 cells
+    hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    const uint32_t Z = (uint32_t)h_ctr[8];
+    if ((size_t)Z > z_cap) { im->eng->err = "internal: level-1 cells exceed their bound"; return XCK_E_STATE; }
+    const size_t zs = (size_t)Z + 1;
+    const unsigned gz = (unsigned)((zs + 255) / 256);
+    hipLaunchKernelGGL(k_pf_rowtab, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)zb, n_rows, kl.cbits, rowtab, zrow);
+    // ---- level 1: histogram over the cells, work items
+    const size_t ss = ((size_t)Z << pl) + 1;
+    HIP_TRY(hipMemsetAsync(S1, 0, ss * 4, im->s_comp));
+    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_chunks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pf_scan(im, S1, ss, bsum, nullptr))) return rc;
+    hipLaunchKernelGGL(k_pf_plan1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, fs, fb, fc, fz, ctr);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pf_scan(im, fs, zs, bsum, ctr + 0))) return rc;                              // ctr[0] = level-1 work items
+    if ((rc = pf_scan(im, fb, zs, bsum, ctr + 1))) return rc;                              // ctr[1] = big cells
+    if ((rc = pf_scan(im, fc, zs, bsum, ctr + 2))) return rc;                              // ctr[2] = level-2 chunks
+    if ((rc = pf_scan(im, fz, zs, bsum, ctr + 9))) return rc;                              // ctr[9] = level-2 cells
+    hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    const size_t n_wi1 = h_ctr[0], n_big = h_ctr[1], n_chunks2 = h_ctr[2], n_bigkeys = h_ctr[3], Z2 = h_ctr[9];
+    if (Z2 > (size_t(1) << 26)) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: %zu level-2 cells\n", Z2); return PF_FALLBACK; }
+    const size_t zs2 = Z2 + 1;
+    const size_t wi2_cap = n_big + 3 * (n_bigkeys >> lgC) + 8;
+    const size_t sb2 = (std::max(std::max(zs2, wi2_cap + 1), n_wi1 + 1) + SC_TILE - 1) / SC_TILE + 8;
+    // ---- workspace 2: everything whose size is known now
+    if ((rc = arena_begin(im, im->ws2, (n_wi1 + 1) * (sizeof(WorkItem) + 4) + (n_big + 2) * 4 * 10 + n * 4 + 2 * (zs2 * 4 + 256) + (wi2_cap + 1) * (sizeof(WorkItem) + 8)
+                                       + n_bigkeys * 4 + sb2 * 4 + n * 12 + (1 << 16)))) return rc;
+    WorkItem* wi1 = im->ws2.get<WorkItem>(n_wi1 + 1); uint32_t* nnz1 = im->ws2.get<uint32_t>(n_wi1 + 1);
+    BigArrays big; big.off = im->ws2.get<uint32_t>(n_big + 2); big.cnt = im->ws2.get<uint32_t>(n_big + 2); big.chunk0 = im->ws2.get<uint32_t>(n_big + 2);
+    big.wi = im->ws2.get<uint32_t>(n_big + 2); big.span = im->ws2.get<uint32_t>(n_big + 2); big.first2 = im->ws2.get<uint32_t>(n_big + 2);
+    big.z2base = im->ws2.get<uint32_t>(n_big + 2); big.sg = im->ws2.get<uint32_t>(n_big + 2); big.eb = im->ws2.get<uint32_t>(n_big + 2); big.rcl0 = im->ws2.get<uint32_t>(n_big + 2);
+    uint32_t* res1 = im->ws2.get<uint32_t>(n);
+    uint32_t* S2 = im->ws2.get<uint32_t>(zs2); uint32_t* fs2 = im->ws2.get<uint32_t>(zs2);
+    WorkItem* wi2 = im->ws2.get<WorkItem>(wi2_cap + 1); uint32_t* nnz2 = im->ws2.get<uint32_t>(wi2_cap + 1); uint32_t* cont2 = im->ws2.get<uint32_t>(wi2_cap + 1);
+    uint32_t* res2 = im->ws2.get<uint32_t>(n_bigkeys); uint32_t* bsum2 = im->ws2.get<uint32_t>(sb2);
+    if (!wi1 || !nnz1 || !big.rcl0 || !res1 || !S2 || !fs2 || !wi2 || !nnz2 || !cont2 || !res2 || !bsum2) { im->eng->err = "workspace exhausted (partition fold, stage 2)"; return XCK_E_NOMEM; }
+    hipLaunchKernelGGL(k_pf_emit1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, (const uint32_t*)fs, (const uint32_t*)fb, (const uint32_t*)fc,
+                       (const uint32_t*)fz, wi1, big);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_chunks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1, A);   // (S1 is the cursor array from here on)
+    HIP_TRY(hipGetLastError());
+    const int lds = pf_bucket_lds(g.sb);
+    size_t n_wi2 = 0;
+    K* B = (K*)im->d_keys;                                                                 // level-2 output: the shard slices are dead once level 1 has moved the keys
+    if (n_big) {
+        BigChunks bc; bc.off = big.off; bc.cnt = big.cnt; bc.chunk0 = big.chunk0; bc.z2base = big.z2base; bc.sg = big.sg; bc.eb = big.eb; bc.n_big = (uint32_t)n_big;
+        const unsigned gz2 = (unsigned)((zs2 + 255) / 256);
+        HIP_TRY(hipMemsetAsync(S2, 0, zs2 * 4, im->s_comp));
+        hipLaunchKernelGGL((k_pf_hist<2>), dim3((unsigned)n_chunks2), dim3(PT_THREADS), 0, im->s_comp, (const K*)A, sc, bc, g, 0, S2);
+        HIP_TRY(hipGetLastError());
+        if ((rc = pf_scan(im, S2, zs2, bsum2, nullptr))) return rc;
+        hipLaunchKernelGGL(k_pf_plan2, dim3(gz2), dim3(256), 0, im->s_comp, (const uint32_t*)S2, (uint32_t)Z2, g, (const uint32_t*)big.z2base, (uint32_t)n_big, fs2, ctr);
+        HIP_TRY(hipGetLastError());
+        if ((rc = pf_scan(im, fs2, zs2, bsum2, ctr + 4))) return rc;                       // ctr[4] = level-2 work items
+        hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(im->s_comp));
+        if (h_ctr[5]) {                                                                   // (the shard slices still hold the keys: level 2 has not written yet)
+            if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: a level-2 sub-cell holds %llu keys (more than %d): n=%zu cells=%u big=%zu (%zu keys, %zu sub-cells)\n",
+                                                    h_ctr[10], 2 << lgC, n, Z, n_big, n_bigkeys, Z2);
+            return PF_FALLBACK;
+        }
+        n_wi2 = h_ctr[4];
+        if (n_wi2 > wi2_cap) { im->eng->err = "internal: level-2 work items exceed their bound"; return XCK_E_STATE; }
+        hipLaunchKernelGGL(k_pf_emit2, dim3(gz2), dim3(256), 0, im->s_comp, (const uint32_t*)S2, (uint32_t)Z2, (const uint32_t*)fs2, (uint32_t)n_big, wi2, big);
+        hipLaunchKernelGGL((k_pf_part<2>), dim3((unsigned)n_chunks2), dim3(PT_THREADS), 0, im->s_comp, (const K*)A, sc, bc, g, 0, S2, B);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)n_wi2), dim3(PF_THREADS), lds, im->s_comp, (const K*)B, (const WorkItem*)wi2, kl.ubits, g.sb, res2, nnz2, cont2, ctr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(nnz2 + n_wi2, 0, 4, im->s_comp));
+        if ((rc = pf_scan(im, nnz2, n_wi2 + 1, bsum2, nullptr))) return rc;                // nnz2 -> O2
+        hipLaunchKernelGGL(k_pf_bignnz, dim3((unsigned)((n_big + 255) / 256)), dim3(256), 0, im->s_comp, (uint32_t)n_big, big, (const uint32_t*)nnz2, nnz1);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)n_wi1), dim3(PF_THREADS), lds, im->s_comp, (const K*)A, (const WorkItem*)wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(nnz1 + n_wi1, 0, 4, im->s_comp));
+    if ((rc = pf_scan(im, nnz1, n_wi1 + 1, bsum2, ctr + 6))) return rc;                    // nnz1 -> O1, ctr[6] = non-zeros of the matrix
+    hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    if (h_ctr[7]) { im->eng->err = "internal: a work item of the partition fold exceeds its capacity"; return XCK_E_STATE; }
+    const size_t total = h_ctr[6];
+    if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: n=%zu rows=%u cells=%u (sample stride %u) items=%zu big=%zu (%zu keys, %zu sub-cells, %zu items) nnz=%zu C=%d sb=%d\n",
+                                            n, n_rows, Z, stride, n_wi1, n_big, n_bigkeys, Z2, n_wi2, total, 1 << lgC, g.sb);
+    im->res_nnz[0] = total; im->d_res[0] = nullptr;
+    if (!total) return 0;
+    if ((rc = res_reserve(im, 0, total))) return rc;
+    int32_t* d_o = im->ws2.get<int32_t>(total * 3);
+    if (!d_o) { im->eng->err = "workspace exhausted (COO)"; return XCK_E_NOMEM; }
+    if (n_wi2) HIP_TRY(hipMemsetAsync(d_o + 2 * total, 0, total * sizeof(int32_t), im->s_comp));      // level-2 counts are added
+    hipLaunchKernelGGL((k_pf_write<1>), dim3((unsigned)n_wi1), dim3(128), 0, im->s_comp, (const WorkItem*)wi1, (const uint32_t*)res1, (const uint32_t*)nnz1, (const uint32_t*)nnz2, (const uint32_t*)nullptr, big,
+                       kl.cbits, g.sb, (unsigned long long)total, d_o);
+    if (n_wi2) hipLaunchKernelGGL((k_pf_write<2>), dim3((unsigned)n_wi2), dim3(128), 0, im->s_comp, (const WorkItem*)wi2, (const uint32_t*)res2, (const uint32_t*)nnz1, (const uint32_t*)nnz2, (const uint32_t*)cont2, big,
+                                  kl.cbits, g.sb, (unsigned long long)total, d_o);
+    HIP_TRY(hipGetLastError());
+    return copy_out(im, 0, d_o, total);
+}
