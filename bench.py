@@ -19,12 +19,24 @@ node share the output directory).  --gather restores the exchange of the sparse 
 one padded gather of the blocks still resident in HBM (RCCL over xGMI) to rank 0, which merges and writes.
 
 Sub-records of the same JSON line:
+  end_to_end_zlib6 / cellranger_shape   the same pipeline (same engine, same tables) on two 50 M-read files that look like what
+                   users hold: BGZF blocks written by zlib level 6 (htslib's default; the headline file is written by this repo's own
+                   fast compressor), and on top of that Cell Ranger's record shape (39-character read names, 16 aux tags with CB / UB
+                   near the end: twice the bytes per record) - with their ratio to the headline rate.
   roofline         dominant hand-written kernel on the HBM-resident form of the same workload shape (500 M synthetic
                    reads generated on the device; one fused launch per pass), HIP-event time per launch against SURVEY
                    section 8d's algorithmic bytes;  `device_resident` holds that pass's rate and stage times.
   cpu_baseline     oracle/xck_oracle.c (CPU restatement of the reference's per-region / per-SNP loops) on whole
-                   contigs of the SAME BAM, and the GPU rows of those contigs compared with it bit for bit.
+                   contigs of the SAME BAM, and the GPU rows of those contigs compared with it bit for bit; `value` times the
+                   counting alone (records already decoded), `value_with_decode` the host decode of those contigs + the counting -
+                   the boundary the headline has.
+
+--workload well    BASELINE.json configs[4]: 384 per-cell BAMs (paired-end 2 x 75, no CB / UB: the column is the BAM, the key the
+                   read name), basefc + pileup from one decode of every file, matrices compared with the oracle on sampled contigs.
+--selfcheck        N > 1: before the timed pass the N ranks count a smaller file together and rank 0 counts it alone; the eight
+                   output files must be byte-identical (exit code 3 otherwise).
 """
+import hashlib
 import argparse
 import json
 import os
@@ -66,32 +78,149 @@ def host_cores():
     return max(1, n), max(1, threads)
 
 
-def make_inputs(args, work, threads, log):
-    """Tables + the synthetic BAM (generated once per work dir and size; reused by later runs / other ranks)."""
+def writer_name(level):
+    return "deflate_fast (this repo's own compressor, csrc/deflate_fast.h)" if level <= 0 else "zlib level %d (what htslib / samtools write)" % level
+
+
+def gen_bam(args, work, bam, reads, level, shape, threads, log, seed=11):
+    """One synthetic BAM through csrc/xck_synth_bam (tables in `work`); generated once per path.  -> True if it was generated now."""
+    ok = bam + ".ok"
+    if os.path.isfile(ok) and os.path.isfile(bam) and os.path.isfile(bam + ".bai"):
+        return False
+    t0 = time.time()
+    env = dict(os.environ)
+    env.pop("XCK_SYNTH_SHAPE", None)
+    if shape:
+        env["XCK_SYNTH_SHAPE"] = shape
+    subprocess.check_call([os.path.join(ROOT, "xcltk_amd", "csrc", "xck_synth_bam"), bam, work + "/contigs.tsv",
+                           work + "/regions.tsv", work + "/barcodes.tsv", str(reads), str(seed), str(threads), str(level)],
+                          stderr=subprocess.DEVNULL if not args.verbose else None, env=env)
+    open(ok, "w").write("ok\n")
+    log("%s generated in %.1f s: %.2f GB" % (os.path.basename(bam), time.time() - t0, os.path.getsize(bam) / 1e9))
+    return True
+
+
+def make_tables_files(args, work, n_cells):
+    """Tables (regions, SNPs, contig names, barcodes) and their files for the generator."""
     os.makedirs(work, exist_ok=True)
     regions, snps, names = soa.make_tables(args.genes, args.snps, soa.HG38_LENGTHS, seed=2)
     rng = np.random.default_rng(7)
-    bcs = sorted({"".join("ACGT"[i] for i in rng.integers(0, 4, 16)) + "-1" for _ in range(args.cells)})
-    while len(bcs) < args.cells:                            # (a duplicate draw: top up)
+    bcs = sorted({"".join("ACGT"[i] for i in rng.integers(0, 4, 16)) + "-1" for _ in range(n_cells)})
+    while len(bcs) < n_cells:                               # (a duplicate draw: top up)
         bcs = sorted(set(bcs) | {"".join("ACGT"[i] for i in rng.integers(0, 4, 16)) + "-1"})
+    with open(work + "/contigs.tsv.tmp%d" % os.getpid(), "w") as fp:
+        fp.write("".join("chr%s\t%d\n" % (n, l) for n, l in zip(names, soa.HG38_LENGTHS)))
+    os.replace(work + "/contigs.tsv.tmp%d" % os.getpid(), work + "/contigs.tsv")
+    with open(work + "/regions.tsv.tmp%d" % os.getpid(), "w") as fp:
+        fp.write("".join("chr%s\t%d\t%d\t%s\n" % r for r in regions))
+    os.replace(work + "/regions.tsv.tmp%d" % os.getpid(), work + "/regions.tsv")
+    with open(work + "/barcodes.tsv.tmp%d" % os.getpid(), "w") as fp:
+        fp.write("".join(b + "\n" for b in bcs))
+    os.replace(work + "/barcodes.tsv.tmp%d" % os.getpid(), work + "/barcodes.tsv")
+    return regions, snps, names, bcs
+
+
+def make_inputs(args, work, threads, log, generate=True):
+    """Tables + the synthetic BAM of the headline (generated once per work dir and size; reused by later runs / other ranks)."""
+    regions, snps, names, bcs = make_tables_files(args, work, args.cells)
     bam = os.path.join(work, "synth_%d_%d_l%d.bam" % (args.reads, args.cells, args.level))
-    ok = bam + ".ok"
-    fresh = False
-    if not (os.path.isfile(ok) and os.path.isfile(bam) and os.path.isfile(bam + ".bai")):
-        t0 = time.time()
-        with open(work + "/contigs.tsv", "w") as fp:
-            fp.write("".join("chr%s\t%d\n" % (n, l) for n, l in zip(names, soa.HG38_LENGTHS)))
-        with open(work + "/regions.tsv", "w") as fp:
-            fp.write("".join("chr%s\t%d\t%d\t%s\n" % r for r in regions))
-        with open(work + "/barcodes.tsv", "w") as fp:
-            fp.write("".join(b + "\n" for b in bcs))
-        subprocess.check_call([os.path.join(ROOT, "xcltk_amd", "csrc", "xck_synth_bam"), bam, work + "/contigs.tsv",
-                               work + "/regions.tsv", work + "/barcodes.tsv", str(args.reads), "11", str(threads), str(args.level)],
-                              stderr=subprocess.DEVNULL if not args.verbose else None)
-        open(ok, "w").write("ok\n")
-        fresh = True
-        log("BAM generated in %.1f s: %.1f GB" % (time.time() - t0, os.path.getsize(bam) / 1e9))
+    fresh = gen_bam(args, work, bam, args.reads, args.level, "", threads, log) if generate else False
     return regions, snps, names, bcs, bam, fresh
+
+
+def bgzf_inflated_per_compressed(path, max_blocks=4000):
+    """Inflated bytes per compressed byte over the first BGZF blocks of a file (header fields BSIZE / ISIZE only)."""
+    comp = infl = 0
+    with open(path, "rb") as fp:
+        for _ in range(max_blocks):
+            h = fp.read(18)
+            if len(h) < 18 or h[:4] != b"\x1f\x8b\x08\x04":
+                break
+            bsize = int.from_bytes(h[16:18], "little") + 1
+            fp.seek(bsize - 18 - 4, 1)
+            infl += int.from_bytes(fp.read(4), "little")
+            comp += bsize
+    return infl / comp if comp else 0.0
+
+
+def md5_of(path):
+    h = hashlib.md5()
+    with open(path, "rb") as fp:
+        for blk in iter(lambda: fp.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+MTX_FILES = (("count", "basefc", "matrix.mtx"), ("ad", "baf", "xcltk.AD.mtx"), ("dp", "baf", "xcltk.DP.mtx"), ("oth", "baf", "xcltk.OTH.mtx"))
+
+
+def write_tables(out_dir, regions, cols):
+    for d, reg_fn, col_fn in (("basefc", "features.tsv", "barcodes.tsv"), ("baf", "xcltk.region.tsv", "xcltk.samples.tsv")):
+        os.makedirs(os.path.join(out_dir, d), exist_ok=True)
+        with open(os.path.join(out_dir, d, reg_fn), "w") as fp:
+            fp.write("".join("%s\t%d\t%d\t%s\n" % r for r in regions))
+        with open(os.path.join(out_dir, d, col_fn), "w") as fp:
+            fp.write("".join(b + "\n" for b in cols))
+
+
+def whole_file_pass(eng, bams, out_dir, regions, cols, threads, ctx=None):
+    """One untimed-setup, timed-run pass without slicing: every BAM (this rank's contigs when ctx is given) -> xck_finish -> the four
+    .mtx files + tables.  ctx = dict(rank, world, mask, row_owner, all_reduce_sum, barrier) for a sharded run.  -> (seconds, records, coo)."""
+    rank = ctx["rank"] if ctx else 0
+    if rank == 0:
+        for _, d, _f in MTX_FILES:
+            os.makedirs(os.path.join(out_dir, d), exist_ok=True)
+    if ctx:
+        ctx["barrier"]()
+    eng.reset()
+    n = len(regions)
+    rm = np.arange(1, n + 1, dtype=np.int32)
+    t0 = time.perf_counter()
+    recs = 0
+    for i, bam in enumerate(bams):
+        recs += eng.ingest_bam(bam, sample=i, n_threads=threads, contig_mask=ctx["mask"] if ctx else None, use_index=bool(ctx))
+    t_ing = time.perf_counter() - t0
+    coo = eng.finish(copy=False)
+    t_fin = time.perf_counter() - t0
+    for k, d, f in MTX_FILES:
+        fn = os.path.join(out_dir, d, f)
+        if ctx:
+            write_mtx_sharded(fn, coo[k], rm, ctx["row_owner"], n, len(cols), rank, ctx["all_reduce_sum"], ctx["barrier"], eng.lib)
+        else:
+            eng.write_mtx_arrays(fn, coo[k], rm, n)
+    if rank == 0:
+        write_tables(out_dir, regions, cols)
+    if ctx:
+        ctx["barrier"]()
+    dt = time.perf_counter() - t0
+    return dict(seconds=dt, ingest=t_ing, finish=t_fin), recs, coo
+
+
+def rank_threads(world, local, cores, pool_threads, shared_gpu):
+    """Host decode threads of this rank.  Behind a CPU-time quota (the 1-GPU boxes: 16 CPUs' worth of time) the ranks share it.  Without
+    one, a rank's decoder binds to the NUMA node of its GPU (csrc/bam.cpp), so its budget is that node's CPUs divided by the ranks
+    whose GPUs sit on the same node - not the machine's CPUs divided by all ranks (a node with 6 of 8 GPUs would starve them)."""
+    share = max(1, pool_threads // world)
+    try:
+        n_vis = len(os.sched_getaffinity(0))
+        if cores < n_vis or shared_gpu or world == 1:          # quota (or a test rehearsal on one GPU): an even share of it
+            return share
+
+        def node_of(i):
+            pr = torch.cuda.get_device_properties(i)
+            bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            return int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        nodes = [node_of(i) for i in range(world)]
+        mine = nodes[local]
+        if mine < 0:
+            return share
+        cpus = 0
+        for part in open("/sys/devices/system/node/node%d/cpulist" % mine).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += int(b or a) - int(a) + 1
+        return max(1, cpus // max(1, nodes.count(mine)))
+    except Exception:
+        return share
 
 
 def warm_page_cache(path):
@@ -123,6 +252,12 @@ def main():
                     "its k_join launches are the 500 M-read launches the roofline is computed from)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--sub-reads", type=int, default=50_000_000, help="records of the two side files (zlib level 6; Cell Ranger record shape); 0 = skip the sub-records")
+    ap.add_argument("--workload", default="10x", choices=["10x", "well"], help="10x: BASELINE configs[2] (default); well: configs[4], 384 per-cell BAMs")
+    ap.add_argument("--well-bams", type=int, default=384)
+    ap.add_argument("--well-reads", type=int, default=2_000_000, help="records per per-cell BAM (--workload well)")
+    ap.add_argument("--selfcheck", action="store_true", help="N > 1: first count a --selfcheck-reads file with N ranks and with rank 0 alone; the output files must be identical")
+    ap.add_argument("--selfcheck-reads", type=int, default=50_000_000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,7 +296,13 @@ def main():
         torch.cuda.synchronize()
 
     cores, pool_threads = host_cores()
-    threads = args.threads if args.threads > 0 else max(1, pool_threads // world)
+    threads = args.threads if args.threads > 0 else rank_threads(world, local, cores, pool_threads, shared_gpu)
+
+    if args.workload == "well":
+        if world != 1:
+            sys.exit("--workload well is a single-GPU run here (shard it by BAM across GPUs: disjoint columns, SURVEY 8e)")
+        print(json.dumps(well_workload(args, dev_idx, threads, cores, log)))
+        return
 
     if args.resident_only:                                     # profiling aid, N = 1: no BAM, no files
         if world != 1:
@@ -202,6 +343,39 @@ def main():
         os.makedirs(os.path.join(out_dir, "basefc"), exist_ok=True)
         os.makedirs(os.path.join(out_dir, "baf"), exist_ok=True)
     gatherer = BlockGatherer(world, rank, device, backend_is_nccl=not shared_gpu) if world > 1 and args.gather else None
+
+    # ---- --selfcheck: the N ranks together against rank 0 alone on a smaller file, before anything is timed ----
+    selfcheck = None
+    if args.selfcheck and world > 1:
+        def all_reduce_sum_sc(x):
+            t_ = torch.from_numpy(np.ascontiguousarray(x)).to(gather_device)
+            dist.all_reduce(t_)
+            return t_.cpu().numpy()
+        bam_sc = os.path.join(args.work, "synth_%d_%d_l%d.bam" % (args.selfcheck_reads, args.cells, args.level))
+        if rank == 0:
+            gen_bam(args, args.work, bam_sc, args.selfcheck_reads, args.level, "", cores, log)
+        barrier()
+        counts_sc = eng.contig_record_counts(bam_sc)
+        owner_sc = contig_owner(names, counts_sc.astype(np.float64) + 1e-9, world)
+        ctx = dict(rank=rank, world=world, mask=owner_sc == rank, row_owner=owner_sc[row_contig], all_reduce_sum=all_reduce_sum_sc, barrier=dist.barrier)
+        dir_n, dir_1 = os.path.join(args.work, "selfcheck_n%d" % world), os.path.join(args.work, "selfcheck_n1")
+        whole_file_pass(eng, [bam_sc], dir_n, regions, bcs, threads, ctx)
+        bad = 0
+        if rank == 0:
+            whole_file_pass(eng, [bam_sc], dir_1, regions, bcs, max(threads, min(cores, pool_threads)), None)
+            diff = [f for _, d, f in MTX_FILES if md5_of(os.path.join(dir_n, d, f)) != md5_of(os.path.join(dir_1, d, f))]
+            bad = len(diff)
+            selfcheck = dict(reads=int(counts_sc.sum()), ranks=world, files_compared=len(MTX_FILES), identical=not diff, differing=diff)
+            log("selfcheck: %s" % selfcheck)
+        flag = torch.tensor([bad], dtype=torch.int64, device=gather_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if rank == 0:
+                sys.stderr.write("bench.py --selfcheck: the %d-rank output differs from the single-rank output: %s\n" % (world, selfcheck["differing"]))
+            dist.destroy_process_group()
+            sys.exit(3)
+        eng.reset()
+        barrier()
 
     # ---- the pass: warmup + steps slices of this rank's records ----
     n_slices = max(1, args.warmup + args.steps)
@@ -283,7 +457,8 @@ def main():
     mtx_bytes = sum(os.path.getsize(os.path.join(out_dir, d, f)) for d, f in (("basefc", "matrix.mtx"), ("baf", "xcltk.AD.mtx"), ("baf", "xcltk.DP.mtx"), ("baf", "xcltk.OTH.mtx")))
     e2e = dict(records_in_bam=n_total, records_decoded=decoded_all, records_timed=timed_all, seconds=round(dt, 3),
                phase_seconds={k: round(v, 3) for k, v in marks.items()}, host_threads_per_rank=threads, host_cores=cores,
-               bam_gb=round(bam_bytes / 1e9, 2), bam_bytes_per_record=round(bam_bytes / max(n_total, 1), 1), bgzf_level=args.level,
+               bam_gb=round(bam_bytes / 1e9, 2), bam_bytes_per_record=round(bam_bytes / max(n_total, 1), 1), bgzf_writer=writer_name(args.level),
+               inflated_bytes_per_record=round(bgzf_inflated_per_compressed(bam) * bam_bytes / max(n_total, 1), 1),
                mtx_output_mb=round(mtx_bytes / 1e6, 1), engine_setup_s=round(setup_s, 2),
                engine_ms=dict(h2d=round(stats["ms_h2d"], 1), join=round(stats["ms_join"], 1), fold=round(stats["ms_sort"], 1), d2h=round(stats["ms_d2h"], 1)),
                hits=dict(accepted=int(stats["n_hits"]), after_lds_dedup=int(stats["n_hits_unique"])))
@@ -293,6 +468,25 @@ def main():
     cpu = None
     if args.cpu_sample > 0 and world == 1:
         cpu = cpu_baseline(args, eng, bam, names, regions, snps, bcs, counts, coo, row_contig, threads, cores, log)
+
+    # ---- the same pipeline on files that look like a user's: zlib-6 blocks; Cell Ranger's record shape on top ----
+    subs = {}
+    if args.sub_reads > 0 and world == 1:
+        for key, level, shape, what in (("end_to_end_zlib6", 6, "", "the headline's record shape (12-character names, tags NH CB UB), BGZF blocks by zlib level 6"),
+                                        ("cellranger_shape", 6, "cellranger", "Cell Ranger's record shape: 39-character read names, 16 aux tags (NH HI AS nM RE xf li RG TX GX GN CR CY CB UR UY UB), "
+                                                                              "BGZF blocks by zlib level 6")):
+            bam2 = os.path.join(args.work, "synth_%d_%d_l%d%s.bam" % (args.sub_reads, args.cells, level, "_" + shape if shape else ""))
+            if not gen_bam(args, args.work, bam2, args.sub_reads, level, shape, cores, log):
+                warm_page_cache(bam2)
+            tm, n2, _ = whole_file_pass(eng, [bam2], os.path.join(args.work, "out_" + key), regions, bcs, threads)
+            b2 = os.path.getsize(bam2)
+            subs[key] = dict(value=round(n2 / tm["seconds"], 1), unit="reads/s", records=n2, seconds=round(tm["seconds"], 3),
+                             phase_seconds=dict(ingest=round(tm["ingest"], 3), finish=round(tm["finish"], 3), write=round(tm["seconds"], 3)),
+                             bam_gb=round(b2 / 1e9, 2), bam_bytes_per_record=round(b2 / max(n2, 1), 1),
+                             inflated_bytes_per_record=round(bgzf_inflated_per_compressed(bam2) * b2 / max(n2, 1), 1),
+                             bgzf_writer=writer_name(level), record_shape=what, ratio_to_headline=round(n2 / tm["seconds"] / value, 3),
+                             note="one untimed-setup pass over the whole file (no slicing), same engine / tables / threads as the headline")
+            log("%s: %.2f M reads/s (%.2f of the headline)" % (key, subs[key]["value"] / 1e6, subs[key]["ratio_to_headline"]))
     eng.close()
 
     # ---- HBM-resident sub-record + roofline of the dominant kernel ----
@@ -308,10 +502,103 @@ def main():
                                      "24 hg38 contigs; end to end BAM -> basefc matrix.mtx + AD/DP/OTH.mtx from one decode; a step = 1/%d of the file's records, "
                                      "the last step also folds and writes" % (cfg_name, n_total, bam_bytes / 1e9, len(bcs), len(snps), len(regions), n_slices),
                             parallelism="contig-shard x%d (LPT on .bai counts)" % world, host_threads_per_rank=threads, nnz=nnz),
-                end_to_end=e2e, device_resident=resident, roofline=roofline, cpu_baseline=cpu)
+                end_to_end=e2e, end_to_end_zlib6=subs.get("end_to_end_zlib6"), cellranger_shape=subs.get("cellranger_shape"),
+                device_resident=resident, roofline=roofline, cpu_baseline=cpu, selfcheck=selfcheck)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def well_workload(args, dev_idx, threads, cores, log):
+    """BASELINE.json configs[4]: N per-cell BAMs (SMART-seq style: paired-end 2 x 75, mates share the read name, no CB / UB tags) through
+    the multi-BAM ingest path - column = index of the BAM, key = read name (interned per file), basefc + pileup from ONE decode of every
+    file - to the four .mtx files; reference path: xcltk/rdr/fc/core.py:153-170 (the loop over sam_list), rdr/fc/mcount.py:37-42,120-127.
+    The matrices' rows of the sampled contigs are compared with the oracle (same files decoded again by the host decoder) in the run."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    import util
+    work = os.path.join(args.work, "well")
+    n_snps = min(args.snps, 100_000)
+    a2 = argparse.Namespace(**vars(args)); a2.snps = n_snps
+    regions, snps, names, _ = make_tables_files(a2, work, 1)
+    cols = ["cell%03d" % i for i in range(args.well_bams)]
+    t0 = time.time()
+    bams = [os.path.join(work, "cell_%03d_%d_l%d.bam" % (i, args.well_reads, args.level)) for i in range(args.well_bams)]
+    from concurrent.futures import ThreadPoolExecutor              # small files: four generator processes side by side
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(lambda ib: gen_bam(a2, work, ib[1], args.well_reads, args.level, "smartseq", max(1, cores // 4), lambda m: None, seed=100 + ib[0]), enumerate(bams)))
+    bam_bytes = sum(os.path.getsize(b) for b in bams)
+    log("%d per-cell BAMs x %d records: %.1f GB, ready after %.1f s" % (len(bams), args.well_reads, bam_bytes / 1e9, time.time() - t0))
+    eng = Engine(capi.XCK_MODE_BOTH, names, regions, len(cols), snps=snps, barcodes=None, cell_tag=None, umi_tag=None,
+                 device=dev_idx, min_include=0.9, min_count=1, min_maf=0, no_dup_hap=True, n_threads=threads, **FILT)
+    out_dir = os.path.join(work, "out")
+    runs = []
+    for rep in range((1 if args.warmup > 0 else 0) + 1):          # one untimed pass (buffers reach their sizes), one timed
+        tm, n_rec, coo = whole_file_pass(eng, bams, out_dir, regions, cols, threads)
+        runs.append((tm, n_rec))
+    tm, n_rec = runs[-1]
+    stats = eng.stats()
+    nnz = {k: int(len(coo[k][0])) for k, _, _ in MTX_FILES}
+    # ---- the oracle on the smallest contigs of every file (up to --cpu-sample records in total), and the GPU's rows of those contigs
+    cpu = None
+    if args.cpu_sample > 0:
+        counts = np.zeros(len(names), dtype=np.int64)
+        for b in bams[:8]:                                         # (the per-contig shares are the same in every file: 8 files estimate them)
+            counts += eng.contig_record_counts(b)
+        scale = len(bams) / 8.0
+        take, tot = [], 0.0
+        for c in sorted(range(len(names)), key=lambda c: (counts[c], c)):
+            if counts[c] == 0:
+                continue
+            if tot >= args.cpu_sample or (take and tot + counts[c] * scale > 2 * args.cpu_sample):
+                break
+            take.append(c); tot += counts[c] * scale
+        mask = np.zeros(len(names), dtype=bool); mask[take] = True
+        cidx = {n: i for i, n in enumerate(names)}
+        row_contig = np.array([cidx[r[0]] for r in regions], dtype=np.int32)
+        dec = Engine(capi.XCK_MODE_BOTH, names, regions, len(cols), snps=snps, barcodes=None, cell_tag=None, umi_tag=None, decode_only=True, n_threads=threads)
+        t_d = time.perf_counter()
+        hb = []
+        for i, b in enumerate(bams):
+            hb += [util.batch_from_dict(d) for d in dec.decode_bam(b, sample=i, contig_mask=mask, use_index=True)]
+        t_dec = time.perf_counter() - t_d
+        dec.close()
+        n_dec = sum(b.n_reads for b, _ in hb)
+        cpu_threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, 16))
+        sample_rows = mask[row_contig]
+        parity, n_cmp, tc = "ok", 0, 0.0
+        for mode, sn, mats in ((capi.XCK_MODE_BASEFC, [], ["count"]), (capi.XCK_MODE_BAF, snps, ["ad", "dp", "oth"])):
+            cfg, keep = O.make_config(mode, names, regions, sn, len(cols), min_include=0.9, min_count=1, min_maf=0, no_dup_hap=True, **FILT)
+            t1 = time.perf_counter()
+            exp = O.run_oracle(cfg, [b for b, _ in hb], n_threads=cpu_threads)
+            tc += time.perf_counter() - t1
+            for m in mats:
+                g = coo[m]
+                sel = sample_rows[g[0]]
+                n_cmp += int(sel.sum())
+                if not all(np.array_equal(g[j][sel], exp[m][j]) for j in range(3)):
+                    parity = "MISMATCH in %s" % m
+        if parity != "ok":
+            sys.exit("bench.py --workload well: GPU result differs from the oracle on the sampled contigs: " + parity)
+        cpu = dict(value=round(n_dec / tc, 1), unit="reads/s", cores=cpu_threads, kind="port", seconds=round(tc, 2),
+                   value_with_decode=round(n_dec / (tc + t_dec), 1), decode_seconds=round(t_dec, 2), decode_threads=threads,
+                   sample="the %d records of contig(s) %s of all %d BAMs, basefc + pileup, oracle/xck_oracle.c over %d threads" % (n_dec, ",".join(names[c] for c in take), len(bams), cpu_threads),
+                   gpu_rows_vs_oracle="%s (%d non-zeros of the four matrices compared bit for bit)" % (parity, n_cmp))
+    eng.close()
+    value = n_rec / tm["seconds"]
+    return dict(metric="reads/sec into AD/DP+basefc matrices", value=round(value, 1), unit="reads/s", n_gpus=1, steps=1, warmup=len(runs) - 1,
+                ms_per_step=round(tm["seconds"] * 1e3, 1), higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int64", data="synthetic",
+                config=dict(workload="BASELINE.json configs[4]: %d per-cell BAMs x %d records (paired-end 2 x 75, mates share the read name, no CB / UB tags; %.1f GB BGZF by %s, "
+                                     "page cache), %d het SNPs, %d genes, 24 hg38 contigs; multi-BAM ingest (column = BAM, key = read name), basefc matrix.mtx + AD/DP/OTH.mtx from one "
+                                     "decode of every file; a step = the whole list" % (len(bams), args.well_reads, bam_bytes / 1e9, writer_name(args.level), len(snps), len(regions)),
+                            parallelism="1 GPU (N GPUs: shard the list by BAM - disjoint columns, SURVEY 8e)", host_threads_per_rank=threads, nnz=nnz),
+                end_to_end=dict(records=n_rec, seconds=round(tm["seconds"], 3), phase_seconds=dict(ingest=round(tm["ingest"], 3), finish=round(tm["finish"], 3), write=round(tm["seconds"], 3)),
+                                warmup_pass_seconds=round(runs[0][0]["seconds"], 3), bam_gb=round(bam_bytes / 1e9, 2), bam_bytes_per_record=round(bam_bytes / max(n_rec, 1), 1),
+                                bgzf_writer=writer_name(args.level), host_threads_per_rank=threads, host_cores=cores, key_bits=int(stats["key_bits"]), basefc_fold_path=int(stats["fold_path"]),
+                                engine_ms=dict(h2d=round(stats["ms_h2d"], 1), join=round(stats["ms_join"], 1), fold=round(stats["ms_sort"], 1), d2h=round(stats["ms_d2h"], 1)),
+                                hits=dict(accepted=int(stats["n_hits"]), after_lds_dedup=int(stats["n_hits_unique"]))),
+                roofline=None, cpu_baseline=cpu)
 
 
 def cpu_baseline(args, eng, bam, names, regions, snps, bcs, counts, coo, row_contig, threads, cores, log):
@@ -333,7 +620,9 @@ def cpu_baseline(args, eng, bam, names, regions, snps, bcs, counts, coo, row_con
     mask[take] = True
     dec = Engine(capi.XCK_MODE_BOTH, names, regions, len(bcs), snps=snps, barcodes=bcs, cell_tag="CB", umi_tag="UB",
                  decode_only=True, n_threads=threads)
+    t_d = time.perf_counter()                                  # host decode of the sampled contigs (BGZF inflate + record parse, `threads` threads)
     hb = [util.batch_from_dict(d) for d in dec.decode_bam(bam, contig_mask=mask, use_index=True)]
+    t_dec = time.perf_counter() - t_d
     dec.close()
     n_dec = sum(b.n_reads for b, _ in hb)
     cpu_threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(cores, 16))
@@ -356,7 +645,11 @@ def cpu_baseline(args, eng, bam, names, regions, snps, bcs, counts, coo, row_con
     return dict(value=round(n_dec / tc, 1), unit="reads/s", cores=cpu_threads, kind="port",
                 sample="the %d records of contig(s) %s of the same BAM (decoded to SoA batches before the timed call), basefc + pileup, "
                        "oracle/xck_oracle.c (xo_run_mt: region chunks over %d threads)" % (n_dec, ",".join(names[c] for c in take), cpu_threads),
-                seconds=round(tc, 2), gpu_rows_vs_oracle="%s (%d non-zeros of the end-to-end matrices compared bit for bit)" % (parity, n_cmp))
+                seconds=round(tc, 2),
+                value_with_decode=round(n_dec / (tc + t_dec), 1), decode_seconds=round(t_dec, 2), decode_threads=threads,
+                with_decode_note="value_with_decode = the same records / (host decode of those contigs by this repo's decoder, %d threads behind %d CPUs, "
+                                 "copied out as numpy batches + the oracle's counting): the CPU-only form of the headline's boundary, minus the .mtx text" % (threads, cores),
+                gpu_rows_vs_oracle="%s (%d non-zeros of the end-to-end matrices compared bit for bit)" % (parity, n_cmp))
 
 
 def device_resident(args, names, regions, snps, dev_idx, device, log):

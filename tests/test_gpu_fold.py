@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def fold_env():
-    saved = {k: os.environ.get(k) for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG")}
+    saved = {k: os.environ.get(k) for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT")}
     yield os.environ
     for k, v in saved.items():
         if v is None:
@@ -137,3 +137,27 @@ def test_unplaceable_input_hands_over_to_the_sort_fold(fold_env):
     cfg, keep = O.make_config(capi.XCK_MODE_BASEFC, names, regions, [], 1, **cfg_kw)
     exp = O.run_oracle(cfg, [b for b, _ in batches])
     util.assert_coo_equal(got, exp, ["count"])
+
+
+def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
+    """The pileup's (key, value) hits: row partition + one LDS sort per item (XCK_PILEUP_SORT=partition; opt-in, it is slower than the
+    radix sort at configs[2]) against the radix sort (default) and the oracle, at the default page size and at small ones."""
+    regions, snps, names = soa.make_tables(120, 4000, [1500000], seed=51, max_len=150000)
+    bs = soa.gen_reads(regions, names, 150000, 300, seed=52)
+    batches = [util.batch_from_dict(b) for b in bs]
+    for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG"):
+        fold_env.pop(k, None)
+    fold_env["XCK_PILEUP_SORT"] = "partition"
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+    assert st["pileup_sort_path"] == 1 and len(exp["dp"][0]) > 1000
+    for page in ("64", "8"):
+        fold_env["XCK_FOLD_C"] = page
+        got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
+        util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+        assert st["pileup_sort_path"] in (1, 2)
+    fold_env.pop("XCK_FOLD_C")
+    fold_env.pop("XCK_PILEUP_SORT")                    # the default: radix sort
+    got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+    assert st["pileup_sort_path"] == 2

@@ -1234,14 +1234,36 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
 //                that starts in the tile gets its counts up to the tile end, what later tiles hold of it arrives by atomicAdd
 //   k_hap_final: the no_dup_hap arithmetic on the per-run sums -> AD / DP / OTH per run
 template <class K>
-__global__ void k_hap_class(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, uint8_t* __restrict__ cls) {
+__global__ void k_hap_class(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, uint8_t* __restrict__ cls, unsigned long long* __restrict__ long_runs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const K me = k[i];
     if (i > 0 && k[i - 1] == me) { cls[i] = 0; return; }
     uint32_t bits = v[i];
-    for (long long j = i + 1; j < n && k[j] == me; j++) bits |= v[j];
+    long long j = i + 1;
+    for (; j < n && j <= i + RUN_WALK && k[j] == me; j++) bits |= v[j];
+    // a molecule that meets more than RUN_WALK SNPs of one region (constant UMI tags, bulk input: thousands) is not walked by its
+    // head lane: the head queues the run and one block per run finishes it (k_hap_class_long)
+    if (j < n && j > i + RUN_WALK && k[j] == me) { cls[i] = 4; long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = (unsigned long long)i; return; }
     cls[i] = (uint8_t)bits;                                               // 1 REF haplotype, 2 ALT haplotype, 4 other allele; never 0 at a head
+}
+template <class K>
+__global__ void __launch_bounds__(256) k_hap_class_long(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, const unsigned long long* __restrict__ long_runs, uint8_t* __restrict__ cls) {
+    __shared__ uint32_t s_or[4];
+    const unsigned long long n_long = long_runs[0];
+    for (unsigned long long r = blockIdx.x; r < n_long; r += gridDim.x) {
+        const long long h = (long long)long_runs[1 + r];
+        const K me = k[h];
+        long long lo = h + 1, hi = n;                                     // first index past the run
+        while (lo < hi) { const long long mid = lo + ((hi - lo) >> 1); if (k[mid] == me) lo = mid + 1; else hi = mid; }
+        uint32_t bits = 0;
+        for (long long j = h + threadIdx.x; j < lo; j += blockDim.x) bits |= v[j];
+        for (int d = 32; d; d >>= 1) bits |= __shfl_xor(bits, d);
+        if ((threadIdx.x & 63) == 0) s_or[threadIdx.x >> 6] = bits;
+        __syncthreads();
+        if (threadIdx.x == 0) cls[h] = (uint8_t)(s_or[0] | s_or[1] | s_or[2] | s_or[3]);
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long* s_wave, unsigned long long& total) {
@@ -1486,6 +1508,7 @@ struct EngineImpl {
     unsigned long long cursor = 0;             // sum of cur[]; hit_cap is the capacity of ONE shard
     int fold_extra_digits = 0;                 // basefc hash fold: extra radix digits that earlier finishes needed (giant runs)
     int fold_path = 0, fold_fallbacks = 0;     // xck_stats: which basefc fold ran last (1 partition, 2 radix sort), hand-overs so far
+    int pileup_sort_path = 0;                  // pileup hits of the last finish: 1 sorted by partition + LDS sort, 2 by the radix sort
     // fused launch queue
     std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
     std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
@@ -2189,12 +2212,29 @@ static int finish_t(EngineImpl* im) {
         if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 16 + std::max<size_t>(n * 8, 8192) + n / 8 + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
+        // the hits sorted by (key, value): by row partition + one LDS sort per item (fold_partition.h); a SNP deeper than an item, or
+        // 128-bit keys, take the radix sort
+        bool sorted = false;
+        if constexpr (sizeof(K) == 8) {
+            // (opt-in: at configs[2] the partition + LDS item sort takes 2.6 ms against the radix sort's 2.2 ms - the bitonic network moves
+            // every pair through LDS 66 times; profiles/r03_q_*)
+            const bool want_part = getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "partition");
+            if (want_part) {
+                KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
+                rc = pileup_partition_sort(im, kl8, n, (unsigned long long*)alt, valt);
+                if (rc == 0) { sorted = true; im->pileup_sort_path = 1; }
+                else if (rc != PF_FALLBACK) return rc;
+            }
+        }
+        if (!sorted) {
+        im->pileup_sort_path = 2;
         { ShardSpan sp; sp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) sp.start[sh + 1] = sp.start[sh] + im->cur[sh];
           hipLaunchKernelGGL((k_pack_pairs<K>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, im->s_comp,
                              (const K*)im->d_keys, (const uint64_t*)im->d_vals, (unsigned long long)im->hit_cap, sp, alt, valt);
           HIP_TRY(hipGetLastError()); }
         if ((rc = sort_run<K, uint64_t>(im, tmp, tmpb, alt, keys, valt, im->d_vals, n, top))) return rc;
         std::swap(alt, keys); { uint64_t* t_ = valt; valt = im->d_vals; (void)t_; }   // sorted data now lives in d_keys / d_vals
+        }
         HIP_TRY(hipMemsetAsync(im->d_tally, 0, std::max<size_t>((size_t)im->n_snps_sorted * 5, 1) * sizeof(uint32_t), im->s_comp));
         unsigned long long* long_runs = im->ws1.get<unsigned long long>(n / (size_t)RUN_WALK + 2);      // [0] = count, then the heads of the runs longer than RUN_WALK
         if (!long_runs) { im->eng->err = "workspace exhausted (pileup fold)"; return XCK_E_NOMEM; }
@@ -2241,7 +2281,7 @@ static int finish_t(EngineImpl* im) {
         if (n2) {
             const size_t tmpb2 = sort_tmp_bytes<K, uint8_t>(n2, top);
             const size_t nb2 = (n2 + CP_TILE - 1) / CP_TILE;
-            if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + 4 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (1 << 16)))) return rc;
+            if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + 4 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (n2 / RUN_WALK + 2) * 8 + (1 << 16)))) return rc;
             K* k2 = im->ws2.get<K>(n2); K* k2b = im->ws2.get<K>(n2); uint8_t* v2 = im->ws2.get<uint8_t>(n2); uint8_t* v2b = im->ws2.get<uint8_t>(n2);
             void* tmp2 = im->ws2.get<char>(tmpb2); int32_t* dense = im->ws2.get<int32_t>(3 * n2);
             hipLaunchKernelGGL((k_expand<K, true>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
@@ -2256,7 +2296,11 @@ static int finish_t(EngineImpl* im) {
             if (!d_blk2 || !d_off2 || !acc) { im->eng->err = "workspace exhausted (haplotype sums)"; return XCK_E_NOMEM; }
             HIP_TRY(hipMemsetAsync(acc, 0, 4 * n2 * sizeof(uint32_t), im->s_comp));
             HIP_TRY(hipMemsetAsync(dense, 0, 3 * n2 * sizeof(int32_t), im->s_comp));
-            hipLaunchKernelGGL((k_hap_class<K>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const uint8_t*)v2b, (long long)n2, cls);
+            unsigned long long* long2 = im->ws2.get<unsigned long long>(n2 / (size_t)RUN_WALK + 2);   // [0] = count, then the heads of the (row, cell, UMI) runs longer than RUN_WALK
+            if (!long2) { im->eng->err = "workspace exhausted (haplotype classes)"; return XCK_E_NOMEM; }
+            HIP_TRY(hipMemsetAsync(long2, 0, sizeof(unsigned long long), im->s_comp));
+            hipLaunchKernelGGL((k_hap_class<K>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const uint8_t*)v2b, (long long)n2, cls, long2);
+            hipLaunchKernelGGL((k_hap_class_long<K>), dim3(256), dim3(256), 0, im->s_comp, (const K*)k2b, (const uint8_t*)v2b, (long long)n2, (const unsigned long long*)long2, cls);
             hipLaunchKernelGGL((k_fold_heads<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (long long)n2, kl, d_blk2);
             hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk2, (long long)nt2, d_off2, im->d_ctl + CTL_SCRATCH);
             hipLaunchKernelGGL((k_hap_sum<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (const uint8_t*)cls, (long long)n2, kl,
@@ -2350,7 +2394,7 @@ int engine_stats(const xck_engine* e, xck_stats* out) {
     if (!im) return XCK_E_STATE;
     *out = im->st; out->key_bits = im->key_bits; out->umi_bits = im->ubits;
     out->n_join_launches = im->n_join_launches;
-    out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks;
+    out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks; out->pileup_sort_path = im->pileup_sort_path; out->reserved0 = 0;
     return 0;
 }
 

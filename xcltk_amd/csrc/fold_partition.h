@@ -38,10 +38,14 @@ constexpr int PF_FALLBACK = 1;
 constexpr int PF_C_MAX = 1024;                         // page size C (keys); a work item holds at most CAP = 2C keys
 constexpr int PF_CAP_MAX = 2 * PF_C_MAX;
 constexpr int PF_SLOTS = 4096;                         // LDS set of k_pf_bucket: 32 KB, load <= 0.5
-constexpr int PF_THREADS = 512, PF_KPT = PF_CAP_MAX / PF_THREADS;
+#ifndef XCK_PF_THREADS
+#define XCK_PF_THREADS 512
+#endif
+constexpr int PF_THREADS = XCK_PF_THREADS, PF_KPT = PF_CAP_MAX / PF_THREADS;
 constexpr int PF_SB_MAX = 16, PF_BM_WORDS_MAX = (1 << PF_SB_MAX) / 32;   // bitmap over the span: at most 65536 (row, cell) pairs
-constexpr int PT_THREADS = 512, PT_KPT = 8, PT_CHUNK = PT_THREADS * PT_KPT;
+constexpr int PT_THREADS = 512, PT_KPT = 16, PT_CHUNK = PT_THREADS * PT_KPT;
 constexpr int PT_TAB_LG = 11, PT_TAB = 1 << PT_TAB_LG; // LDS aggregation table of the histogram / partition kernels
+constexpr int PT_WIN = 2048;                           // keys per LDS output window of the partition kernel
 constexpr uint32_t PF_BIG = 0x80000000u;               // WorkItem.span: the item is a big z (its keys are handled by level 2)
 
 struct PartGeom {
@@ -59,30 +63,45 @@ constexpr uint32_t PF_CONT = 0x80000000u;              // WorkItem.pad: that (ro
 struct ShardChunks { unsigned long long cap; uint32_t cnt[NSHARD]; uint32_t chunk0[NSHARD + 1]; };   // level 1: the 16 shard slices of the hit buffer
 struct BigChunks { const uint32_t* off; const uint32_t* cnt; const uint32_t* chunk0; const uint32_t* z2base; const uint32_t* sg; const uint32_t* eb; uint32_t n_big; };   // level 2: the big z of the level-1 output
 
+// XCK_EXP_XCC_ATOMICS (experiment): counters / cursors privatised per XCD (copy = the hardware XCC id) and updated with workgroup-scope
+// atomics, which the per-XCD L2 executes locally instead of forwarding them to the memory-side atomic units.
+#ifdef XCK_EXP_XCC_ATOMICS
+#define PF_GADD(p, v) (pl ? __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAdd(p, v))   /* pl == 0: one shared copy */
+__device__ __forceinline__ uint32_t pf_copy_of_block(int pl) { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x & ((1u << pl) - 1u); }
+#else
+#define PF_GADD(p, v) atomicAdd(p, v)
+__device__ __forceinline__ uint32_t pf_copy_of_block(int pl) { return blockIdx.x & ((1u << pl) - 1u); }
+#endif
 struct AggTab { uint32_t tag[PT_TAB]; uint32_t cnt[PT_TAB]; uint32_t base[PT_TAB]; };
 __device__ __forceinline__ int agg_find(AggTab& t, uint32_t z) {
     uint32_t h = (z * 0x9E3779B1u) >> (32 - PT_TAB_LG);
 #pragma unroll 1
     for (int p = 0; p < 24; p++) {
-        const uint32_t prev = atomicCAS(&t.tag[h], 0xffffffffu, z);
-        if (prev == 0xffffffffu || prev == z) return (int)h;
+        // a plain read first: nearly every key of a chunk finds its cell already in the table (thousands of keys, a few hundred cells),
+        // and LDS atomics - one lane at a time under conflicts - were the longest phase of these kernels (45 k cycles per 8192-key chunk)
+        const uint32_t cur = t.tag[h];
+        if (cur == z) return (int)h;
+        if (cur == 0xffffffffu) { const uint32_t prev = atomicCAS(&t.tag[h], 0xffffffffu, z); if (prev == 0xffffffffu || prev == z) return (int)h; }
         h = (h + 1) & (PT_TAB - 1);
     }
     return -1;                                         // table crowded (unsorted input): the key is handled on its own
 }
 
-template <int THREADS>
+// Barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt(0)), which
+// would turn the bucket kernel's prefetch of the next item's keys into a stall at the first barrier.
+#define PF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int THREADS, bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t block_excl_scan_t(uint32_t v, uint32_t* s_wave, uint32_t& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
     if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
+    if (LDS_ONLY) PF_LDS_BARRIER(); else __syncthreads();
     uint32_t base = 0; total = 0;
 #pragma unroll
     for (int w = 0; w < THREADS / 64; w++) { const uint32_t t = s_wave[w]; if (w < wave) base += t; total += t; }
-    __syncthreads();
+    if (LDS_ONLY) PF_LDS_BARRIER(); else __syncthreads();
     return base + inc - v;
 }
 
@@ -165,6 +184,7 @@ __device__ __forceinline__ ChunkLoc pf_locate2(const BigChunks& bc, uint32_t chu
 template <int LEVEL>
 __device__ __forceinline__ uint32_t pf_cell(unsigned long long key, const PartGeom& g, const ChunkLoc& L) {
     const unsigned long long rc = key >> g.ubits;
+    if (LEVEL == 0) return (uint32_t)(rc >> g.cbits);                     // the row itself (pileup hits: one cell per SNP)
     if (LEVEL == 1) {
         const uint32_t t = g.rowtab[(uint32_t)(rc >> g.cbits)];
         return (t >> 5) + (((uint32_t)rc & ((1u << g.cbits) - 1u)) >> (t & 31u));
@@ -220,7 +240,7 @@ __global__ void k_pf_rowtab(const uint32_t* __restrict__ zb, uint32_t n_rows, in
     const uint32_t base = zb[r], G = zb[r + 1] - base;
     const int lg = 31 - __builtin_clz(G);
     rowtab[r] = (base << 5) | (uint32_t)(cbits - lg);
-    for (uint32_t q = 0; q < G; q++) zrow[base + q] = r;
+    if (zrow) for (uint32_t q = 0; q < G; q++) zrow[base + q] = r;
 }
 
 // Level 1 keeps 2^pl copies of every counter / cursor (copy = block index mod 2^pl; the copies of a cell are adjacent, so the scan
@@ -232,54 +252,132 @@ __global__ __launch_bounds__(PT_THREADS) void k_pf_hist(const unsigned long long
     __shared__ AggTab t;
     __shared__ uint32_t s_b;
     for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
-    const uint32_t copy = blockIdx.x & ((1u << pl) - 1u);
-    const ChunkLoc L = LEVEL == 1 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
+    const uint32_t copy = pf_copy_of_block(pl);
+    const ChunkLoc L = LEVEL != 2 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
     unsigned long long k[PT_KPT];
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) { const uint32_t i = q * PT_THREADS + threadIdx.x; k[q] = i < L.n ? keys[L.base + i] : 0ull; }
     __syncthreads();
+    uint32_t zq[PT_KPT];
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) zq[q] = (uint32_t)(q * PT_THREADS + threadIdx.x) < L.n ? pf_cell<LEVEL>(k[q], g, L) : 0u;   // (level 1: a table look-up per key - all in flight together)
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) {
         if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n) continue;
-        const uint32_t z = pf_cell<LEVEL>(k[q], g, L);
+        const uint32_t z = zq[q];
+#ifdef XCK_EXP_HIST_NOLDS
+        if (z == 0xfffffff0u) atomicAdd(&hist[0], 1u);
+#else
         const int slot = agg_find(t, z);
-        if (slot >= 0) atomicAdd(&t.cnt[slot], 1u); else atomicAdd(&hist[(z << pl) | copy], 1u);
+        if (slot >= 0) atomicAdd(&t.cnt[slot], 1u); else PF_GADD(&hist[(z << pl) | copy], 1u);
+#endif
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) atomicAdd(&hist[(t.tag[s] << pl) | copy], t.cnt[s]);
+#ifndef XCK_EXP_HIST_NOFLUSH
+    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) PF_GADD(&hist[(t.tag[s] << pl) | copy], t.cnt[s]);
+#endif
 }
 
+#ifdef XCK_EXP_PART_STAMPS
+__device__ unsigned long long pf_stamps[8];
+#define PF_STAMP(slot) do { const long long t_ = clock64(); if (threadIdx.x == 0) atomicAdd(&pf_stamps[slot], (unsigned long long)(t_ - t_s0)); t_s0 = t_; } while (0)
+#else
+#define PF_STAMP(slot) do {} while (0)
+#endif
 // cursor[z << pl | copy] = first free index of that copy of z in the output (starts at the exclusive scan of the histogram)
 template <int LEVEL>
-__global__ __launch_bounds__(PT_THREADS) void k_pf_part(const unsigned long long* __restrict__ keys, ShardChunks sc, BigChunks bc, PartGeom g, int pl,
-                                                        uint32_t* __restrict__ cursor, unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pf_part(const unsigned long long* __restrict__ keys, ShardChunks sc, BigChunks bc, PartGeom g, int pl,
+                                                        uint32_t* __restrict__ cursor, unsigned long long* __restrict__ out,
+                                                        const uint64_t* __restrict__ vals = nullptr, uint64_t* __restrict__ out_vals = nullptr) {
     __shared__ AggTab t;
     __shared__ uint32_t s_b;
+#ifdef XCK_EXP_PART_STAMPS
+    long long t_s0 = clock64();
+#endif
     for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
-    const uint32_t copy = blockIdx.x & ((1u << pl) - 1u);
-    const ChunkLoc L = LEVEL == 1 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
+    const uint32_t copy = pf_copy_of_block(pl);
+    const ChunkLoc L = LEVEL != 2 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
     unsigned long long k[PT_KPT];
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) { const uint32_t i = q * PT_THREADS + threadIdx.x; k[q] = i < L.n ? keys[L.base + i] : 0ull; }
     __syncthreads();
-    int slot[PT_KPT]; uint32_t rank[PT_KPT], zz[PT_KPT];
+    PF_STAMP(0);                                                          // keys arrived
+    uint32_t sr[PT_KPT];                                                  // first the key's cell, then slot << 16 | rank in the slot's run; ~0 = not in the table
+    static_assert(PT_CHUNK <= 65536 && PT_TAB <= 32768, "slot and rank share a word");
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) sr[q] = (uint32_t)(q * PT_THREADS + threadIdx.x) < L.n ? pf_cell<LEVEL>(k[q], g, L) : 0xffffffffu;   // (level 1: a table look-up per key - all in flight together)
+#ifdef XCK_EXP_PART_STAMPS
+    { uint32_t x = 0;
+#pragma unroll
+      for (int q = 0; q < PT_KPT; q++) x ^= sr[q];
+      if (x == 0x12345678u) atomicAdd(&pf_stamps[7], 1ull); }            // (forces the look-ups to have arrived)
+    __syncthreads();
+    PF_STAMP(5);                                                          // cells looked up
+#endif
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) {
-        slot[q] = -2; rank[q] = 0; zz[q] = 0;
         if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n) continue;
-        zz[q] = pf_cell<LEVEL>(k[q], g, L);
-        slot[q] = agg_find(t, zz[q]);
-        if (slot[q] >= 0) rank[q] = atomicAdd(&t.cnt[slot[q]], 1u);
+        const int slot = agg_find(t, sr[q]);
+        sr[q] = slot >= 0 ? ((uint32_t)slot << 16) | atomicAdd(&t.cnt[slot], 1u) : 0xffffffffu;
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) t.base[s] = atomicAdd(&cursor[(t.tag[s] << pl) | copy], t.cnt[s]);   // one run per (chunk, cell)
-    __syncthreads();
+    PF_STAMP(1);                                                          // slots and ranks
+    // run bases: one returning atomic per (chunk, cell); the runs' places inside the chunk by a block scan of the slot counts
+    __shared__ uint32_t s_wave[PT_THREADS / 64];
+    constexpr int SPT = PT_TAB / PT_THREADS;                              // slots per thread (blocked)
+    uint32_t c4[SPT], g4[SPT], sum = 0;
 #pragma unroll
-    for (int q = 0; q < PT_KPT; q++) {
-        if (slot[q] == -2) continue;
-        const uint32_t dst = slot[q] >= 0 ? t.base[slot[q]] + rank[q] : atomicAdd(&cursor[(zz[q] << pl) | copy], 1u);
-        out[dst] = k[q];
+    for (int i = 0; i < SPT; i++) {
+        const int sl = threadIdx.x * SPT + i;
+        c4[i] = t.tag[sl] != 0xffffffffu ? t.cnt[sl] : 0u; g4[i] = 0; sum += c4[i];
+        if (c4[i])
+#ifdef XCK_EXP_PART_NOATOM
+            g4[i] = cursor[(t.tag[sl] << pl) | copy];
+#else
+            g4[i] = PF_GADD(&cursor[(t.tag[sl] << pl) | copy], c4[i]);
+#endif
     }
+    uint32_t n_tab;
+    uint32_t run = block_excl_scan_t<PT_THREADS>(sum, s_wave, n_tab);      // (its barriers also end the reads of t.cnt)
+#pragma unroll
+    for (int i = 0; i < SPT; i++) { const int sl = threadIdx.x * SPT + i; t.cnt[sl] = run; t.base[sl] = g4[i] - run; run += c4[i]; }   // cnt := place in the chunk, base := destination - place
+    __syncthreads();
+    PF_STAMP(2);                                                          // run bases (returning global atomics)
+    // the keys leave through an LDS window in run order: consecutive lanes then store to consecutive addresses (a scattered 8-byte
+    // store costs the address unit a cycle per lane: 55 k cycles per chunk when every key went out on its own)
+    __shared__ unsigned long long s_key[PT_WIN];
+    __shared__ uint16_t s_slot[PT_WIN];
+    __shared__ uint16_t s_src[PT_WIN];
+    for (uint32_t w0 = 0; w0 < n_tab; w0 += PT_WIN) {
+#pragma unroll
+        for (int q = 0; q < PT_KPT; q++) {
+            if (sr[q] == 0xffffffffu) continue;
+            const uint32_t pos = t.cnt[sr[q] >> 16] + (sr[q] & 0xffffu) - w0;
+            if (pos < (uint32_t)PT_WIN) { s_key[pos] = k[q]; s_slot[pos] = (uint16_t)(sr[q] >> 16); if (vals) s_src[pos] = (uint16_t)(q * PT_THREADS + threadIdx.x); }
+        }
+        __syncthreads();
+        const uint32_t m = min((uint32_t)PT_WIN, n_tab - w0);
+        for (uint32_t i = threadIdx.x; i < m; i += PT_THREADS) {
+            const uint32_t dst = t.base[s_slot[i]] + w0 + i;
+#ifdef XCK_EXP_PART_NOSTORE
+            if (dst == 0xfffffff0u)
+#endif
+            { out[dst] = s_key[i]; if (vals) out_vals[dst] = vals[L.base + s_src[i]]; }   // (pileup hits: the value travels with its key)
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {                                    // keys that found no place in the table (a chunk with too many cells)
+        if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n || sr[q] != 0xffffffffu) continue;
+        const uint32_t dst = PF_GADD(&cursor[(pf_cell<LEVEL>(k[q], g, L) << pl) | copy], 1u);
+        out[dst] = k[q];
+        if (vals) out_vals[dst] = vals[L.base + q * PT_THREADS + threadIdx.x];
+    }
+#ifdef XCK_EXP_PART_STAMPS
+    PF_STAMP(3);                                                          // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PF_STAMP(4);                                                          // stores acknowledged
+#endif
 }
 
 // ---- work items --------------------------------------------------------------------------------------------------------
@@ -380,12 +478,15 @@ __global__ void k_pf_emit2(const uint32_t* __restrict__ S, uint32_t Z, const uin
     wi[id[z]] = w;
 }
 
-// ---- one block per work item ------------------------------------------------------------------------------------------------
-// res[off + i] = (low sb bits of (row, cell)) << 16 | distinct keys, i < nnz, in (row, cell) order; nnz_out[w] = nnz
-__global__ __launch_bounds__(PF_THREADS) void k_pf_bucket(const unsigned long long* __restrict__ keys, const WorkItem* __restrict__ wi, int ubits, int sb,
+// ---- the work items: a block takes every gridDim.x-th item -------------------------------------------------------------------
+// res[off + i] = (low sb bits of (row, cell)) << 16 | distinct keys, i < nnz, in (row, cell) order; nnz_out[w] = entries that open a
+// new (row, cell); cont_out[w] (level 2) = 1 when the item's first entry continues the last entry of the items before it (a
+// (row, cell) cut into UMI-hash parts that fell into several items).
+// An item lives ~2 us in LDS but its keys take as long to arrive, and a block per item left the CUs waiting for loads (2.9 ms for
+// the 424 k items of configs[2]); here the keys of the block's NEXT item (and the descriptor of the one after) are requested
+// before the current item is processed.
+__global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pf_bucket(const unsigned long long* __restrict__ keys, const WorkItem* __restrict__ wi, uint32_t n_items, int ubits, int sb,
                                                           uint32_t* __restrict__ res, uint32_t* __restrict__ nnz_out, uint32_t* __restrict__ cont_out, uint32_t* __restrict__ ctr) {
-    // nnz_out[w] = entries that open a new (row, cell); cont_out[w] (level 2) = 1 when the item's first entry continues the last entry
-    // of the items before it (a (row, cell) cut into UMI-hash parts that fell into several items)
     extern __shared__ unsigned long long pf_smem[];
     unsigned long long* set = pf_smem;                                     // phase 1: PF_SLOTS slots
     uint32_t* cnt32 = reinterpret_cast<uint32_t*>(pf_smem);                // later (the set is dead): PF_CAP_MAX 16-bit counters
@@ -395,70 +496,121 @@ __global__ __launch_bounds__(PF_THREADS) void k_pf_bucket(const unsigned long lo
     static_assert(PF_CAP_MAX * 2 + PF_CAP_MAX * 4 + PF_BM_WORDS_MAX * 4 <= PF_SLOTS * 8, "the late arrays alias the set");
     __shared__ uint32_t s_wave[PF_THREADS / 64];
     const int tid = threadIdx.x;
-    const WorkItem me = wi[blockIdx.x];
-    const uint32_t off = me.off, n = wi[blockIdx.x + 1].off - off;
-    if (me.span & PF_BIG) return;                                          // level 1: its keys went through level 2 (k_pf_bignnz fills nnz_out)
-    if (n == 0) { if (tid == 0) { nnz_out[blockIdx.x] = 0; if (cont_out) cont_out[blockIdx.x] = 0; } return; }
-    if (n > (uint32_t)PF_CAP_MAX) { if (tid == 0) { ctr[7] = 1u; nnz_out[blockIdx.x] = 0; if (cont_out) cont_out[blockIdx.x] = 0; } return; }   // cannot happen (k_pf_plan); never index out of the LDS arrays
+    const uint32_t G = gridDim.x;
     const uint32_t bmask = (1u << sb) - 1u;
     const int n_words = 1 << (sb - 5);
+    const int wpt = (n_words + PF_THREADS - 1) / PF_THREADS;               // bitmap words per thread (blocked)
+    const int w0 = tid * wpt;
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    auto usable = [](const WorkItem& w, uint32_t n) { return !(w.span & PF_BIG) && n > 0 && n <= (uint32_t)PF_CAP_MAX; };
+    // (descriptors through VECTOR loads: a scalar load shares its counter with LDS, and every LDS wait of the item being processed
+    // would then wait for the descriptor of the item after next to arrive from HBM)
+    const uint32_t vz = __builtin_amdgcn_mbcnt_lo(0u, 0u);                 // 0 in every lane, unknown to the compiler
+    auto load_item = [&](uint32_t i, WorkItem& w, uint32_t& n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(wi + i + vz); const uint32_t e = wi[i + 1 + vz].off;
+        w.off = __builtin_amdgcn_readfirstlane(a.x); w.span = __builtin_amdgcn_readfirstlane(a.y); w.aux = __builtin_amdgcn_readfirstlane(a.z); w.pad = __builtin_amdgcn_readfirstlane(a.w);
+        n = __builtin_amdgcn_readfirstlane(e) - w.off;
+    };
+    WorkItem cur; uint32_t n_cur; load_item(item, cur, n_cur);
+    bool has_nxt = item + G < n_items;
+    WorkItem nxt = cur; uint32_t n_nxt = 0;
+    if (has_nxt) load_item(item + G, nxt, n_nxt);
     unsigned long long k[PF_KPT];
 #pragma unroll
-    for (int q = 0; q < PF_KPT; q++) { const uint32_t i = q * PF_THREADS + tid; k[q] = i < n ? keys[off + i] : ~0ull; }
-    for (int s = tid; s < PF_SLOTS; s += PF_THREADS) set[s] = ~0ull;
-    for (int s = tid; s < n_words; s += PF_THREADS) bm[s] = 0u;
-    __syncthreads();
-    uint32_t win = 0;                                                      // bit q: this thread's key q is the first occurrence of its (row, cell, umi)
+    for (int q = 0; q < PF_KPT; q++) { const uint32_t i = q * PF_THREADS + tid; k[q] = (usable(cur, n_cur) && i < n_cur) ? keys[cur.off + i] : ~0ull; }
+    for (;;) {
+        // ---- requests for the following items
+        unsigned long long kn[PF_KPT];
+        const bool ok_nxt = has_nxt && usable(nxt, n_nxt);
 #pragma unroll
-    for (int q = 0; q < PF_KPT; q++) {
-        if ((uint32_t)(q * PF_THREADS + tid) >= n) continue;
-        const unsigned long long key = k[q];
-        const uint32_t rcl = (uint32_t)(key >> ubits) & bmask;
-        atomicOr(&bm[rcl >> 5], 1u << (rcl & 31));
-        uint32_t slot = set_slot<PF_SLOTS>(key);
-        for (;;) {                                                         // load <= 0.5: ends
-            const unsigned long long prev = atomicCAS(&set[slot], ~0ull, key);
-            if (prev == ~0ull) { win |= 1u << q; break; }
-            if (prev == key) break;
-            slot = (slot + 1) & (PF_SLOTS - 1);
-        }
-    }
-    __syncthreads();                                                       // set dead from here on: cnt32 / stage / wpre alias it
-    // bitmap words, blocked over the threads (wpt consecutive words each; sb >= 14 with 512 threads: 1 - 4 words)
-    const int wpt = (n_words + PF_THREADS - 1) / PF_THREADS;
-    const int w0 = tid * wpt;
-    uint32_t pc = 0;
-    for (int i = 0; i < wpt; i++) if (w0 + i < n_words) pc += (uint32_t)__popc(bm[w0 + i]);
-    uint32_t nnz;
-    uint32_t run = block_excl_scan_t<PF_THREADS>(pc, s_wave, nnz);
-    for (int i = 0; i < wpt; i++) if (w0 + i < n_words) { wpre[w0 + i] = run; run += (uint32_t)__popc(bm[w0 + i]); }
-    for (int s = tid; s < PF_CAP_MAX / 2; s += PF_THREADS) cnt32[s] = 0u;
-    __syncthreads();
+        for (int q = 0; q < PF_KPT; q++) { const uint32_t i = q * PF_THREADS + tid; kn[q] = (ok_nxt && i < n_nxt) ? keys[nxt.off + i] : ~0ull; }
+        const bool has_nn = has_nxt && item + 2 * G < n_items;
+        WorkItem nn = nxt; uint32_t n_nn = 0;
+        uint4 nn_a = make_uint4(0, 0, 0, 0); uint32_t nn_e = 0;                // (consumed at the end of the iteration)
+        if (has_nn) { nn_a = *reinterpret_cast<const uint4*>(wi + item + 2 * G + vz); nn_e = wi[item + 2 * G + 1 + vz].off; }
+        // ---- the current item (every condition below is uniform over the block)
+        const uint32_t off = cur.off, n = n_cur;
+        if (cur.span & PF_BIG) { /* level 1: its keys went through level 2 (k_pf_bignnz fills nnz_out) */ }
+        else if (n == 0 || n > (uint32_t)PF_CAP_MAX) {
+            if (tid == 0) { if (n) ctr[7] = 1u; nnz_out[item] = 0; if (cont_out) cont_out[item] = 0; }   // n > CAP cannot happen (k_pf_plan); never index out of the LDS arrays
+        } else {
+            int lg_slots = 8; while ((1u << lg_slots) < 2 * n) lg_slots++;  // load <= 0.5; small items clear and probe a small table
+            const uint32_t smask = (1u << lg_slots) - 1u;
+            for (uint32_t s = tid; s <= smask; s += PF_THREADS) set[s] = ~0ull;
+            for (int s = tid; s < n_words; s += PF_THREADS) bm[s] = 0u;
+            PF_LDS_BARRIER();
+            uint32_t win = 0;                                              // bit q: this thread's key q is the first occurrence of its (row, cell, umi)
 #pragma unroll
-    for (int q = 0; q < PF_KPT; q++) {
-        if (!(win & (1u << q))) continue;
-        const uint32_t rcl = (uint32_t)(k[q] >> ubits) & bmask;
-        const uint32_t rank = wpre[rcl >> 5] + (uint32_t)__popc(bm[rcl >> 5] & ((1u << (rcl & 31)) - 1u));
-        atomicAdd(&cnt32[rank >> 1], 1u << ((rank & 1u) * 16));
-    }
-    __syncthreads();
-    for (int i = 0; i < wpt; i++) {
-        if (w0 + i >= n_words) break;
-        uint32_t bits = bm[w0 + i];
-        run = wpre[w0 + i];
-        while (bits) {
-            const uint32_t b = (uint32_t)__builtin_ctz(bits); bits &= bits - 1u;
-            const uint32_t c = (cnt32[run >> 1] >> ((run & 1u) * 16)) & 0xffffu;
-            stage[run] = ((uint32_t)((w0 + i) * 32 + b) << 16) | c;
-            run++;
+            for (int q = 0; q < PF_KPT; q++) {
+                if ((uint32_t)(q * PF_THREADS + tid) >= n) continue;
+                const unsigned long long key = k[q];
+                const uint32_t rcl = (uint32_t)(key >> ubits) & bmask;
+                // (an item of a hot gene holds one or two cells: after the first keys every lane finds its bit set, and 64 lanes no
+                // longer queue on one LDS word)
+                if (!(bm[rcl >> 5] & (1u << (rcl & 31)))) atomicOr(&bm[rcl >> 5], 1u << (rcl & 31));
+                uint32_t slot = set_slot<PF_SLOTS>(key) & smask;
+                for (;;) {
+                    const unsigned long long prev = atomicCAS(&set[slot], ~0ull, key);
+                    if (prev == ~0ull) { win |= 1u << q; break; }
+                    if (prev == key) break;
+                    slot = (slot + 1) & smask;
+                }
+            }
+            PF_LDS_BARRIER();                                               // set dead from here on: cnt32 / stage / wpre alias it
+            uint32_t pc = 0;
+            for (int i = 0; i < wpt; i++) if (w0 + i < n_words) pc += (uint32_t)__popc(bm[w0 + i]);
+            uint32_t nnz;
+            uint32_t run = block_excl_scan_t<PF_THREADS, true>(pc, s_wave, nnz);
+            for (int i = 0; i < wpt; i++) if (w0 + i < n_words) { wpre[w0 + i] = run; run += (uint32_t)__popc(bm[w0 + i]); }
+            for (uint32_t s = tid; s < (nnz + 1) / 2; s += PF_THREADS) cnt32[s] = 0u;
+            PF_LDS_BARRIER();
+            // count the first occurrences per (row, cell).  Same-address LDS atomics of a wave are served one lane at a time, and in
+            // the items of a hot gene all 64 lanes meet on one or two counters: two rounds of "the lanes that share the first
+            // active lane's rank add once, together" take those out; whatever is left (many cells: different counters) adds alone.
+#pragma unroll
+            for (int q = 0; q < PF_KPT; q++) {
+                bool mine = (win >> q) & 1u;
+                uint32_t rank = 0;
+                if (mine) { const uint32_t rcl = (uint32_t)(k[q] >> ubits) & bmask;
+                            rank = wpre[rcl >> 5] + (uint32_t)__popc(bm[rcl >> 5] & ((1u << (rcl & 31)) - 1u)); }
+#pragma unroll
+                for (int round = 0; round < 2; round++) {
+                    const unsigned long long act = __ballot(mine);
+                    if (!act) break;
+                    const uint32_t r0 = __builtin_amdgcn_readlane(rank, (int)__builtin_ctzll(act));
+                    const unsigned long long same = __ballot(mine && rank == r0);
+                    if (mine && rank == r0) { if ((int)(tid & 63) == (int)__builtin_ctzll(same)) atomicAdd(&cnt32[r0 >> 1], (uint32_t)__popcll(same) << ((r0 & 1u) * 16)); mine = false; }
+                }
+                if (mine) atomicAdd(&cnt32[rank >> 1], 1u << ((rank & 1u) * 16));
+            }
+            PF_LDS_BARRIER();
+            for (int i = 0; i < wpt; i++) {
+                if (w0 + i >= n_words) break;
+                uint32_t bits = bm[w0 + i];
+                run = wpre[w0 + i];
+                while (bits) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(bits); bits &= bits - 1u;
+                    const uint32_t c = (cnt32[run >> 1] >> ((run & 1u) * 16)) & 0xffffu;
+                    stage[run] = ((uint32_t)((w0 + i) * 32 + b) << 16) | c;
+                    run++;
+                }
+            }
+            PF_LDS_BARRIER();
+            for (uint32_t i = tid; i < nnz; i += PF_THREADS) res[off + i] = stage[i];
+            if (tid == 0) {
+                const uint32_t cont = (cont_out && (cur.pad & PF_CONT) && (stage[0] >> 16) == (cur.pad & bmask)) ? 1u : 0u;
+                nnz_out[item] = nnz - cont;
+                if (cont_out) cont_out[item] = cont;
+            }
+            PF_LDS_BARRIER();                                               // stage is read: the next item may clear the set
         }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < nnz; i += PF_THREADS) res[off + i] = stage[i];
-    if (tid == 0) {
-        const uint32_t cont = (cont_out && (me.pad & PF_CONT) && (stage[0] >> 16) == (me.pad & bmask)) ? 1u : 0u;
-        nnz_out[blockIdx.x] = nnz - cont;
-        if (cont_out) cont_out[blockIdx.x] = cont;
+        if (!has_nxt) break;
+        if (has_nn) { nn.off = __builtin_amdgcn_readfirstlane(nn_a.x); nn.span = __builtin_amdgcn_readfirstlane(nn_a.y); nn.aux = __builtin_amdgcn_readfirstlane(nn_a.z);
+                      nn.pad = __builtin_amdgcn_readfirstlane(nn_a.w); n_nn = __builtin_amdgcn_readfirstlane(nn_e) - nn.off; }
+        item += G; cur = nxt; n_cur = n_nxt; nxt = nn; n_nxt = n_nn; has_nxt = has_nn;
+#pragma unroll
+        for (int q = 0; q < PF_KPT; q++) k[q] = kn[q];
     }
 }
 
@@ -598,7 +750,14 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_chunks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1, A);   // (S1 is the cursor array from here on)
     HIP_TRY(hipGetLastError());
+#ifdef XCK_EXP_PART_STAMPS
+    { unsigned long long st[8]; HIP_TRY(hipStreamSynchronize(im->s_comp)); HIP_TRY(hipMemcpyFromSymbol(st, HIP_SYMBOL(pf_stamps), sizeof st));
+      fprintf(stderr, "[stamps part<1>] blocks=%u cycles per block: load %.0f  cells %.0f  find+rank %.0f  atomics %.0f  store-issue %.0f  store-ack %.0f\n", n_chunks1,
+              (double)st[0] / n_chunks1, (double)st[5] / n_chunks1, (double)st[1] / n_chunks1, (double)st[2] / n_chunks1, (double)st[3] / n_chunks1, (double)st[4] / n_chunks1);
+      memset(st, 0, sizeof st); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pf_stamps), st, sizeof st)); }
+#endif
     const int lds = pf_bucket_lds(g.sb);
+    const size_t bucket_grid = (size_t)std::max(1, pf_env_int("XCK_FOLD_BUCKET_BLOCKS", 256 * 4 * 2));     // resident blocks (4 per CU by LDS) x 2: the tail evens out
     size_t n_wi2 = 0;
     K* B = (K*)im->d_keys;                                                                 // level-2 output: the shard slices are dead once level 1 has moved the keys
     if (n_big) {
@@ -624,14 +783,14 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
         hipLaunchKernelGGL(k_pf_emit2, dim3(gz2), dim3(256), 0, im->s_comp, (const uint32_t*)S2, (uint32_t)Z2, (const uint32_t*)fs2, (uint32_t)n_big, wi2, big);
         hipLaunchKernelGGL((k_pf_part<2>), dim3((unsigned)n_chunks2), dim3(PT_THREADS), 0, im->s_comp, (const K*)A, sc, bc, g, 0, S2, B);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)n_wi2), dim3(PF_THREADS), lds, im->s_comp, (const K*)B, (const WorkItem*)wi2, kl.ubits, g.sb, res2, nnz2, cont2, ctr);
+        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi2, bucket_grid)), dim3(PF_THREADS), lds, im->s_comp, (const K*)B, (const WorkItem*)wi2, (uint32_t)n_wi2, kl.ubits, g.sb, res2, nnz2, cont2, ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(nnz2 + n_wi2, 0, 4, im->s_comp));
         if ((rc = pf_scan(im, nnz2, n_wi2 + 1, bsum2, nullptr))) return rc;                // nnz2 -> O2
         hipLaunchKernelGGL(k_pf_bignnz, dim3((unsigned)((n_big + 255) / 256)), dim3(256), 0, im->s_comp, (uint32_t)n_big, big, (const uint32_t*)nnz2, nnz1);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)n_wi1), dim3(PF_THREADS), lds, im->s_comp, (const K*)A, (const WorkItem*)wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
+    hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, bucket_grid)), dim3(PF_THREADS), lds, im->s_comp, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(nnz1 + n_wi1, 0, 4, im->s_comp));
     if ((rc = pf_scan(im, nnz1, n_wi1 + 1, bsum2, ctr + 6))) return rc;                    // nnz1 -> O1, ctr[6] = non-zeros of the matrix
@@ -654,4 +813,140 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
                                   kl.cbits, g.sb, (unsigned long long)total, d_o);
     HIP_TRY(hipGetLastError());
     return copy_out(im, 0, d_o, total);
+}
+
+
+// ---- pileup: the (key, value) hits sorted WITHOUT a radix sort -------------------------------------------------------------------
+// The hits with a base leave k_join<pileup> in position order and a key's top field is the SNP's index in position order: the
+// stream is almost sorted by row already.  The radix sort took 8 passes over the 25 M pairs of configs[2] (4.0 of the pileup
+// fold's 11 ms); here the pairs are partitioned by row (one pass, the kernels above with z = row) into items of whole SNPs of at
+// most 2C pairs, and every item is sorted in LDS (bitonic network on (key, value)).  A SNP deeper than an item (UMI-less deep
+// pileups) returns PF_FALLBACK: the radix sort handles it.  Reference semantics: first read per (SNP, cell, UMI) in fetch order,
+// xcltk/baf/fc/mcount.py:109-127 - the order inside a key run is irrelevant to what follows (k_first_base takes the minimum).
+constexpr int PS_CAP = PF_CAP_MAX, PS_THREADS = 256;
+__global__ void k_pf_plan0(const uint32_t* __restrict__ S, uint32_t Z, int lgC, uint32_t* __restrict__ fs, uint32_t* __restrict__ ctr) {
+    const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z > Z) return;
+    if (z == Z) { fs[z] = 0; return; }
+    const uint32_t C = 1u << lgC, CAP = 2u << lgC;
+    const uint32_t s = S[z], c = S[z + 1] - s, sp = z ? S[z - 1] : 0u, cp = z ? s - sp : 0u;
+    fs[z] = (z == 0 || (s >> lgC) != (sp >> lgC) || c > C || cp > C) ? 1u : 0u;
+    if (c > CAP) ctr[5] = 1u;
+}
+__global__ void k_pf_emit0(const uint32_t* __restrict__ S, uint32_t Z, const uint32_t* __restrict__ id, uint32_t* __restrict__ item_off) {
+    const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    if (z == 0) item_off[id[Z]] = S[Z];
+    if (id[z + 1] != id[z]) item_off[id[z]] = S[z];
+}
+__global__ __launch_bounds__(PS_THREADS) void k_pf_sort_items(unsigned long long* __restrict__ keys, uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off, uint32_t* __restrict__ ctr) {
+    // Bitonic network on (key, value) in LDS.  Every wave owns a quarter of the array: the stages whose partner distance stays inside
+    // a quarter are run by that wave alone, in lock step, without block barriers (63 of the 66 stages of a 2048-pair item); only
+    // the three stages that pair elements of different quarters meet at a barrier.  (A barrier per stage: 67 us per item, 1.9 ms
+    // for the 29 k items of configs[2].)
+    __shared__ unsigned long long sk[PS_CAP];
+    __shared__ unsigned long long sv[PS_CAP];
+    const uint32_t off = item_off[blockIdx.x], n = item_off[blockIdx.x + 1] - off;
+    if (n < 2) return;
+    if (n > (uint32_t)PS_CAP) { if (threadIdx.x == 0) ctr[7] = 1u; return; }
+    uint32_t N2 = 2; while (N2 < n) N2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < N2; i += PS_THREADS) { sk[i] = i < n ? keys[off + i] : ~0ull; sv[i] = i < n ? vals[off + i] : ~0ull; }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t SEG = max(N2 / (PS_THREADS / 64), 128u);                // elements of a wave's segment (a power of two, >= 2 per lane)
+    const bool wave_on = wave * SEG < N2;
+    auto cmpx = [&](uint32_t p, uint32_t j, uint32_t k) {                 // pair number p of stage (k, j)
+        const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), x = i | j;
+        const unsigned long long ka = sk[i], kb = sk[x], va = sv[i], vb = sv[x];
+        const bool gt = ka > kb || (ka == kb && va > vb);
+        if (gt == ((i & k) == 0)) { sk[i] = kb; sk[x] = ka; sv[i] = vb; sv[x] = va; }
+    };
+    __syncthreads();
+    for (uint32_t k = 2; k <= N2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= SEG) {                                               // partners in different segments: the whole block, between barriers
+                __syncthreads();
+                for (uint32_t p = threadIdx.x; p < N2 / 2; p += PS_THREADS) cmpx(p, j, k);
+                __syncthreads();
+            } else {
+                if (wave_on) for (uint32_t p = lane; p < min(SEG, N2) / 2; p += 64) cmpx(wave * (SEG / 2) + p, j, k);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's exchanges have landed before its next stage reads
+            }
+        }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += PS_THREADS) { keys[off + i] = sk[i]; vals[off + i] = sv[i]; }
+}
+
+// (key, value) hits in the shard slices of im->d_keys / d_vals -> out_keys / out_vals (n entries each) sorted by (key, value).
+// Cells as in the basefc fold: every SNP gets 2^l cell groups so that a group holds about C / 2 hits (a SNP in a hot gene is tens of
+// thousands of reads deep); the groups of a SNP are in cell order, so cell order = key order.  0 = done, PF_FALLBACK = use the radix
+// sort (the shard slices are untouched either way), < 0 = error.  Scratch from im->ws2.
+static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> kl, size_t n, unsigned long long* out_keys, uint64_t* out_vals) {
+    typedef unsigned long long K;
+    if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;
+    const uint32_t n_rows = (uint32_t)std::max(im->n_snps_sorted, 1);
+    int lgC = 0;
+    { const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }
+    PartGeom g; memset(&g, 0, sizeof g); g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.sb = PF_SB_MAX; g.n_cells = (uint32_t)im->n_cells;
+    const int lg_max = std::max(0, std::min(pf_env_int("XCK_FOLD_LGG", 8), kl.cbits));
+    ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
+    for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
+    const unsigned n_chunks = sc.chunk0[NSHARD];
+    const uint32_t stride = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n_chunks / 4096));
+    ShardChunks scs = sc;
+    for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((im->cur[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
+    BigChunks bc0; memset(&bc0, 0, sizeof bc0);
+    const size_t rs = (size_t)n_rows + 1;
+    const size_t z_cap = (size_t)n_rows + 4 * ((n + (size_t)NSHARD * stride * PT_CHUNK) >> lgC) + 64;
+    if (z_cap > (size_t(1) << 26)) return PF_FALLBACK;
+    const size_t zs_cap = z_cap + 1, wi_cap = 3 * (n >> lgC) + 8;
+    const size_t sb = (std::max(std::max(zs_cap, rs), wi_cap + 1) + SC_TILE - 1) / SC_TILE + 8;
+    int rc;
+    if ((rc = arena_begin(im, im->ws2, 3 * (rs * 4 + 256) + 2 * (zs_cap * 4 + 256) + (wi_cap + 1) * 4 + sb * 4 + 64 * 4 + (1 << 16)))) return rc;
+    uint32_t* rowcnt = im->ws2.get<uint32_t>(rs); uint32_t* zb = im->ws2.get<uint32_t>(rs); uint32_t* rowtab = im->ws2.get<uint32_t>(rs);
+    uint32_t* S = im->ws2.get<uint32_t>(zs_cap); uint32_t* fs = im->ws2.get<uint32_t>(zs_cap); uint32_t* item_off = im->ws2.get<uint32_t>(wi_cap + 1);
+    uint32_t* bsum = im->ws2.get<uint32_t>(sb); uint32_t* ctr = im->ws2.get<uint32_t>(64);
+    if (!rowcnt || !zb || !rowtab || !S || !fs || !item_off || !bsum || !ctr) { im->eng->err = "workspace exhausted (pileup partition)"; return XCK_E_NOMEM; }
+    g.rowtab = rowtab;
+    unsigned long long* h_ctr = im->h_ctl + CTL_X0; unsigned long long* d_hctr = im->d_hctl + CTL_X0;   // (the k_expand words: not in use yet)
+    const unsigned gr = (unsigned)((rs + 255) / 256);
+    HIP_TRY(hipMemsetAsync(rowcnt, 0, rs * 4, im->s_comp));
+    HIP_TRY(hipMemsetAsync(ctr, 0, 64 * 4, im->s_comp));
+    hipLaunchKernelGGL(k_pf_rowhist, dim3(scs.chunk0[NSHARD]), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, scs, stride, kl.ubits + kl.cbits, rowcnt);
+    hipLaunchKernelGGL(k_pf_rowplan, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)rowcnt, n_rows, stride, 0, lg_max, lgC, zb);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pf_scan(im, zb, rs, bsum, ctr + 8))) return rc;
+    hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    const uint32_t Z = (uint32_t)h_ctr[8];
+    if ((size_t)Z > z_cap) { im->eng->err = "internal: pileup cells exceed their bound"; return XCK_E_STATE; }
+    const size_t zs = (size_t)Z + 1;
+    const unsigned gz = (unsigned)((zs + 255) / 256);
+    hipLaunchKernelGGL(k_pf_rowtab, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)zb, n_rows, kl.cbits, rowtab, (uint32_t*)nullptr);
+    HIP_TRY(hipMemsetAsync(S, 0, zs * 4, im->s_comp));
+    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_chunks), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pf_scan(im, S, zs, bsum, nullptr))) return rc;
+    hipLaunchKernelGGL(k_pf_plan0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, lgC, fs, ctr);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pf_scan(im, fs, zs, bsum, ctr + 0))) return rc;
+    hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    if (h_ctr[5]) {                                                                       // a (SNP, cell group) with more hits than an item holds
+        if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] pileup partition sort: a cell group exceeds an item (n=%zu cells=%u): radix sort\n", n, Z);
+        return PF_FALLBACK;
+    }
+    const size_t n_items = h_ctr[0];
+    if (n_items > wi_cap) { im->eng->err = "internal: pileup items exceed their bound"; return XCK_E_STATE; }
+    hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
+    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_chunks), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S, out_keys, (const uint64_t*)im->d_vals, out_vals);
+    hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(im->s_comp));
+    if (h_ctr[7]) { im->eng->err = "internal: a pileup item exceeds its capacity"; return XCK_E_STATE; }
+    if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] pileup partition sort: n=%zu snps=%u cells=%u items=%zu C=%d\n", n, n_rows, Z, n_items, 1 << lgC);
+    return 0;
 }

@@ -17,6 +17,12 @@
 // LEVEL 1-9: zlib; 0: csrc/deflate_fast.h (greedy LZ77 + dynamic Huffman, ~10x less CPU than zlib -6; streams are
 // about 8 % larger).  CONTIGS.tsv: name<TAB>length ; REGIONS.tsv: chrom start end name (chrom must match a contig name
 // after stripping "chr") ; BARCODES.tsv: one barcode per line.  XCK_SYNTH_NOTAGS=1: no CB / UB tags (well-based style).
+// XCK_SYNTH_SHAPE selects the record shape:
+//   (unset)     the SURVEY 8d shape: 12-character read names, tags NH CB UB, ~230 bytes per record
+//   cellranger  what a Cell Ranger possorted_genome_bam.bam record looks like: 39-character Illumina read names and 16 aux tags
+//               (NH HI AS nM RE xf li RG TX GX GN CR CY CB UR UY UB - CB / UB near the END of the tag list), ~470 bytes per record
+//   smartseq    BASELINE configs[4]: paired-end 2 x 75, mates share the read name, flags 99 / 147 / 83 / 163 (3 % of the pairs
+//               not "proper": orphans for --countORPHAN), no CB / UB tags (N_READS counts records = 2 x pairs)
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
@@ -85,7 +91,10 @@ int main(int argc, char** argv) {
     const int64_t n_reads = atoll(argv[5]); const uint64_t seed = strtoull(argv[6], nullptr, 10);
     int n_thr = argc > 7 ? atoi(argv[7]) : (int)std::thread::hardware_concurrency(); if (n_thr <= 0) n_thr = 4;
     const int level = argc > 8 ? atoi(argv[8]) : 6;
-    const bool no_tags = getenv("XCK_SYNTH_NOTAGS") && atoi(getenv("XCK_SYNTH_NOTAGS"));
+    const char* shape_env = getenv("XCK_SYNTH_SHAPE");
+    const bool cr_shape = shape_env && !strcmp(shape_env, "cellranger"), paired = shape_env && !strcmp(shape_env, "smartseq");
+    if (shape_env && *shape_env && !cr_shape && !paired) { fprintf(stderr, "unknown XCK_SYNTH_SHAPE '%s'\n", shape_env); return 2; }
+    const bool no_tags = paired || (getenv("XCK_SYNTH_NOTAGS") && atoi(getenv("XCK_SYNTH_NOTAGS")));
     std::vector<std::string> cname; std::vector<int32_t> clen;
     { std::ifstream f(argv[2]); std::string a; int64_t l; while (f >> a >> l) { cname.push_back(a); clen.push_back((int32_t)l); } }
     std::vector<Gene> genes;
@@ -96,7 +105,7 @@ int main(int argc, char** argv) {
     std::vector<std::string> bcs;
     { std::ifstream f(argv[4]); std::string b; while (f >> b) bcs.push_back(b); }
     if (cname.empty() || genes.empty() || bcs.empty() || n_reads <= 0) { fprintf(stderr, "empty contigs / regions / barcodes\n"); return 2; }
-    const int L = 91;
+    const int L = paired ? 75 : 91;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     const size_t n_ctg = cname.size();
@@ -108,7 +117,7 @@ int main(int argc, char** argv) {
       std::vector<double> w(genes.size()); double acc = 0;
       for (size_t i = 0; i < perm.size(); i++) { w[perm[i]] = 1.0 / std::pow((double)(i + 1), 0.8); }
       for (double x : w) acc += x;
-      const double M = std::ceil((double)n_reads / 4.5 * 1.005) + 8;
+      const double M = std::ceil((double)n_reads / (paired ? 9.0 : 4.5) * 1.005) + 8;
       double run = 0; uint64_t prev = 0;
       for (size_t g = 0; g < genes.size(); g++) { run += w[g] / acc; const uint64_t cur = (uint64_t)std::floor(M * std::min(run, 1.0) + 1e-9); mol_n[g] = (uint32_t)(cur - prev); prev = cur; mol_base[g + 1] = (uint32_t)cur; } }
     // ---- phase 1: the records of every contig, sorted (parallel over contigs, largest first) ----
@@ -123,7 +132,7 @@ int main(int argc, char** argv) {
               const size_t oi = next.fetch_add(1); if (oi >= n_ctg) break;
               const int t = order[oi];
               std::vector<Rec>& v = recs[t];
-              v.reserve((size_t)(weight[t] * 4.6) + 16);
+              v.reserve((size_t)(weight[t] * (paired ? 9.2 : 4.6)) + 16);
               for (uint32_t g : genes_of[t]) {
                   const Gene& ge = genes[g];
                   const int64_t span = (int64_t)ge.e - ge.s + 40;
@@ -135,7 +144,10 @@ int main(int argc, char** argv) {
                       for (uint32_t q = 0; q < k; q++) {
                           int64_t pos = anchor + r.below(200); if (pos < 0) pos = 0;
                           if (pos > clen[t] - L - 25000) pos = std::max<int64_t>(0, clen[t] - L - 25000);
-                          v.push_back({(int32_t)pos, mol, q});
+                          if (!paired) { v.push_back({(int32_t)pos, mol, q}); continue; }
+                          int64_t mpos = pos + 60 + r.below(300);                     // the mate: same read name, its own record
+                          if (mpos > clen[t] - L - 25000) mpos = std::max<int64_t>(0, clen[t] - L - 25000);
+                          v.push_back({(int32_t)pos, mol, 2 * q}); v.push_back({(int32_t)mpos, mol, 2 * q + 1});
                       }
                   }
               }
@@ -191,13 +203,26 @@ int main(int argc, char** argv) {
                 int64_t rlen = 0; for (int c = 0; c < nc; c++) { const int op = cig[c] & 15; if (op == 0 || op == 2 || op == 3) rlen += cig[c] >> 4; }
                 const uint8_t mapq = r.uni() < 0.9 ? 255 : (uint8_t)(r.below(3) == 2 ? 3 : r.below(2));
                 uint16_t flag = r.below(2) ? 16 : 0; if (r.uni() < 0.03) flag |= 256; if (r.uni() < 0.05) flag |= 1024;
-                char qn[24]; int ql;                                        // "r%010llu" + NUL
+                char qn[48]; int ql;                                        // "r%010llu" + NUL
                 { unsigned long long v = (unsigned long long)(rec_base[S.tid] + i); int nd = 10; for (unsigned long long t = 10000000000ull; v >= t; t *= 10) nd++;
                   qn[0] = 'r'; for (int j = nd; j >= 1; j--) { qn[j] = (char)('0' + v % 10); v /= 10; } qn[nd + 1] = 0; ql = nd + 2; }
+                if (cr_shape) {                                             // instrument:run:flowcell:lane:tile:x:y - 39 characters
+                    const unsigned long long v = (unsigned long long)(rec_base[S.tid] + i);
+                    ql = 1 + snprintf(qn, sizeof qn, "A00228:279:HFWFVDMXX:%u:%04u:%05u:%05u", 1 + (unsigned)(v % 4), 1101 + (unsigned)((v / 40000000000ull) % 8899),
+                                      (unsigned)((v / 4) % 100000), (unsigned)((v / 400000) % 100000));
+                }
+                if (paired) {                                               // the pair's name (both mates), pair-level strand / properness
+                    Rng pr(seed * 0x9E3779B1ull + (((uint64_t)R.mol << 4) | (R.k >> 1)));
+                    const bool rev = pr.below(2) != 0, proper = pr.uni() >= 0.03, first = (R.k & 1) == 0;
+                    flag = (uint16_t)(1 | (proper ? 2 : 0) | (first ? 64 : 128) | ((first ? rev : !rev) ? 16 : 32));
+                    if (pr.uni() < 0.03) flag |= 256;
+                    ql = 1 + snprintf(qn, sizeof qn, "SRR.%u.%u", (unsigned)R.mol, (unsigned)(R.k >> 1));
+                }
                 rec.clear();
                 put32(rec, (uint32_t)S.tid); put32(rec, (uint32_t)R.pos); rec.push_back((uint8_t)ql); rec.push_back(mapq);
                 put16(rec, (uint16_t)reg2bin(R.pos, R.pos + (rlen ? rlen : 1))); put16(rec, (uint16_t)nc); put16(rec, flag); put32(rec, L);
-                put32(rec, (uint32_t)-1); put32(rec, (uint32_t)-1); put32(rec, 0);
+                if (paired) { put32(rec, (uint32_t)S.tid); put32(rec, (uint32_t)R.pos); put32(rec, 0); }   // (mate fields: same reference; xcltk reads the flags only)
+                else { put32(rec, (uint32_t)-1); put32(rec, (uint32_t)-1); put32(rec, 0); }
                 putn(rec, qn, ql); putn(rec, cig, nc * 4);
                 { uint8_t sq[(91 + 1) / 2]; uint64_t x = 0; int left = 0;                // two random bases per byte (4 bits of entropy)
                   for (int j = 0; j < (L + 1) / 2; j++) { if (!left) { x = r.next(); left = 16; } sq[j] = (uint8_t)(((1u << (x & 3)) << 4) | (1u << ((x >> 2) & 3))); x >>= 4; left--; }
@@ -206,9 +231,24 @@ int main(int argc, char** argv) {
                   for (int j = 0; j < L; j++) { if (!left) { x = r.next(); left = 32; } ql_[j] = q4[x & 3]; x >>= 2; left--; }
                   putn(rec, ql_, L); }
                 putn(rec, "NHC", 3); rec.push_back(1);
+                if (cr_shape) {                                             // the tags Cell Ranger writes before the barcode / UMI tags
+                    const uint32_t gene = (uint32_t)(std::upper_bound(mol_base.begin(), mol_base.end(), R.mol) - mol_base.begin()) - 1;
+                    char tx[64];
+                    putn(rec, "HIC", 3); rec.push_back(1); putn(rec, "ASC", 3); rec.push_back((uint8_t)(L - 2)); putn(rec, "nMC", 3); rec.push_back((uint8_t)r.below(3));
+                    putn(rec, "REA", 3); rec.push_back('E'); putn(rec, "xfC", 3); rec.push_back(25); putn(rec, "liC", 3); rec.push_back(0);
+                    putn(rec, "RGZ", 3); putn(rec, "synth:0:1:HFWFVDMXX:1", 22);
+                    putn(rec, "TXZ", 3); putn(rec, tx, 1 + (size_t)snprintf(tx, sizeof tx, "ENST%011u,+%u,%dM", gene * 7 + 3, (unsigned)r.below(3000), L));
+                    putn(rec, "GXZ", 3); putn(rec, tx, 1 + (size_t)snprintf(tx, sizeof tx, "ENSG%011u", gene + 100000));
+                    putn(rec, "GNZ", 3); putn(rec, tx, 1 + (size_t)snprintf(tx, sizeof tx, "GENE%05u", gene));
+                    char raw[17]; if (cell >= 0) memcpy(raw, bcs[cell].c_str(), 16); else { uint64_t x = mix(R.mol); for (int j = 0; j < 16; j++) { raw[j] = "ACGT"[x & 3]; x >>= 2; } } raw[16] = 0;
+                    char q16[17]; { uint64_t x = r.next(); for (int j = 0; j < 16; j++) { q16[j] = (x & 7) ? 'F' : ','; x >>= 3; } q16[16] = 0; }
+                    putn(rec, "CRZ", 3); putn(rec, raw, 17); putn(rec, "CYZ", 3); putn(rec, q16, 17);
+                }
                 if (!no_tags) {                                       // XCK_SYNTH_NOTAGS=1: well-based (SMART-seq) style BAM without CB / UB
                     if (cell >= 0) { putn(rec, "CBZ", 3); putn(rec, bcs[cell].c_str(), bcs[cell].size() + 1); }
                     else if (outside) { putn(rec, "CBZ", 3); uint64_t x = m.next(); for (int j = 0; j < 16; j++) { rec.push_back((uint8_t)"ACGT"[x & 3]); x >>= 2; } putn(rec, "-9", 3); }
+                    if (cr_shape) { char q12[13]; uint64_t x = r.next(); for (int j = 0; j < 12; j++) { q12[j] = (x & 7) ? 'F' : ':'; x >>= 3; } q12[12] = 0;
+                                    putn(rec, "URZ", 3); putn(rec, umi, 13); putn(rec, "UYZ", 3); putn(rec, q12, 13); }
                     if (has_ub) { putn(rec, "UBZ", 3); putn(rec, umi, 13); }
                 }
                 const uint32_t bs = (uint32_t)rec.size();
