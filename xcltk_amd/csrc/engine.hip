@@ -668,7 +668,10 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     constexpr int CAP_ENTRIES = JoinSmem<K, MODE>::USE_SET ? JoinSmem<K, MODE>::SLOTS : JoinSmem<K, MODE>::QCAP;
     // set mode: the de-duplicated fill of a 1024-read tile is a few hundred keys, so flush once, at the end
     // (better de-duplication, half the cursor atomics); saturation still spills correctly through emit_global()
-    constexpr int FLUSH_EVERY = (JoinSmem<K, MODE>::SPLIT || JoinSmem<K, MODE>::USE_SET) ? TILE_ITEMS
+#ifndef XCK_SET_FLUSH_EVERY
+#define XCK_SET_FLUSH_EVERY TILE_ITEMS
+#endif
+    constexpr int FLUSH_EVERY = JoinSmem<K, MODE>::USE_SET ? XCK_SET_FLUSH_EVERY : JoinSmem<K, MODE>::SPLIT ? TILE_ITEMS
                               : ((CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)) < 1 ? 1 : (CAP_ENTRIES / 2 / (JOIN_BLOCK * 2)));
 #pragma unroll
     for (int j = 0; j < TILE_ITEMS; j++) {

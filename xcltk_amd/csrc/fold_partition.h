@@ -35,9 +35,12 @@
 #pragma once
 
 constexpr int PF_FALLBACK = 1;
-constexpr int PF_C_MAX = 1024;                         // page size C (keys); a work item holds at most CAP = 2C keys
+#ifndef XCK_PF_C
+#define XCK_PF_C 1024
+#endif
+constexpr int PF_C_MAX = XCK_PF_C;                     // page size C (keys); a work item holds at most CAP = 2C keys
 constexpr int PF_CAP_MAX = 2 * PF_C_MAX;
-constexpr int PF_SLOTS = 4096;                         // LDS set of k_pf_bucket: 32 KB, load <= 0.5
+constexpr int PF_SLOTS = 4 * PF_C_MAX;                 // LDS set of k_pf_bucket: 32 KB at C = 1024, load <= 0.5
 #ifndef XCK_PF_THREADS
 #define XCK_PF_THREADS 512
 #endif
@@ -181,6 +184,19 @@ __device__ __forceinline__ ChunkLoc pf_locate2(const BigChunks& bc, uint32_t chu
     L.n = min((uint32_t)PT_CHUNK, bc.cnt[b] - c * PT_CHUNK); L.zbase = bc.z2base[b]; L.sub_mask = (1u << bc.sg[b]) - 1u; L.eb = (int)(bc.eb[b] & 31u); L.tb = (int)(bc.eb[b] >> 5);
     return L;
 }
+// Level 1 through a per-block LDS cache of the row table (direct-mapped, row << 32 | entry): a chunk holds a handful of rows, and
+// 16 table look-ups per thread, all lanes at once, kept the address unit busy for 21 k cycles per chunk (the phase stamps of
+// k_pf_part<1>); now the first key of a thread goes to the table in HBM / L2 and fills the cache, the others mostly hit it.
+constexpr int PT_RC = 256;
+__device__ __forceinline__ uint32_t pf_cell1_cached(unsigned long long key, const PartGeom& g, unsigned long long* s_rc, bool use_cache) {
+    const unsigned long long rc = key >> g.ubits;
+    const uint32_t row = (uint32_t)(rc >> g.cbits);
+    uint32_t t;
+    const unsigned long long e = use_cache ? s_rc[row & (PT_RC - 1)] : ~0ull;
+    if ((uint32_t)(e >> 32) == row) t = (uint32_t)e;
+    else { t = g.rowtab[row]; s_rc[row & (PT_RC - 1)] = ((unsigned long long)row << 32) | t; }
+    return (t >> 5) + (((uint32_t)rc & ((1u << g.cbits) - 1u)) >> (t & 31u));
+}
 template <int LEVEL>
 __device__ __forceinline__ uint32_t pf_cell(unsigned long long key, const PartGeom& g, const ChunkLoc& L) {
     const unsigned long long rc = key >> g.ubits;
@@ -243,6 +259,30 @@ __global__ void k_pf_rowtab(const uint32_t* __restrict__ zb, uint32_t n_rows, in
     if (zrow) for (uint32_t q = 0; q < G; q++) zrow[base + q] = r;
 }
 
+// The keys of a block.  Level 2: PT_CHUNK consecutive keys of one big z.  Level 0 / 1: the SAME 512-key segment of each of the 16
+// shard slices (thread t, key q = slice q, position block * 512 + t): the slices are filled round-robin by consecutive join tiles, so
+// equal positions hold keys of the same stretch of the file - a block then meets ALL keys of a narrow position range (a gene with
+// 50 k keys used to be 16 runs of 3 k keys in 16 different blocks: 16 x the (block, cell) pairs, i.e. atomics, and runs 16 x
+// shorter).  ok = bit q set when key q exists.
+static_assert(PT_KPT == NSHARD, "one key per shard slice and thread");
+template <int LEVEL>
+__device__ __forceinline__ uint32_t pf_load_keys(const unsigned long long* __restrict__ keys, const ShardChunks& sc, const ChunkLoc& L, unsigned long long (&k)[PT_KPT]) {
+    uint32_t ok = 0;
+#pragma unroll
+    for (int q = 0; q < PT_KPT; q++) {
+        k[q] = 0ull;
+        if (LEVEL == 2) { const uint32_t i = q * PT_THREADS + threadIdx.x; if (i < L.n) { k[q] = keys[L.base + i]; ok |= 1u << q; } }
+        else { const uint32_t i = blockIdx.x * PT_THREADS + threadIdx.x; if (i < sc.cnt[q]) { k[q] = keys[(unsigned long long)q * sc.cap + i]; ok |= 1u << q; } }
+    }
+    return ok;
+}
+// where key number src (= q * PT_THREADS + thread) of the block came from (the pileup's values sit at the same place of their own array)
+template <int LEVEL>
+__device__ __forceinline__ unsigned long long pf_src_index(const ShardChunks& sc, const ChunkLoc& L, uint32_t src) {
+    if (LEVEL == 2) return L.base + src;
+    return (unsigned long long)(src / PT_THREADS) * sc.cap + (unsigned long long)blockIdx.x * PT_THREADS + (src % PT_THREADS);
+}
+
 // Level 1 keeps 2^pl copies of every counter / cursor (copy = block index mod 2^pl; the copies of a cell are adjacent, so the scan
 // lays a cell's keys out copy after copy): the chunks of a hot gene - thousands in flight - otherwise queue on the same ~150
 // addresses, and device-scope atomics on one address serialise at well under 2 per microsecond (first version: 5.4 ms for the
@@ -252,18 +292,23 @@ __global__ __launch_bounds__(PT_THREADS) void k_pf_hist(const unsigned long long
     __shared__ AggTab t;
     __shared__ uint32_t s_b;
     for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
+    __shared__ unsigned long long s_rc[LEVEL == 1 ? PT_RC : 1];
+    if (LEVEL == 1) for (int s = threadIdx.x; s < PT_RC; s += PT_THREADS) s_rc[s] = ~0ull;
     const uint32_t copy = pf_copy_of_block(pl);
-    const ChunkLoc L = LEVEL != 2 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
+    ChunkLoc L; L.base = 0; L.n = 0; L.zbase = 0; L.sub_mask = 0; L.eb = 0; L.tb = 0;
+    if (LEVEL == 2) L = pf_locate2(bc, blockIdx.x, &s_b);
     unsigned long long k[PT_KPT];
-#pragma unroll
-    for (int q = 0; q < PT_KPT; q++) { const uint32_t i = q * PT_THREADS + threadIdx.x; k[q] = i < L.n ? keys[L.base + i] : 0ull; }
+    const uint32_t ok = pf_load_keys<LEVEL>(keys, sc, L, k);
     __syncthreads();
     uint32_t zq[PT_KPT];
 #pragma unroll
-    for (int q = 0; q < PT_KPT; q++) zq[q] = (uint32_t)(q * PT_THREADS + threadIdx.x) < L.n ? pf_cell<LEVEL>(k[q], g, L) : 0u;   // (level 1: a table look-up per key - all in flight together)
+    for (int q = 0; q < PT_KPT; q++) {
+        if (!((ok >> q) & 1u)) { zq[q] = 0u; continue; }
+        zq[q] = LEVEL == 1 ? pf_cell1_cached(k[q], g, s_rc, q > 0) : pf_cell<LEVEL>(k[q], g, L);
+    }
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) {
-        if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n) continue;
+        if (!((ok >> q) & 1u)) continue;
         const uint32_t z = zq[q];
 #ifdef XCK_EXP_HIST_NOLDS
         if (z == 0xfffffff0u) atomicAdd(&hist[0], 1u);
@@ -295,17 +340,22 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     long long t_s0 = clock64();
 #endif
     for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
+    __shared__ unsigned long long s_rc[LEVEL == 1 ? PT_RC : 1];
+    if (LEVEL == 1) for (int s = threadIdx.x; s < PT_RC; s += PT_THREADS) s_rc[s] = ~0ull;
     const uint32_t copy = pf_copy_of_block(pl);
-    const ChunkLoc L = LEVEL != 2 ? pf_locate1(sc, blockIdx.x) : pf_locate2(bc, blockIdx.x, &s_b);
+    ChunkLoc L; L.base = 0; L.n = 0; L.zbase = 0; L.sub_mask = 0; L.eb = 0; L.tb = 0;
+    if (LEVEL == 2) L = pf_locate2(bc, blockIdx.x, &s_b);
     unsigned long long k[PT_KPT];
-#pragma unroll
-    for (int q = 0; q < PT_KPT; q++) { const uint32_t i = q * PT_THREADS + threadIdx.x; k[q] = i < L.n ? keys[L.base + i] : 0ull; }
+    const uint32_t ok = pf_load_keys<LEVEL>(keys, sc, L, k);
     __syncthreads();
     PF_STAMP(0);                                                          // keys arrived
     uint32_t sr[PT_KPT];                                                  // first the key's cell, then slot << 16 | rank in the slot's run; ~0 = not in the table
     static_assert(PT_CHUNK <= 65536 && PT_TAB <= 32768, "slot and rank share a word");
 #pragma unroll
-    for (int q = 0; q < PT_KPT; q++) sr[q] = (uint32_t)(q * PT_THREADS + threadIdx.x) < L.n ? pf_cell<LEVEL>(k[q], g, L) : 0xffffffffu;   // (level 1: a table look-up per key - all in flight together)
+    for (int q = 0; q < PT_KPT; q++) {
+        if (!((ok >> q) & 1u)) { sr[q] = 0xffffffffu; continue; }
+        sr[q] = LEVEL == 1 ? pf_cell1_cached(k[q], g, s_rc, q > 0) : pf_cell<LEVEL>(k[q], g, L);
+    }
 #ifdef XCK_EXP_PART_STAMPS
     { uint32_t x = 0;
 #pragma unroll
@@ -316,7 +366,7 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 #endif
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) {
-        if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n) continue;
+        if (!((ok >> q) & 1u)) continue;
         const int slot = agg_find(t, sr[q]);
         sr[q] = slot >= 0 ? ((uint32_t)slot << 16) | atomicAdd(&t.cnt[slot], 1u) : 0xffffffffu;
     }
@@ -362,16 +412,16 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 #ifdef XCK_EXP_PART_NOSTORE
             if (dst == 0xfffffff0u)
 #endif
-            { out[dst] = s_key[i]; if (vals) out_vals[dst] = vals[L.base + s_src[i]]; }   // (pileup hits: the value travels with its key)
+            { out[dst] = s_key[i]; if (vals) out_vals[dst] = vals[pf_src_index<LEVEL>(sc, L, s_src[i])]; }   // (pileup hits: the value travels with its key)
         }
         __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) {                                    // keys that found no place in the table (a chunk with too many cells)
-        if ((uint32_t)(q * PT_THREADS + threadIdx.x) >= L.n || sr[q] != 0xffffffffu) continue;
+        if (!((ok >> q) & 1u) || sr[q] != 0xffffffffu) continue;
         const uint32_t dst = PF_GADD(&cursor[(pf_cell<LEVEL>(k[q], g, L) << pl) | copy], 1u);
         out[dst] = k[q];
-        if (vals) out_vals[dst] = vals[L.base + q * PT_THREADS + threadIdx.x];
+        if (vals) out_vals[dst] = vals[pf_src_index<LEVEL>(sc, L, q * PT_THREADS + threadIdx.x)];
     }
 #ifdef XCK_EXP_PART_STAMPS
     PF_STAMP(3);                                                          // stores issued
@@ -669,11 +719,15 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     PartGeom g; g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.n_cells = (uint32_t)im->n_cells;
     g.sb = std::min(PF_SB_MAX, std::max(kl.cbits, 11));                                    // 14 cell bits: one row per span, a 2 KB bitmap
     const int lg_min = std::max(0, kl.cbits - g.sb);                                      // a level-1 cell never straddles two spans
-    const int lg_max = std::max(lg_min, std::min(pf_env_int("XCK_FOLD_LGG", 8), kl.cbits));
+    // at most 2^6 cell groups per row: more groups keep more keys out of level 2 but leave the level-1 kernels more (block, cell) pairs -
+    // atomics, short runs (A/B on one box at configs[2]: 8 -> 9.6 ms, 7 -> 8.9, 6 -> 8.7, 5 -> 8.9; profiles/r03_x_fold_variants_ab.log)
+    const int lg_max = std::max(lg_min, std::min(pf_env_int("XCK_FOLD_LGG", 6), kl.cbits));
     const uint32_t n_rows = (uint32_t)im->n_regions;
     ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
     const unsigned n_chunks1 = sc.chunk0[NSHARD];
+    size_t max_cur = 0; for (int sh = 0; sh < NSHARD; sh++) max_cur = std::max<size_t>(max_cur, im->cur[sh]);
+    const unsigned n_blocks1 = (unsigned)((max_cur + PT_THREADS - 1) / PT_THREADS);       // level-1 blocks: segment b of every slice
     const uint32_t stride = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n_chunks1 / 4096));          // the row sample: one piece of 64 keys in `stride`, >= 16 M keys
     ShardChunks scs = sc;                                                                  // its blocks: PT_CHUNK * stride stream keys each
     for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((im->cur[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
@@ -716,7 +770,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     // ---- level 1: histogram over the cells, work items
     const size_t ss = ((size_t)Z << pl) + 1;
     HIP_TRY(hipMemsetAsync(S1, 0, ss * 4, im->s_comp));
-    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_chunks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1);
+    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1);
     HIP_TRY(hipGetLastError());
     if ((rc = pf_scan(im, S1, ss, bsum, nullptr))) return rc;
     hipLaunchKernelGGL(k_pf_plan1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, fs, fb, fc, fz, ctr);
@@ -748,12 +802,12 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     hipLaunchKernelGGL(k_pf_emit1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, (const uint32_t*)fs, (const uint32_t*)fb, (const uint32_t*)fc,
                        (const uint32_t*)fz, wi1, big);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_chunks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1, A);   // (S1 is the cursor array from here on)
+    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1, A);   // (S1 is the cursor array from here on)
     HIP_TRY(hipGetLastError());
 #ifdef XCK_EXP_PART_STAMPS
     { unsigned long long st[8]; HIP_TRY(hipStreamSynchronize(im->s_comp)); HIP_TRY(hipMemcpyFromSymbol(st, HIP_SYMBOL(pf_stamps), sizeof st));
-      fprintf(stderr, "[stamps part<1>] blocks=%u cycles per block: load %.0f  cells %.0f  find+rank %.0f  atomics %.0f  store-issue %.0f  store-ack %.0f\n", n_chunks1,
-              (double)st[0] / n_chunks1, (double)st[5] / n_chunks1, (double)st[1] / n_chunks1, (double)st[2] / n_chunks1, (double)st[3] / n_chunks1, (double)st[4] / n_chunks1);
+      fprintf(stderr, "[stamps part<1>] blocks=%u cycles per block: load %.0f  cells %.0f  find+rank %.0f  atomics %.0f  store-issue %.0f  store-ack %.0f\n", n_blocks1,
+              (double)st[0] / n_blocks1, (double)st[5] / n_blocks1, (double)st[1] / n_blocks1, (double)st[2] / n_blocks1, (double)st[3] / n_blocks1, (double)st[4] / n_blocks1);
       memset(st, 0, sizeof st); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pf_stamps), st, sizeof st)); }
 #endif
     const int lds = pf_bucket_lds(g.sb);
@@ -887,10 +941,12 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     int lgC = 0;
     { const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }
     PartGeom g; memset(&g, 0, sizeof g); g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.sb = PF_SB_MAX; g.n_cells = (uint32_t)im->n_cells;
-    const int lg_max = std::max(0, std::min(pf_env_int("XCK_FOLD_LGG", 8), kl.cbits));
+    const int lg_max = std::max(0, std::min(pf_env_int("XCK_FOLD_LGG", 6), kl.cbits));
     ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
     const unsigned n_chunks = sc.chunk0[NSHARD];
+    size_t max_cur = 0; for (int sh = 0; sh < NSHARD; sh++) max_cur = std::max<size_t>(max_cur, im->cur[sh]);
+    const unsigned n_blocks1 = (unsigned)((max_cur + PT_THREADS - 1) / PT_THREADS);
     const uint32_t stride = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n_chunks / 4096));
     ShardChunks scs = sc;
     for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((im->cur[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
@@ -924,7 +980,7 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     const unsigned gz = (unsigned)((zs + 255) / 256);
     hipLaunchKernelGGL(k_pf_rowtab, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)zb, n_rows, kl.cbits, rowtab, (uint32_t*)nullptr);
     HIP_TRY(hipMemsetAsync(S, 0, zs * 4, im->s_comp));
-    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_chunks), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S);
+    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S);
     HIP_TRY(hipGetLastError());
     if ((rc = pf_scan(im, S, zs, bsum, nullptr))) return rc;
     hipLaunchKernelGGL(k_pf_plan0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, lgC, fs, ctr);
@@ -940,7 +996,7 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     const size_t n_items = h_ctr[0];
     if (n_items > wi_cap) { im->eng->err = "internal: pileup items exceed their bound"; return XCK_E_STATE; }
     hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
-    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_chunks), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S, out_keys, (const uint64_t*)im->d_vals, out_vals);
+    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S, out_keys, (const uint64_t*)im->d_vals, out_vals);
     hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
