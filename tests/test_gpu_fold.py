@@ -161,3 +161,26 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
     got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
     assert st["pileup_sort_path"] == 2
+
+
+def test_uneven_cells_refine_the_level_two_geometry(fold_env):
+    """Well-based data: every cell has its own hot genes, so the cells of a group are far from even - here 70 % of the reads of 64 cells
+    sit in cell 5.  With 4 cell groups per row and pages of 64 keys the group that holds cell 5 comes out "big", its sub-cells (sized for
+    even cells) overflow, and the fold asks for a finer geometry of that group instead of handing over to the radix fold."""
+    import oracle as O
+    regions, snps, names = soa.make_tables(6, 0, [400000], seed=61, max_len=150000)
+    bs = soa.gen_reads(regions, names, 120000, 64, seed=62)
+    rng = np.random.default_rng(63)
+    for b in bs:
+        c = b["cell"]
+        hot = (rng.random(len(c)) < 0.7) & (c >= 0)
+        c[hot] = 5
+    batches = [util.batch_from_dict(b) for b in bs]
+    cfg_kw = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True, min_include=0.9, min_count=1, min_maf=0, no_dup_hap=True)
+    cfg, keep = O.make_config(capi.XCK_MODE_BASEFC, names, regions, [], 64, **cfg_kw)
+    exp = O.run_oracle(cfg, [b for b, _ in batches])
+    fold_env.pop("XCK_FOLD", None)
+    fold_env["XCK_FOLD_C"], fold_env["XCK_FOLD_LGG"] = "64", "2"
+    got, st = _run(names, regions, 64, batches)
+    util.assert_coo_equal(got, exp, ["count"])
+    assert st["fold_path"] == 1 and st["fold_refinements"] >= 1

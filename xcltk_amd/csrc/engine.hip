@@ -1512,6 +1512,7 @@ struct EngineImpl {
     int fold_extra_digits = 0;                 // basefc hash fold: extra radix digits that earlier finishes needed (giant runs)
     int fold_path = 0, fold_fallbacks = 0;     // xck_stats: which basefc fold ran last (1 partition, 2 radix sort), hand-overs so far
     int pileup_sort_path = 0;                  // pileup hits of the last finish: 1 sorted by partition + LDS sort, 2 by the radix sort
+    int fold_refinements = 0;                  // partition fold of the last finish: refinements of the level-2 geometry
     // fused launch queue
     std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
     std::vector<BatchDesc> inflight;           // launched, not yet confirmed (kept for overflow replay)
@@ -2397,7 +2398,7 @@ int engine_stats(const xck_engine* e, xck_stats* out) {
     if (!im) return XCK_E_STATE;
     *out = im->st; out->key_bits = im->key_bits; out->umi_bits = im->ubits;
     out->n_join_launches = im->n_join_launches;
-    out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks; out->pileup_sort_path = im->pileup_sort_path; out->reserved0 = 0;
+    out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks; out->pileup_sort_path = im->pileup_sort_path; out->fold_refinements = im->fold_refinements;
     return 0;
 }
 

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
 // S = exclusive scan of the histogram, Z + 1 entries (S[Z] = number of keys).  Flags per cell z: fs = "starts a work item",
 // level 1 also fb = "big" (more than CAP keys: goes through level 2), fc = its number of level-2 chunks, fz = its sub-cells.
 // ctr: [3] += keys in big cells, [5] = 1 when some cell cannot be placed (PF_FALLBACK)
-struct BigArrays { uint32_t* off; uint32_t* cnt; uint32_t* chunk0; uint32_t* wi; uint32_t* span; uint32_t* first2; uint32_t* z2base; uint32_t* sg; uint32_t* eb; uint32_t* rcl0; };
+struct BigArrays { uint32_t* off; uint32_t* cnt; uint32_t* chunk0; uint32_t* wi; uint32_t* span; uint32_t* first2; uint32_t* z2base; uint32_t* sg; uint32_t* eb; uint32_t* rcl0; uint32_t* need; };
 // Level-2 geometry of a big z with c keys over `cells` existing cells (of the 2^sg the z spans; the last group of a row is only
 // partly filled).  depth = keys per cell if the cells were even.  Shallow cells: groups of 2^tb cells of about C / 2 keys; cells
 // deeper than C / 2: tb = 0 and 2^eb UMI-hash parts per cell, at most 2^16 sub-cells per big z.  Returns eb | tb << 5;
@@ -442,8 +442,9 @@ struct BigArrays { uint32_t* off; uint32_t* cnt; uint32_t* chunk0; uint32_t* wi;
 __device__ __forceinline__ uint32_t pf_sub_geom(uint32_t c, int sg, int lgC, uint32_t cells) {
     const uint32_t half = max(1u, (1u << lgC) / 2), depth = (c + cells - 1) / cells;
     if (depth <= half) { int tb = 0; while (tb < sg && (depth << (tb + 1)) <= half) tb++; return (uint32_t)tb << 5; }
+    // (parts of a quarter page: the cells of a group are not even - one that is 4x deeper than the group's mean still fits an item)
     int eb = 0;
-    while (sg + eb < 16 && ((depth + (1u << eb) - 1) >> eb) > half) eb++;
+    while (sg + eb < 16 && ((depth + (1u << eb) - 1) >> eb) > max(1u, half / 2)) eb++;
     return (uint32_t)eb;
 }
 __device__ __forceinline__ uint32_t pf_sub_cells(uint32_t geom, int sg) { return 1u << (sg - (int)(geom >> 5) + (int)(geom & 31u)); }
@@ -462,34 +463,34 @@ __device__ __forceinline__ uint32_t pf_cells_in(uint32_t z, const PartGeom& g, c
     return (uint32_t)min((unsigned long long)g.n_cells - lo, 1ull << sg);
 }
 __global__ void k_pf_plan1(const uint32_t* __restrict__ Sp, int pl, uint32_t Z, PartGeom g, const uint32_t* __restrict__ zrow,
-                           uint32_t* __restrict__ fs, uint32_t* __restrict__ fb, uint32_t* __restrict__ fc, uint32_t* __restrict__ fz, uint32_t* __restrict__ ctr) {
+                           uint32_t* __restrict__ fs, uint32_t* __restrict__ fb, uint32_t* __restrict__ fc, uint32_t* __restrict__ ctr) {
     const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z > Z) return;
-    if (z == Z) { fs[z] = 0; fb[z] = 0; fc[z] = 0; fz[z] = 0; return; }                 // sentinel: the scans then end with the totals
+    if (z == Z) { fs[z] = 0; fb[z] = 0; fc[z] = 0; return; }                             // sentinel: the scans then end with the totals
     const uint32_t C = 1u << g.lgC, CAP = 2u << g.lgC;
     const uint32_t s = Sp[(size_t)z << pl], c = Sp[(size_t)(z + 1) << pl] - s, sp = z ? Sp[(size_t)(z - 1) << pl] : 0u, cp = z ? s - sp : 0u;
     int sg;
     const uint32_t span = pf_span1(z, g, zrow, &sg), spanp = z ? pf_span1(z - 1, g, zrow, nullptr) : 0u;
     const bool start = z == 0 || (s >> g.lgC) != (sp >> g.lgC) || c > C || cp > C || span != spanp;
     const bool big = c > CAP;
-    fs[z] = start ? 1u : 0u; fb[z] = big ? 1u : 0u; fc[z] = big ? (c + PT_CHUNK - 1) / PT_CHUNK : 0u; fz[z] = big ? pf_sub_cells(pf_sub_geom(c, sg, g.lgC, pf_cells_in(z, g, zrow)), sg) : 0u;
+    fs[z] = start ? 1u : 0u; fb[z] = big ? 1u : 0u; fc[z] = big ? (c + PT_CHUNK - 1) / PT_CHUNK : 0u;
     if (big) atomicAdd(&ctr[3], c);
 }
-// id / bid / ch0 / zb2 = exclusive scans of fs / fb / fc / fz (Z + 1 entries each)
+// id / bid / ch0 = exclusive scans of fs / fb / fc (Z + 1 entries each)
 __global__ void k_pf_emit1(const uint32_t* __restrict__ Sp, int pl, uint32_t Z, PartGeom g, const uint32_t* __restrict__ zrow, const uint32_t* __restrict__ id, const uint32_t* __restrict__ bid,
-                           const uint32_t* __restrict__ ch0, const uint32_t* __restrict__ zb2, WorkItem* __restrict__ wi, BigArrays big) {
+                           const uint32_t* __restrict__ ch0, WorkItem* __restrict__ wi, BigArrays big) {
     const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= Z) return;
     if (z == 0) {                                                                      // sentinels
         wi[id[Z]].off = Sp[(size_t)Z << pl]; wi[id[Z]].span = 0; wi[id[Z]].aux = 0xffffffffu;
-        big.chunk0[bid[Z]] = ch0[Z]; big.off[bid[Z]] = Sp[(size_t)Z << pl]; big.cnt[bid[Z]] = 0; big.z2base[bid[Z]] = zb2[Z]; big.sg[bid[Z]] = 0; big.eb[bid[Z]] = 0; big.rcl0[bid[Z]] = 0;
+        big.chunk0[bid[Z]] = ch0[Z]; big.off[bid[Z]] = Sp[(size_t)Z << pl]; big.cnt[bid[Z]] = 0; big.z2base[bid[Z]] = 0; big.sg[bid[Z]] = 0; big.eb[bid[Z]] = 0; big.rcl0[bid[Z]] = 0; big.need[bid[Z]] = 0;
     }
     if (id[z + 1] == id[z]) return;                                                    // not a start
     int sg;
     WorkItem w; w.off = Sp[(size_t)z << pl]; w.pad = 0; w.aux = 0xffffffffu; w.span = pf_span1(z, g, zrow, &sg);
     if (bid[z + 1] != bid[z]) {
         const uint32_t b = bid[z];
-        big.off[b] = Sp[(size_t)z << pl]; big.cnt[b] = Sp[(size_t)(z + 1) << pl] - Sp[(size_t)z << pl]; big.chunk0[b] = ch0[z]; big.wi[b] = id[z]; big.span[b] = w.span; big.z2base[b] = zb2[z]; big.sg[b] = (uint32_t)sg;
+        big.off[b] = Sp[(size_t)z << pl]; big.cnt[b] = Sp[(size_t)(z + 1) << pl] - Sp[(size_t)z << pl]; big.chunk0[b] = ch0[z]; big.wi[b] = id[z]; big.span[b] = w.span; big.z2base[b] = 0; big.sg[b] = (uint32_t)sg; big.need[b] = 0;
         big.eb[b] = pf_sub_geom(Sp[(size_t)(z + 1) << pl] - Sp[(size_t)z << pl], sg, g.lgC, pf_cells_in(z, g, zrow));
         { const uint32_t row = zrow[z], t = g.rowtab[row];                             // (row, cell) of the big z's first cell, inside its span
           big.rcl0[b] = (uint32_t)((((unsigned long long)row << g.cbits) | ((unsigned long long)(z - (t >> 5)) << sg)) & ((1ull << g.sb) - 1ull)); }
@@ -503,7 +504,23 @@ __device__ __forceinline__ uint32_t pf_big_of(const uint32_t* __restrict__ z2bas
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (z2base[mid] <= z2) lo = mid; else hi = mid; }
     return lo;
 }
-__global__ void k_pf_plan2(const uint32_t* __restrict__ S, uint32_t Z, PartGeom g, const uint32_t* __restrict__ z2base, uint32_t n_big, uint32_t* __restrict__ fs, uint32_t* __restrict__ ctr) {
+// The geometry of a big z (pf_sub_geom) assumes its cells even.  Where they are not (well-based data: every cell has its own hot genes) a
+// sub-cell comes out above CAP: its big z then asks for single cells cut into enough UMI-hash parts for the case that ALL keys of the
+// sub-cell belong to one cell (big.need), and the host runs the level-2 histogram again (k_pf_big_refine; ctr[5] = 1).  A z that is
+// already at 2^16 sub-cells cannot be refined: ctr[11] = 1 -> PF_FALLBACK.
+__global__ void k_pf_big_sub(uint32_t n_big, BigArrays big) {                            // big.z2base[b] := sub-cells of b (scanned next)
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_big) return;
+    big.z2base[b] = b < n_big ? pf_sub_cells(big.eb[b], (int)big.sg[b]) : 0u;
+}
+__global__ void k_pf_big_refine(uint32_t n_big, BigArrays big) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_big || !big.need[b]) return;
+    big.eb[b] = big.need[b] - 1u;                                                       // tb = 0, eb = need - 1
+    big.need[b] = 0;
+}
+__global__ void k_pf_plan2(const uint32_t* __restrict__ S, uint32_t Z, PartGeom g, BigArrays big, uint32_t n_big, uint32_t* __restrict__ fs, uint32_t* __restrict__ ctr) {
+    const uint32_t* __restrict__ z2base = big.z2base;
     const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
     if (z > Z) return;
     if (z == Z) { fs[z] = 0; return; }
@@ -511,7 +528,14 @@ __global__ void k_pf_plan2(const uint32_t* __restrict__ S, uint32_t Z, PartGeom 
     const uint32_t s = S[z], c = S[z + 1] - s, sp = z ? S[z - 1] : 0u, cp = z ? s - sp : 0u;
     const bool first = z2base[pf_big_of(z2base, n_big, z)] == z;                          // first sub-cell of a big z
     fs[z] = (z == 0 || first || (s >> g.lgC) != (sp >> g.lgC) || c > C || cp > C) ? 1u : 0u;
-    if (c > CAP) { ctr[5] = 1u; atomicMax(&ctr[10], c); }                                // a sub-cell the geometry could not bring under CAP
+    if (c > CAP) {                                                                    // a sub-cell the geometry could not bring under CAP
+        const uint32_t b = pf_big_of(z2base, n_big, z);
+        const int sg = (int)big.sg[b], eb = (int)(big.eb[b] & 31u), tb = (int)(big.eb[b] >> 5);
+        int more = 1; while ((c >> more) > max(1u, C / 4)) more++;                      // parts that bring c under a quarter page
+        const int eb_new = (tb ? 0 : eb) + more;
+        ctr[5] = 1u; atomicMax(&ctr[10], c);
+        if (sg + eb_new > 16) ctr[11] = 1u; else atomicMax(&big.need[b], (uint32_t)eb_new + 1u);
+    }
 }
 __global__ void k_pf_emit2(const uint32_t* __restrict__ S, uint32_t Z, const uint32_t* __restrict__ id, uint32_t n_big, WorkItem* __restrict__ wi, BigArrays big) {
     const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
@@ -721,7 +745,9 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     const int lg_min = std::max(0, kl.cbits - g.sb);                                      // a level-1 cell never straddles two spans
     // at most 2^6 cell groups per row: more groups keep more keys out of level 2 but leave the level-1 kernels more (block, cell) pairs -
     // atomics, short runs (A/B on one box at configs[2]: 8 -> 9.6 ms, 7 -> 8.9, 6 -> 8.7, 5 -> 8.9; profiles/r03_x_fold_variants_ab.log)
-    const int lg_max = std::max(lg_min, std::min(pf_env_int("XCK_FOLD_LGG", 6), kl.cbits));
+    // with at most 512 cells (well-based data: one BAM per cell) a row may get one group per cell: the cells of such data are far from
+    // even (every cell has its own hot genes), and a level-1 cell that IS one (row, cell) knows its depth exactly
+    const int lg_max = std::max(lg_min, std::min(pf_env_int("XCK_FOLD_LGG", kl.cbits <= 9 ? kl.cbits : 6), kl.cbits));
     const uint32_t n_rows = (uint32_t)im->n_regions;
     ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
@@ -745,9 +771,9 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     K* A = im->ws1.get<K>(n);
     uint32_t* rowcnt = im->ws1.get<uint32_t>(rs); uint32_t* zb = im->ws1.get<uint32_t>(rs); uint32_t* rowtab = im->ws1.get<uint32_t>(rs);
     uint32_t* S1 = im->ws1.get<uint32_t>(ss_cap); uint32_t* fs = im->ws1.get<uint32_t>(zs_cap); uint32_t* fb = im->ws1.get<uint32_t>(zs_cap);
-    uint32_t* fc = im->ws1.get<uint32_t>(zs_cap); uint32_t* fz = im->ws1.get<uint32_t>(zs_cap); uint32_t* zrow = im->ws1.get<uint32_t>(zs_cap);
+    uint32_t* fc = im->ws1.get<uint32_t>(zs_cap); uint32_t* zrow = im->ws1.get<uint32_t>(zs_cap);
     uint32_t* bsum = im->ws1.get<uint32_t>(sb1 + sbs); uint32_t* ctr = im->ws1.get<uint32_t>(64);
-    if (!A || !rowcnt || !zb || !rowtab || !S1 || !fs || !fb || !fc || !fz || !zrow || !bsum || !ctr) { im->eng->err = "workspace exhausted (partition fold)"; return XCK_E_NOMEM; }
+    if (!A || !rowcnt || !zb || !rowtab || !S1 || !fs || !fb || !fc || !zrow || !bsum || !ctr) { im->eng->err = "workspace exhausted (partition fold)"; return XCK_E_NOMEM; }
     g.rowtab = rowtab;
     unsigned long long* h_ctr = im->h_ctl + CTL_X0; unsigned long long* d_hctr = im->d_hctl + CTL_X0;   // (the k_expand words: unused in basefc mode)
     BigChunks bc0; memset(&bc0, 0, sizeof bc0);
@@ -773,34 +799,34 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1);
     HIP_TRY(hipGetLastError());
     if ((rc = pf_scan(im, S1, ss, bsum, nullptr))) return rc;
-    hipLaunchKernelGGL(k_pf_plan1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, fs, fb, fc, fz, ctr);
+    hipLaunchKernelGGL(k_pf_plan1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, fs, fb, fc, ctr);
     HIP_TRY(hipGetLastError());
     if ((rc = pf_scan(im, fs, zs, bsum, ctr + 0))) return rc;                              // ctr[0] = level-1 work items
     if ((rc = pf_scan(im, fb, zs, bsum, ctr + 1))) return rc;                              // ctr[1] = big cells
     if ((rc = pf_scan(im, fc, zs, bsum, ctr + 2))) return rc;                              // ctr[2] = level-2 chunks
-    if ((rc = pf_scan(im, fz, zs, bsum, ctr + 9))) return rc;                              // ctr[9] = level-2 cells
     hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(im->s_comp));
-    const size_t n_wi1 = h_ctr[0], n_big = h_ctr[1], n_chunks2 = h_ctr[2], n_bigkeys = h_ctr[3], Z2 = h_ctr[9];
-    if (Z2 > (size_t(1) << 26)) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: %zu level-2 cells\n", Z2); return PF_FALLBACK; }
-    const size_t zs2 = Z2 + 1;
+    const size_t n_wi1 = h_ctr[0], n_big = h_ctr[1], n_chunks2 = h_ctr[2], n_bigkeys = h_ctr[3];
+    // level-2 cells: about 4 per page of big keys; room for 16x that (refined geometries of uneven cells), beyond it the radix fold
+    const size_t z2_cap = std::min<size_t>(size_t(1) << 26, 64 * (n_bigkeys >> lgC) + 64 * n_big + 65536);
+    const size_t zs2 = z2_cap + 1;
     const size_t wi2_cap = n_big + 3 * (n_bigkeys >> lgC) + 8;
     const size_t sb2 = (std::max(std::max(zs2, wi2_cap + 1), n_wi1 + 1) + SC_TILE - 1) / SC_TILE + 8;
     // ---- workspace 2: everything whose size is known now
-    if ((rc = arena_begin(im, im->ws2, (n_wi1 + 1) * (sizeof(WorkItem) + 4) + (n_big + 2) * 4 * 10 + n * 4 + 2 * (zs2 * 4 + 256) + (wi2_cap + 1) * (sizeof(WorkItem) + 8)
+    if ((rc = arena_begin(im, im->ws2, (n_wi1 + 1) * (sizeof(WorkItem) + 4) + (n_big + 2) * 4 * 12 + n * 4 + 2 * (zs2 * 4 + 256) + (wi2_cap + 1) * (sizeof(WorkItem) + 8)
                                        + n_bigkeys * 4 + sb2 * 4 + n * 12 + (1 << 16)))) return rc;
     WorkItem* wi1 = im->ws2.get<WorkItem>(n_wi1 + 1); uint32_t* nnz1 = im->ws2.get<uint32_t>(n_wi1 + 1);
     BigArrays big; big.off = im->ws2.get<uint32_t>(n_big + 2); big.cnt = im->ws2.get<uint32_t>(n_big + 2); big.chunk0 = im->ws2.get<uint32_t>(n_big + 2);
     big.wi = im->ws2.get<uint32_t>(n_big + 2); big.span = im->ws2.get<uint32_t>(n_big + 2); big.first2 = im->ws2.get<uint32_t>(n_big + 2);
-    big.z2base = im->ws2.get<uint32_t>(n_big + 2); big.sg = im->ws2.get<uint32_t>(n_big + 2); big.eb = im->ws2.get<uint32_t>(n_big + 2); big.rcl0 = im->ws2.get<uint32_t>(n_big + 2);
+    big.z2base = im->ws2.get<uint32_t>(n_big + 2); big.sg = im->ws2.get<uint32_t>(n_big + 2); big.eb = im->ws2.get<uint32_t>(n_big + 2); big.rcl0 = im->ws2.get<uint32_t>(n_big + 2); big.need = im->ws2.get<uint32_t>(n_big + 2);
     uint32_t* res1 = im->ws2.get<uint32_t>(n);
     uint32_t* S2 = im->ws2.get<uint32_t>(zs2); uint32_t* fs2 = im->ws2.get<uint32_t>(zs2);
     WorkItem* wi2 = im->ws2.get<WorkItem>(wi2_cap + 1); uint32_t* nnz2 = im->ws2.get<uint32_t>(wi2_cap + 1); uint32_t* cont2 = im->ws2.get<uint32_t>(wi2_cap + 1);
     uint32_t* res2 = im->ws2.get<uint32_t>(n_bigkeys); uint32_t* bsum2 = im->ws2.get<uint32_t>(sb2);
-    if (!wi1 || !nnz1 || !big.rcl0 || !res1 || !S2 || !fs2 || !wi2 || !nnz2 || !cont2 || !res2 || !bsum2) { im->eng->err = "workspace exhausted (partition fold, stage 2)"; return XCK_E_NOMEM; }
+    if (!wi1 || !nnz1 || !big.need || !res1 || !S2 || !fs2 || !wi2 || !nnz2 || !cont2 || !res2 || !bsum2) { im->eng->err = "workspace exhausted (partition fold, stage 2)"; return XCK_E_NOMEM; }
     hipLaunchKernelGGL(k_pf_emit1, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S1, pl, Z, g, (const uint32_t*)zrow, (const uint32_t*)fs, (const uint32_t*)fb, (const uint32_t*)fc,
-                       (const uint32_t*)fz, wi1, big);
+                       wi1, big);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1, A);   // (S1 is the cursor array from here on)
     HIP_TRY(hipGetLastError());
@@ -814,24 +840,43 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     const size_t bucket_grid = (size_t)std::max(1, pf_env_int("XCK_FOLD_BUCKET_BLOCKS", 256 * 4 * 2));     // resident blocks (4 per CU by LDS) x 2: the tail evens out
     size_t n_wi2 = 0;
     K* B = (K*)im->d_keys;                                                                 // level-2 output: the shard slices are dead once level 1 has moved the keys
+    size_t Z2 = 0;
     if (n_big) {
         BigChunks bc; bc.off = big.off; bc.cnt = big.cnt; bc.chunk0 = big.chunk0; bc.z2base = big.z2base; bc.sg = big.sg; bc.eb = big.eb; bc.n_big = (uint32_t)n_big;
-        const unsigned gz2 = (unsigned)((zs2 + 255) / 256);
-        HIP_TRY(hipMemsetAsync(S2, 0, zs2 * 4, im->s_comp));
-        hipLaunchKernelGGL((k_pf_hist<2>), dim3((unsigned)n_chunks2), dim3(PT_THREADS), 0, im->s_comp, (const K*)A, sc, bc, g, 0, S2);
-        HIP_TRY(hipGetLastError());
-        if ((rc = pf_scan(im, S2, zs2, bsum2, nullptr))) return rc;
-        hipLaunchKernelGGL(k_pf_plan2, dim3(gz2), dim3(256), 0, im->s_comp, (const uint32_t*)S2, (uint32_t)Z2, g, (const uint32_t*)big.z2base, (uint32_t)n_big, fs2, ctr);
-        HIP_TRY(hipGetLastError());
-        if ((rc = pf_scan(im, fs2, zs2, bsum2, ctr + 4))) return rc;                       // ctr[4] = level-2 work items
-        hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(im->s_comp));
-        if (h_ctr[5]) {                                                                   // (the shard slices still hold the keys: level 2 has not written yet)
-            if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: a level-2 sub-cell holds %llu keys (more than %d): n=%zu cells=%u big=%zu (%zu keys, %zu sub-cells)\n",
-                                                    h_ctr[10], 2 << lgC, n, Z, n_big, n_bigkeys, Z2);
-            return PF_FALLBACK;
+        const unsigned gb = (unsigned)((n_big + 1 + 255) / 256);
+        im->fold_refinements = 0;
+        for (int attempt = 0;; attempt++) {
+            // sub-cells of every big z from its geometry -> first level-2 cell of every big z
+            hipLaunchKernelGGL(k_pf_big_sub, dim3(gb), dim3(256), 0, im->s_comp, (uint32_t)n_big, big);
+            if ((rc = pf_scan(im, big.z2base, n_big + 1, bsum2, ctr + 9))) return rc;       // ctr[9] = level-2 cells
+            hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(im->s_comp));
+            Z2 = h_ctr[9];
+            if (Z2 > z2_cap) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: %zu level-2 cells (room for %zu)\n", Z2, z2_cap); return PF_FALLBACK; }
+            const size_t zs2n = Z2 + 1;
+            const unsigned gz2 = (unsigned)((zs2n + 255) / 256);
+            HIP_TRY(hipMemsetAsync(S2, 0, zs2n * 4, im->s_comp));
+            HIP_TRY(hipMemsetAsync(ctr + 5, 0, 4, im->s_comp)); HIP_TRY(hipMemsetAsync(ctr + 10, 0, 8, im->s_comp));
+            hipLaunchKernelGGL((k_pf_hist<2>), dim3((unsigned)n_chunks2), dim3(PT_THREADS), 0, im->s_comp, (const K*)A, sc, bc, g, 0, S2);
+            HIP_TRY(hipGetLastError());
+            if ((rc = pf_scan(im, S2, zs2n, bsum2, nullptr))) return rc;
+            hipLaunchKernelGGL(k_pf_plan2, dim3(gz2), dim3(256), 0, im->s_comp, (const uint32_t*)S2, (uint32_t)Z2, g, big, (uint32_t)n_big, fs2, ctr);
+            HIP_TRY(hipGetLastError());
+            if ((rc = pf_scan(im, fs2, zs2n, bsum2, ctr + 4))) return rc;                   // ctr[4] = level-2 work items
+            hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(im->s_comp));
+            if (!h_ctr[5]) break;
+            // (the shard slices still hold the keys: level 2 has not written yet)
+            if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: a level-2 sub-cell holds %llu keys (more than %d) - %s (n=%zu cells=%u big=%zu, %zu keys, %zu sub-cells)\n",
+                                                    h_ctr[10], 2 << lgC, h_ctr[11] || attempt >= 3 ? "radix fold" : "finer geometry for its big cell", n, Z, n_big, n_bigkeys, Z2);
+            if (h_ctr[11] || attempt >= 3) return PF_FALLBACK;
+            im->fold_refinements++;
+            hipLaunchKernelGGL(k_pf_big_refine, dim3(gb), dim3(256), 0, im->s_comp, (uint32_t)n_big, big);
+            HIP_TRY(hipGetLastError());
         }
+        const unsigned gz2 = (unsigned)((Z2 + 1 + 255) / 256);
         n_wi2 = h_ctr[4];
         if (n_wi2 > wi2_cap) { im->eng->err = "internal: level-2 work items exceed their bound"; return XCK_E_STATE; }
         hipLaunchKernelGGL(k_pf_emit2, dim3(gz2), dim3(256), 0, im->s_comp, (const uint32_t*)S2, (uint32_t)Z2, (const uint32_t*)fs2, (uint32_t)n_big, wi2, big);
