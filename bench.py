@@ -525,6 +525,17 @@ def well_workload(args, dev_idx, threads, cores, log):
     cols = ["cell%03d" % i for i in range(args.well_bams)]
     t0 = time.time()
     bams = [os.path.join(work, "cell_%03d_%d_l%d.bam" % (i, args.well_reads, args.level)) for i in range(args.well_bams)]
+    # room for the files (about 75 bytes per record at the generator's fast level): the work directory is scratch, so the 10x workload's
+    # BAMs (regenerated by their own run when missing) give way when the disk is short
+    import glob
+    import shutil
+    need = sum(0 if os.path.isfile(b + ".ok") else int(args.well_reads * 80) for b in bams) + (2 << 30)
+    if shutil.disk_usage(work).free < need:
+        for fn in glob.glob(os.path.join(args.work, "synth_*.bam*")) + glob.glob(os.path.join(args.work, "out_*", "*", "*.mtx")):
+            os.remove(fn)
+        log("removed the 10x workload's files from %s to make room" % args.work)
+    if shutil.disk_usage(work).free < need:
+        sys.exit("bench.py --workload well: %s has %.1f GB free, the %d BAMs need %.1f GB" % (work, shutil.disk_usage(work).free / 1e9, len(bams), need / 1e9))
     from concurrent.futures import ThreadPoolExecutor              # small files: four generator processes side by side
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(lambda ib: gen_bam(a2, work, ib[1], args.well_reads, args.level, "smartseq", max(1, cores // 4), lambda m: None, seed=100 + ib[0]), enumerate(bams)))
