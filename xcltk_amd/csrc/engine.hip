@@ -2221,7 +2221,7 @@ static int finish_t(EngineImpl* im) {
         bool sorted = false;
         if constexpr (sizeof(K) == 8) {
             // (opt-in: at configs[2] the partition + LDS item sort takes 2.6 ms against the radix sort's 2.2 ms - the bitonic network moves
-            // every pair through LDS 66 times; profiles/r03_q_*)
+            // every pair through LDS 66 times)
             const bool want_part = getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "partition");
             if (want_part) {
                 KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
