@@ -1522,6 +1522,7 @@ struct EngineImpl {
     TileMeta* d_meta = nullptr; size_t meta_cap = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_res = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    hipEvent_t ev_f1 = nullptr, ev_f2 = nullptr;   // partition fold: level-1 bucket pass on the copy stream (fold_partition.h)
     bool copy_timed = false, copy_pending = false;
     xck_stats st{};
     int64_t n_join_launches = 0;
@@ -2474,6 +2475,8 @@ void engine_destroy(xck_engine* e) {
     if (im->ev_res) hipEventDestroy(im->ev_res);
     if (im->ev_c0) hipEventDestroy(im->ev_c0);
     if (im->ev_c1) hipEventDestroy(im->ev_c1);
+    if (im->ev_f1) hipEventDestroy(im->ev_f1);
+    if (im->ev_f2) hipEventDestroy(im->ev_f2);
     if (im->s_copy) hipStreamDestroy(im->s_copy);
     if (im->s_comp) hipStreamDestroy(im->s_comp);
     delete im; e->impl = nullptr;

@@ -840,6 +840,17 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     const size_t bucket_grid = (size_t)std::max(1, pf_env_int("XCK_FOLD_BUCKET_BLOCKS", 256 * 4 * 2));     // resident blocks (4 per CU by LDS) x 2: the tail evens out
     size_t n_wi2 = 0;
     K* B = (K*)im->d_keys;                                                                 // level-2 output: the shard slices are dead once level 1 has moved the keys
+    // The level-1 items do not depend on level 2: their bucket pass runs on the copy stream (idle until the copy-out) beside the
+    // level-2 histogram / partition - two latency-bound kernels share the CUs better than either fills them (XCK_FOLD_OVERLAP=0: serial).
+    const bool overlap = n_big && pf_env_int("XCK_FOLD_OVERLAP", 1) != 0;
+    if (overlap) {
+        if (!im->ev_f1) { HIP_TRY(hipEventCreateWithFlags(&im->ev_f1, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&im->ev_f2, hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(im->ev_f1, im->s_comp));
+        HIP_TRY(hipStreamWaitEvent(im->s_copy, im->ev_f1, 0));
+        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, bucket_grid / 2)), dim3(PF_THREADS), lds, im->s_copy, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(im->ev_f2, im->s_copy));
+    }
     size_t Z2 = 0;
     if (n_big) {
         BigChunks bc; bc.off = big.off; bc.cnt = big.cnt; bc.chunk0 = big.chunk0; bc.z2base = big.z2base; bc.sg = big.sg; bc.eb = big.eb; bc.n_big = (uint32_t)n_big;
@@ -853,7 +864,9 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(im->s_comp));
             Z2 = h_ctr[9];
-            if (Z2 > z2_cap) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: %zu level-2 cells (room for %zu)\n", Z2, z2_cap); return PF_FALLBACK; }
+            if (Z2 > z2_cap) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: %zu level-2 cells (room for %zu)\n", Z2, z2_cap);
+                               if (overlap) HIP_TRY(hipStreamSynchronize(im->s_copy));      // (the level-1 bucket pass still reads this workspace)
+                               return PF_FALLBACK; }
             const size_t zs2n = Z2 + 1;
             const unsigned gz2 = (unsigned)((zs2n + 255) / 256);
             HIP_TRY(hipMemsetAsync(S2, 0, zs2n * 4, im->s_comp));
@@ -871,7 +884,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
             // (the shard slices still hold the keys: level 2 has not written yet)
             if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: a level-2 sub-cell holds %llu keys (more than %d) - %s (n=%zu cells=%u big=%zu, %zu keys, %zu sub-cells)\n",
                                                     h_ctr[10], 2 << lgC, h_ctr[11] || attempt >= 3 ? "radix fold" : "finer geometry for its big cell", n, Z, n_big, n_bigkeys, Z2);
-            if (h_ctr[11] || attempt >= 3) return PF_FALLBACK;
+            if (h_ctr[11] || attempt >= 3) { if (overlap) HIP_TRY(hipStreamSynchronize(im->s_copy)); return PF_FALLBACK; }
             im->fold_refinements++;
             hipLaunchKernelGGL(k_pf_big_refine, dim3(gb), dim3(256), 0, im->s_comp, (uint32_t)n_big, big);
             HIP_TRY(hipGetLastError());
@@ -889,8 +902,11 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
         hipLaunchKernelGGL(k_pf_bignnz, dim3((unsigned)((n_big + 255) / 256)), dim3(256), 0, im->s_comp, (uint32_t)n_big, big, (const uint32_t*)nnz2, nnz1);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, bucket_grid)), dim3(PF_THREADS), lds, im->s_comp, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
-    HIP_TRY(hipGetLastError());
+    if (overlap) HIP_TRY(hipStreamWaitEvent(im->s_comp, im->ev_f2, 0));
+    else {
+        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, bucket_grid)), dim3(PF_THREADS), lds, im->s_comp, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemsetAsync(nnz1 + n_wi1, 0, 4, im->s_comp));
     if ((rc = pf_scan(im, nnz1, n_wi1 + 1, bsum2, ctr + 6))) return rc;                    // nnz1 -> O1, ctr[6] = non-zeros of the matrix
     hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
