@@ -847,7 +847,10 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
         if (!im->ev_f1) { HIP_TRY(hipEventCreateWithFlags(&im->ev_f1, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&im->ev_f2, hipEventDisableTiming)); }
         HIP_TRY(hipEventRecord(im->ev_f1, im->s_comp));
         HIP_TRY(hipStreamWaitEvent(im->s_copy, im->ev_f1, 0));
-        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, bucket_grid / 2)), dim3(PF_THREADS), lds, im->s_copy, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
+        // (half of the CUs' wave slots - 2 blocks of 8 waves per CU: a persistent grid that fills the device would leave the level-2
+        // kernels waiting for a slot until it retires)
+        const size_t side_grid = (size_t)std::max(1, pf_env_int("XCK_FOLD_OVERLAP_BLOCKS", 512));
+        hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, side_grid)), dim3(PF_THREADS), lds, im->s_copy, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(im->ev_f2, im->s_copy));
     }
