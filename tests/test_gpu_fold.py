@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def fold_env():
-    saved = {k: os.environ.get(k) for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT")}
+    saved = {k: os.environ.get(k) for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT", "XCK_PILEUP_ITEM_SORT")}
     yield os.environ
     for k, v in saved.items():
         if v is None:
@@ -151,12 +151,14 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
     assert st["pileup_sort_path"] == 1 and len(exp["dp"][0]) > 1000
-    for page in ("64", "8"):
-        fold_env["XCK_FOLD_C"] = page
-        got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
-        util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
-        assert st["pileup_sort_path"] in (1, 2)
-    fold_env.pop("XCK_FOLD_C")
+    for item_sort in ("radix", "bitonic"):              # the LDS radix sort of an item (default) and the bitonic network
+        fold_env["XCK_PILEUP_ITEM_SORT"] = item_sort
+        for page in ("1024", "64", "8"):
+            fold_env["XCK_FOLD_C"] = page
+            got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
+            util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+            assert st["pileup_sort_path"] in (1, 2)
+    fold_env.pop("XCK_FOLD_C"); fold_env.pop("XCK_PILEUP_ITEM_SORT")
     fold_env.pop("XCK_PILEUP_SORT")                    # the default: radix sort
     got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])

@@ -260,6 +260,18 @@ def test_pileup_gap_records_many_cells():
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
 
 
+def test_pileup_deep_snps_are_tallied_by_blocks():
+    """All reads start inside 1 kb: every SNP there holds thousands of (cell, UMI) keys - more than the eight lanes of k_tally_rows
+    take (TALLY_LONG = 2048), so k_tally_long counts them; the SNPs further out (reached through N gaps) stay on the short path.
+    min_count / min_maf make the tallies decide which SNPs survive."""
+    regions, snps, names, batches = _dense_pileup_case(seed=77, n_reads=120000, n_cells=3, n_umis=1 << 22, snp_step=53, span=31000, max_batch=40000, gap_max=9000)
+    got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 3, batches, min_len=10, min_count=3000, min_maf=0.2)
+    got2, exp2, _ = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 3, batches, min_len=10, min_count=20, min_maf=0.0)
+    assert int(exp["dp"][2].max()) > 2048 and len(exp2["dp"][0]) > len(exp["dp"][0]) > 0
+    util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+    util.assert_coo_equal(got2, exp2, ["ad", "dp", "oth"])
+
+
 def test_pileup_overflow_replay_both_streams(monkeypatch):
     """A SNP every 3 bp: ~30 hits with a base and tens of gap records per read overrun the first capacity guess
     (1.25 keys per read) of BOTH pileup streams: overflow flag, growth of all four buffers, cursor rewind, replay."""

@@ -17,7 +17,7 @@
 //   finish      : basefc: radix sort (rocPRIM) over the (row, cell) bits, k_fold_heads / k_fold_emit_unsorted (distinct
 //                 UMIs of a run told apart by an LDS hash set) straight into COO; classic path: full sort + k_fold_emit.
 //                 pileup: sort of the hits with a base, k_first_base (first read per key, Bloom filter; k_first_long for
-//                 runs longer than 64), k_claim (gap records that hold a key earlier in fetch order), k_tally, k_expand
+//                 runs longer than 64), k_claim (gap records that hold a key earlier in fetch order), k_tally_rows, k_expand
 //                 (per-SNP filters, SNP -> region fan-out), k_hap_class / k_hap_sum / k_hap_final (haplotype set algebra
 //                 by block scans), k_cp_* (ordered compaction); 128-bit keys: k_first_read.
 //                 Copy-out on the copy stream (xck_finish_async).
@@ -1077,17 +1077,32 @@ __global__ void __launch_bounds__(256) k_first_long(const K* __restrict__ k, con
 // Blocked Bloom filter over the runs, two levels in one table: (cell, UMI, SNP >> 5) and (cell, UMI, SNP); one 64-bit word,
 // two bits per entry.  A gap record first asks whether its molecule shows a base anywhere in the same block of 32 SNPs, then
 // per SNP, before any exact lookup is made.
-__device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t blk, unsigned long long mask_words, unsigned long long& word, unsigned long long& bits) {
-    unsigned long long x = cellumi ^ ((unsigned long long)blk * 0x9E3779B97F4A7C15ull);
+// The table is laid out ALONG THE SORTED STREAM: the entries of SNP block b go to the words [lo_b, lo_b + len_b), lo_b / len_b =
+// the block's index range in the sorted keys (k_blk_bounds) - one word per key, whatever the depth of the block.  The inserts of
+// k_first_base therefore land next to the keys being read, and the gap records - which arrive in position order - ask a window of
+// the table that moves along with them and stays in L2 (a table hashed over all of its 230 MB cost one HBM round trip per record).
+__device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t tag, unsigned long long lo, unsigned long long len, unsigned long long& word, unsigned long long& bits) {
+    unsigned long long x = cellumi ^ ((unsigned long long)tag * 0x9E3779B97F4A7C15ull);
     x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-    word = x & mask_words;
+    word = lo + (unsigned long long)(((x & 0xffffffffull) * (len & 0xffffffffull)) >> 32);   // len < 2^32 (checked on the host)
     bits = (1ull << ((x >> 40) & 63)) | (1ull << ((x >> 48) & 63));
+}
+// first index of every block of 32 SNPs in the sorted keys (blk_lo[n_blk] = n): one bisection per block
+template <class K>
+__global__ void k_blk_bounds(const K* __restrict__ k, long long n, KeyLayout<K> kl, uint32_t n_blk, unsigned long long* __restrict__ blk_lo) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_blk) return;
+    if (b == n_blk) { blk_lo[b] = (unsigned long long)n; return; }
+    long long lo = 0, hi = n;
+    const uint32_t row0 = b << 5;
+    while (lo < hi) { const long long mid = lo + ((hi - lo) >> 1); if (kl.row(k[mid]) < row0) lo = mid + 1; else hi = mid; }
+    blk_lo[b] = (unsigned long long)lo;
 }
 // per key run: allele code + ordinal of its first read with a base, at the run head; first / one-past-last index of every SNP
 template <class K>
 __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict__ v, long long n, KeyLayout<K> kl,
                              uint8_t* __restrict__ al_out, uint64_t* __restrict__ ord_out, unsigned long long* __restrict__ row_lo, unsigned long long* __restrict__ row_hi,
-                             unsigned long long* __restrict__ bloom, unsigned long long bloom_mask, unsigned long long* __restrict__ long_runs) {
+                             unsigned long long* __restrict__ bloom, const unsigned long long* __restrict__ blk_lo, unsigned long long* __restrict__ long_runs) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const K me = k[i];
@@ -1105,9 +1120,10 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
     }
     unsigned long long word, bits;
     const unsigned long long cu = (unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1));
-    bloom_slot(cu, row >> 5, bloom_mask, word, bits);                 // level 1: (molecule, block of 32 SNPs)
+    const unsigned long long b_lo = blk_lo[row >> 5], b_len = blk_lo[(row >> 5) + 1] - b_lo;   // (this key is inside: b_len >= 1)
+    bloom_slot(cu, row >> 5, b_lo, b_len, word, bits);                // level 1: (molecule, block of 32 SNPs)
     atomicOr(&bloom[word], bits);
-    bloom_slot(cu, 0x80000000u | row, bloom_mask, word, bits);       // level 2: (molecule, SNP)
+    bloom_slot(cu, 0x80000000u | row, b_lo, b_len, word, bits);      // level 2: (molecule, SNP)
     atomicOr(&bloom[word], bits);
 }
 // every gap record (first SNP, cell, UMI | ordinal, count - 1): for each of its SNPs, if (SNP, cell, UMI) has a run and
@@ -1116,28 +1132,31 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
 // the exact lookups that remain are binary searches inside one SNP's run (the stream is in tile order, so
 // neighbouring threads search the same few SNPs and stay in L2).
 template <class K>
-__global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp,
+__global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp, unsigned long long n_units,
                                                  const K* __restrict__ keys, KeyLayout<K> kl, const unsigned long long* __restrict__ row_lo, const unsigned long long* __restrict__ row_hi,
                                                  const uint64_t* __restrict__ ord, uint8_t* __restrict__ al,
-                                                 const unsigned long long* __restrict__ bloom, unsigned long long bloom_mask, uint32_t n_rows) {
-    const unsigned long long n = sp.start[NSHARD];
+                                                 const unsigned long long* __restrict__ bloom, const unsigned long long* __restrict__ blk_lo, uint32_t n_rows) {
     const int low = kl.cbits + kl.ubits;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
-        int sh = 0;
-#pragma unroll
-        for (int q = 1; q < NSHARD; q++) sh += (i >= sp.start[q]) ? 1 : 0;
-        const unsigned long long j = (unsigned long long)sh * cap + (i - sp.start[sh]);
+    // unit u = records [256 * (u / NSHARD), + 256) of shard slice u % NSHARD: the slices are filled round-robin by consecutive join
+    // tiles, so the blocks in flight together hold ONE narrow position range of the file (and one window of the Bloom table)
+    for (unsigned long long u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int sh = (int)(u % NSHARD);
+        const unsigned long long idx = (u / NSHARD) * 256 + threadIdx.x;
+        if (idx >= sp.start[sh + 1] - sp.start[sh]) continue;
+        const unsigned long long j = (unsigned long long)sh * cap + idx;
         const K rec = nk[j];
         const uint64_t v = nv[j];
         const uint64_t ordn = v >> ALLELE_BITS;
         const uint32_t k1 = kl.row(rec), k2 = min(k1 + (uint32_t)(v & ((1u << ALLELE_BITS) - 1)) + 1u, n_rows);
         const K cellumi = rec & ((K(1) << low) - 1);
         for (uint32_t blk = k1 >> 5; blk <= (k2 - 1) >> 5; blk++) {
+            const unsigned long long b_lo = blk_lo[blk], b_len = blk_lo[blk + 1] - b_lo;
+            if (!b_len) continue;                                       // no read shows a base anywhere in this block of SNPs
             unsigned long long word, bits;
-            bloom_slot((unsigned long long)cellumi, blk, bloom_mask, word, bits);
+            bloom_slot((unsigned long long)cellumi, blk, b_lo, b_len, word, bits);
             if ((bloom[word] & bits) != bits) continue;                 // this molecule shows no base in this block of SNPs
             for (uint32_t srow = max(k1, blk << 5); srow < min(k2, (blk + 1) << 5); srow++) {
-                bloom_slot((unsigned long long)cellumi, 0x80000000u | srow, bloom_mask, word, bits);
+                bloom_slot((unsigned long long)cellumi, 0x80000000u | srow, b_lo, b_len, word, bits);
                 if ((bloom[word] & bits) != bits) continue;             // ... and none at this SNP
                 unsigned long long lo = row_lo[srow], hi = row_hi[srow];
                 if (lo >= hi) continue;
@@ -1149,28 +1168,46 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
         }
     }
 }
-template <class K>
-__global__ void k_tally(const K* __restrict__ k, const uint8_t* __restrict__ al, long long n, KeyLayout<K> kl, uint32_t* __restrict__ tally) {
-    // keys are sorted by SNP, so the lanes of a wave form a few segments of equal SNP: the first lane of a segment adds the
-    // segment's five bucket counts (ballots), instead of one atomic per key on the counters of a deep SNP
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const uint32_t code = i < n ? al[i] : 0u;
-    const uint32_t row = i < n ? kl.row(k[i]) : 0xffffffffu;
-    const int bucket = code ? nib_bucket(int(code) - 1) : -1;
-    const uint32_t row_prev = __shfl_up(row, 1, 64);
-    const unsigned long long heads = __ballot(lane == 0 || row != row_prev);
-    unsigned long long bm[5];
+// per-SNP allele tallies (baf/fc/mcount.py:140-150) of the keys that kept an allele.  The keys are sorted by SNP and k_first_base has
+// left every SNP's index range, so nothing is searched or added atomically: EIGHT LANES PER SNP walk the SNP's slice of `al` (one
+// byte per key; neighbouring SNPs are neighbouring slices, so a wave reads one contiguous stretch), three shuffles put the five
+// counts together and lanes 0..4 of the group store them.  (The first form - one thread per key, ballots per wave segment, atomics
+// on the SNP's counters - spent 0.77 ms at configs[2] queueing on counter lines shared by neighbouring SNPs.)
+// A SNP deeper than TALLY_LONG keys (bulk input) is queued and counted by one block (k_tally_long).
+constexpr unsigned long long TALLY_LONG = 2048;
+__device__ __forceinline__ void tally_code(uint32_t code, uint32_t (&c)[5]) {
+    const int b = code ? nib_bucket(int(code) - 1) : -1;
 #pragma unroll
-    for (int b = 0; b < 5; b++) bm[b] = __ballot(bucket == b);
-    if ((heads >> lane) & 1ull) {                                         // segment = [lane, next head)
-        const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
-        const int end = later ? __builtin_ctzll(later) : 64;
-        const unsigned long long seg = (end == 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << lane) - 1);
-        if (row != 0xffffffffu) {
+    for (int q = 0; q < 5; q++) c[q] += (b == q) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_tally_rows(const uint8_t* __restrict__ al, const unsigned long long* __restrict__ row_lo, const unsigned long long* __restrict__ row_hi,
+                                                    uint32_t n_rows, uint32_t* __restrict__ tally, unsigned long long* __restrict__ long_rows) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, s = gid >> 3; const uint32_t sub = (uint32_t)gid & 7u;
+    unsigned long long lo = 0, len = 0;
+    if (s < n_rows) { lo = row_lo[s]; const unsigned long long hi = row_hi[s]; len = hi > lo ? hi - lo : 0; }
+    const bool is_long = len > TALLY_LONG;
+    if (is_long) { if (sub == 0) long_rows[1 + atomicAdd(&long_rows[0], 1ull)] = s; len = 0; }
+    uint32_t c[5] = {0, 0, 0, 0, 0};
+    for (unsigned long long t = sub; t < len; t += 8) tally_code(al[lo + t], c);
 #pragma unroll
-            for (int b = 0; b < 5; b++) { const int c = __popcll(bm[b] & seg); if (c) atomicAdd(&tally[(size_t)row * 5 + b], (uint32_t)c); }
-        }
+    for (int q = 0; q < 5; q++) { c[q] += __shfl_xor(c[q], 1); c[q] += __shfl_xor(c[q], 2); c[q] += __shfl_xor(c[q], 4); }
+    if (s < n_rows && !is_long && sub < 5) tally[(size_t)s * 5 + sub] = sub == 0 ? c[0] : sub == 1 ? c[1] : sub == 2 ? c[2] : sub == 3 ? c[3] : c[4];
+}
+__global__ void __launch_bounds__(256) k_tally_long(const uint8_t* __restrict__ al, const unsigned long long* __restrict__ row_lo, const unsigned long long* __restrict__ row_hi,
+                                                    const unsigned long long* __restrict__ long_rows, uint32_t* __restrict__ tally) {
+    __shared__ uint32_t s_c[4][5];
+    const unsigned long long n_long = long_rows[0];
+    for (unsigned long long r = blockIdx.x; r < n_long; r += gridDim.x) {
+        const size_t s = (size_t)long_rows[1 + r];
+        const unsigned long long lo = row_lo[s], hi = row_hi[s];
+        uint32_t c[5] = {0, 0, 0, 0, 0};
+        for (unsigned long long t = lo + threadIdx.x; t < hi; t += 256) tally_code(al[t], c);
+#pragma unroll
+        for (int q = 0; q < 5; q++) { for (int d = 32; d; d >>= 1) c[q] += __shfl_xor(c[q], d); }
+        if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 5; q++) s_c[threadIdx.x >> 6][q] = c[q]; }
+        __syncthreads();
+        if (threadIdx.x < 5) tally[s * 5 + threadIdx.x] = s_c[0][threadIdx.x] + s_c[1][threadIdx.x] + s_c[2][threadIdx.x] + s_c[3][threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -2214,7 +2251,7 @@ static int finish_t(EngineImpl* im) {
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     } else {
         const size_t tmpb = sort_tmp_bytes<K, uint64_t>(n, top);
-        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 16 + std::max<size_t>(n * 8, 8192) + n / 8 + (1 << 16)))) return rc;
+        if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + n * 8 + n + tmpb + n * 8 + (size_t)std::max(im->n_snps_sorted, 1) * 17 + std::max<size_t>(n * 8, 8192) + n / 8 + (1 << 16)))) return rc;
         K* alt = im->ws1.get<K>(n); uint64_t* valt = im->ws1.get<uint64_t>(n); void* tmp = im->ws1.get<char>(tmpb); uint8_t* al = im->ws1.get<uint8_t>(n);
         if ((rc = tm.start())) return rc;
         // the hits sorted by (key, value): by row partition + one LDS sort per item (fold_partition.h); a SNP deeper than an item, or
@@ -2247,25 +2284,34 @@ static int finish_t(EngineImpl* im) {
         if (sizeof(K) == 8 && split_mode(im)) {
             const size_t ns = std::max<size_t>((size_t)im->n_snps_sorted, 1);
             uint64_t* ordv = im->ws1.get<uint64_t>(n); unsigned long long* row_lo = im->ws1.get<unsigned long long>(2 * ns); unsigned long long* row_hi = row_lo + ns;
-            size_t bw = 1024; while (bw < n / 2) bw <<= 1;                // two entries per run, ~4 entries (8 bits) per 64-bit word
-            unsigned long long* bloom = im->ws1.get<unsigned long long>(bw);
-            if (!ordv || !row_lo || !bloom) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
+            if (n >> 32) { im->eng->err = "pileup fold: more than 2^32 hits with a base in one finish"; return XCK_E_NOMEM; }
+            const uint32_t n_blk = (uint32_t)((ns + 31) >> 5);
+            unsigned long long* bloom = im->ws1.get<unsigned long long>(n);   // one word per key, laid out along the sorted stream (bloom_slot)
+            unsigned long long* blk_lo = im->ws1.get<unsigned long long>((size_t)n_blk + 1);
+            if (!ordv || !row_lo || !bloom || !blk_lo) { im->eng->err = "workspace exhausted (split pileup)"; return XCK_E_NOMEM; }
             HIP_TRY(hipMemsetAsync(row_lo, 0, 2 * ns * sizeof(unsigned long long), im->s_comp));
-            HIP_TRY(hipMemsetAsync(bloom, 0, bw * sizeof(unsigned long long), im->s_comp));
+            HIP_TRY(hipMemsetAsync(bloom, 0, n * sizeof(unsigned long long), im->s_comp));
+            hipLaunchKernelGGL((k_blk_bounds<K>), dim3((n_blk + 256) / 256), dim3(256), 0, im->s_comp, (const K*)alt, (long long)n, kl, n_blk, blk_lo);
             hipLaunchKernelGGL((k_first_base<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, ordv, row_lo, row_hi,
-                               bloom, (unsigned long long)(bw - 1), long_runs);
+                               bloom, (const unsigned long long*)blk_lo, long_runs);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL((k_first_long<K, true>), dim3(1024), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, (const unsigned long long*)long_runs, al, ordv, im->d_tally);
             HIP_TRY(hipGetLastError());
             if (im->ncursor) {
-                ShardSpan nsp; nsp.start[0] = 0; for (int sh = 0; sh < NSHARD; sh++) nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh];
-                hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<size_t>((im->ncursor + 255) / 256, 16384)), dim3(256), 0, im->s_comp,
-                                   (const K*)im->d_nkeys, (const uint64_t*)im->d_nvals, (unsigned long long)im->hit_cap, nsp,
+                ShardSpan nsp; nsp.start[0] = 0; unsigned long long mx = 0;
+                for (int sh = 0; sh < NSHARD; sh++) { nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh]; mx = std::max(mx, im->ncur[sh]); }
+                const unsigned long long n_units = ((mx + 255) / 256) * NSHARD;
+                hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<unsigned long long>(n_units, 16384)), dim3(256), 0, im->s_comp,
+                                   (const K*)im->d_nkeys, (const uint64_t*)im->d_nvals, (unsigned long long)im->hit_cap, nsp, n_units,
                                    (const K*)alt, kl, (const unsigned long long*)row_lo, (const unsigned long long*)row_hi, (const uint64_t*)ordv, al,
-                                   (const unsigned long long*)bloom, (unsigned long long)(bw - 1), (uint32_t)ns);
+                                   (const unsigned long long*)bloom, (const unsigned long long*)blk_lo, (uint32_t)ns);
                 HIP_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL((k_tally<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally);
+            HIP_TRY(hipMemsetAsync(long_runs, 0, sizeof(unsigned long long), im->s_comp));   // (k_first_long is done with the list: now the SNPs deeper than TALLY_LONG)
+            hipLaunchKernelGGL(k_tally_rows, dim3((unsigned)((ns * 8 + 255) / 256)), dim3(256), 0, im->s_comp, (const uint8_t*)al, (const unsigned long long*)row_lo, (const unsigned long long*)row_hi,
+                               (uint32_t)ns, im->d_tally, long_runs);
+            hipLaunchKernelGGL(k_tally_long, dim3(1024), dim3(256), 0, im->s_comp, (const uint8_t*)al, (const unsigned long long*)row_lo, (const unsigned long long*)row_hi,
+                               (const unsigned long long*)long_runs, im->d_tally);
             HIP_TRY(hipGetLastError());
         } else {
         hipLaunchKernelGGL((k_first_read<K>), dim3(gs), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, al, im->d_tally, long_runs);

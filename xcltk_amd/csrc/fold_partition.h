@@ -994,6 +994,96 @@ __global__ __launch_bounds__(PS_THREADS) void k_pf_sort_items(unsigned long long
     for (uint32_t i = threadIdx.x; i < n; i += PS_THREADS) { keys[off + i] = sk[i]; vals[off + i] = sv[i]; }
 }
 
+// The same items sorted by an LSD radix sort in LDS (default; XCK_PILEUP_ITEM_SORT=bitonic keeps the network above).  512 threads, four
+// pairs per thread held in REGISTERS between the passes; element e = wave * 256 + round * 64 + lane.  One pass per 8-bit digit in which
+// the item's keys differ at all (an item spans 2^14 (SNP, cell) pairs: ~5 of the 8 digits): every wave ranks its 256 elements round by
+// round with ballots (lanes of equal digit: eight ballots; rank = the wave's running count of the digit + lanes of the group below me),
+// the 8 x 256 wave counts are scanned digit-major, and the pairs go through ONE LDS buffer to their new places and back into
+// registers.  Stable, so equal keys keep their order and the padding (~0 keys) stays behind.  ~0.5 MB of LDS traffic per item
+// against the network's 4.3 MB.
+constexpr int RS_THREADS = 512, RS_WAVES = RS_THREADS / 64, RS_EPT = PS_CAP / RS_THREADS, RS_SEG = PS_CAP / RS_WAVES;
+__global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long long* __restrict__ keys, uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off, uint32_t* __restrict__ ctr) {
+    static_assert(RS_EPT * RS_THREADS == PS_CAP && RS_SEG == RS_EPT * 64, "item capacity = threads x elements per thread");
+    __shared__ unsigned long long sk[PS_CAP];
+    __shared__ unsigned long long sv[PS_CAP];
+    __shared__ uint32_t hist[RS_WAVES][256];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ unsigned long long s_diff;
+    const uint32_t off = item_off[blockIdx.x], n = item_off[blockIdx.x + 1] - off;
+    if (n < 2) return;
+    if (n > (uint32_t)PS_CAP) { if (threadIdx.x == 0) ctr[7] = 1u; return; }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
+    const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);   // rounds of this wave that hold anything (wave-uniform)
+    unsigned long long key[RS_EPT], val[RS_EPT];
+    if (threadIdx.x == 0) s_diff = 0;
+    const unsigned long long first = keys[off];
+    unsigned long long diff = 0;
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        const uint32_t e = e0 + r * 64;
+        key[r] = ~0ull; val[r] = ~0ull;
+        if (e < n) { key[r] = keys[off + e]; val[r] = vals[off + e]; diff |= key[r] ^ first; }
+    }
+    for (int d = 32; d; d >>= 1) diff |= __shfl_xor(diff, d);
+    __syncthreads();
+    if (lane == 0 && diff) atomicOr(&s_diff, diff);
+    __syncthreads();
+    diff = s_diff;
+    if (!diff) return;                                                    // one key: sorted as it is
+    for (int shift = 0; shift < 64; shift += 8) {
+        if (!((diff >> shift) & 0xffull)) continue;                       // (block-uniform)
+#pragma unroll
+        for (int q = 0; q < 256 / 64; q++) hist[wave][q * 64 + lane] = 0;
+        uint32_t rank[RS_EPT];
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+            if (r < n_rounds) {
+                const uint32_t dg = (uint32_t)(key[r] >> shift) & 0xffu;
+                unsigned long long m = ~0ull;
+#pragma unroll
+                for (int b = 0; b < 8; b++) { const bool on = (dg >> b) & 1u; const unsigned long long bal = __ballot(on); m &= on ? bal : ~bal; }
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t prev = hist[wave][dg];                     // (the lanes of a group read one word; LDS operations of a wave stay in order)
+                if (below == 0) hist[wave][dg] = prev + (uint32_t)__popcll(m);
+                rank[r] = prev + below;
+            }
+        }
+        __syncthreads();
+        uint32_t c[RS_WAVES], tot = 0, inc = 0;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) { c[w] = hist[w][threadIdx.x]; tot += c[w]; }
+            inc = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t; }
+            if (lane == 63) s_wtot[wave] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t base = inc - tot;
+            for (uint32_t w = 0; w < wave; w++) base += s_wtot[w];
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) { hist[w][threadIdx.x] = base; base += c[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+            if (r < n_rounds) {
+                const uint32_t pos = hist[wave][(uint32_t)(key[r] >> shift) & 0xffu] + rank[r];
+                sk[pos] = key[r]; sv[pos] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) {
+            const uint32_t e = e0 + r * 64;
+            if (r < n_rounds) { key[r] = sk[e]; val[r] = sv[e]; }          // (places >= n hold this pass's padding: ~0 again)
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) { const uint32_t e = e0 + r * 64; if (e < n) { keys[off + e] = key[r]; vals[off + e] = val[r]; } }
+}
+
 // (key, value) hits in the shard slices of im->d_keys / d_vals -> out_keys / out_vals (n entries each) sorted by (key, value).
 // Cells as in the basefc fold: every SNP gets 2^l cell groups so that a group holds about C / 2 hits (a SNP in a hot gene is tens of
 // thousands of reads deep); the groups of a SNP are in cell order, so cell order = key order.  0 = done, PF_FALLBACK = use the radix
@@ -1061,7 +1151,9 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     if (n_items > wi_cap) { im->eng->err = "internal: pileup items exceed their bound"; return XCK_E_STATE; }
     hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S, out_keys, (const uint64_t*)im->d_vals, out_vals);
-    hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
+    const bool bitonic = getenv("XCK_PILEUP_ITEM_SORT") && !strcmp(getenv("XCK_PILEUP_ITEM_SORT"), "bitonic");
+    if (bitonic) hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
+    else hipLaunchKernelGGL(k_pf_radix_items, dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);
     HIP_TRY(hipGetLastError());
