@@ -140,14 +140,13 @@ def test_unplaceable_input_hands_over_to_the_sort_fold(fold_env):
 
 
 def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
-    """The pileup's (key, value) hits: row partition + one LDS sort per item (XCK_PILEUP_SORT=partition; opt-in, it is slower than the
-    radix sort at configs[2]) against the radix sort (default) and the oracle, at the default page size and at small ones."""
+    """The pileup's (key, value) hits: row partition + one LDS sort per item (the default) against the library radix sort
+    (XCK_PILEUP_SORT=radix) and the oracle, at the default page size and at small ones, with both item sorts."""
     regions, snps, names = soa.make_tables(120, 4000, [1500000], seed=51, max_len=150000)
     bs = soa.gen_reads(regions, names, 150000, 300, seed=52)
     batches = [util.batch_from_dict(b) for b in bs]
-    for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG"):
+    for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT", "XCK_PILEUP_ITEM_SORT"):
         fold_env.pop(k, None)
-    fold_env["XCK_PILEUP_SORT"] = "partition"
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
     assert st["pileup_sort_path"] == 1 and len(exp["dp"][0]) > 1000
@@ -159,7 +158,7 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
             util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
             assert st["pileup_sort_path"] in (1, 2)
     fold_env.pop("XCK_FOLD_C"); fold_env.pop("XCK_PILEUP_ITEM_SORT")
-    fold_env.pop("XCK_PILEUP_SORT")                    # the default: radix sort
+    fold_env["XCK_PILEUP_SORT"] = "radix"
     got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
     assert st["pileup_sort_path"] == 2

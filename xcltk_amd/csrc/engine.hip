@@ -1074,18 +1074,20 @@ __global__ void __launch_bounds__(256) k_first_long(const K* __restrict__ k, con
 }
 
 // ---- split mode (64-bit keys): the sorted stream holds only hits WITH a base; the hits without one are looked up ----
-// Blocked Bloom filter over the runs, two levels in one table: (cell, UMI, SNP >> 5) and (cell, UMI, SNP); one 64-bit word,
-// two bits per entry.  A gap record first asks whether its molecule shows a base anywhere in the same block of 32 SNPs, then
-// per SNP, before any exact lookup is made.
+// Filter in front of the exact lookups: per (molecule = cell | UMI, block of 32 SNPs) ONE hashed 64-bit word that holds the
+// block's SNPs at which the molecule shows a base twice - SNP offset o as bit (o + r1) & 31 of the low half and bit (o + r2) & 31 of
+// the high half, r1 / r2 two rotations hashed from the molecule.  A gap record loads the word, rotates the halves back and ANDs
+// them: a foreign molecule in the same word must hit the same offset under both of ITS rotations (~0.4 % per SNP), and only the
+// SNPs left in the mask are looked up exactly.  One atomic per key run, one load per (record, block) whatever the gap's length.
 // The table is laid out ALONG THE SORTED STREAM: the entries of SNP block b go to the words [lo_b, lo_b + len_b), lo_b / len_b =
 // the block's index range in the sorted keys (k_blk_bounds) - one word per key, whatever the depth of the block.  The inserts of
 // k_first_base therefore land next to the keys being read, and the gap records - which arrive in position order - ask a window of
 // the table that moves along with them and stays in L2 (a table hashed over all of its 230 MB cost one HBM round trip per record).
-__device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t tag, unsigned long long lo, unsigned long long len, unsigned long long& word, unsigned long long& bits) {
-    unsigned long long x = cellumi ^ ((unsigned long long)tag * 0x9E3779B97F4A7C15ull);
-    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+__device__ __forceinline__ void bloom_slot(unsigned long long cellumi, uint32_t blk, unsigned long long lo, unsigned long long len, unsigned long long& word, uint32_t& r1, uint32_t& r2) {
+    unsigned long long x = cellumi ^ ((unsigned long long)blk * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; x *= 0x94D049BB133111EBull; x ^= x >> 31;
     word = lo + (unsigned long long)(((x & 0xffffffffull) * (len & 0xffffffffull)) >> 32);   // len < 2^32 (checked on the host)
-    bits = (1ull << ((x >> 40) & 63)) | (1ull << ((x >> 48) & 63));
+    r1 = (uint32_t)(x >> 32) & 31u; r2 = (uint32_t)(x >> 40) & 31u;
 }
 // first index of every block of 32 SNPs in the sorted keys (blk_lo[n_blk] = n): one bisection per block
 template <class K>
@@ -1118,13 +1120,11 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
         al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));      // nibble + 1 (never 0 here)
         ord_out[i] = best >> ALLELE_BITS;
     }
-    unsigned long long word, bits;
+    unsigned long long word; uint32_t r1, r2;
     const unsigned long long cu = (unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1));
     const unsigned long long b_lo = blk_lo[row >> 5], b_len = blk_lo[(row >> 5) + 1] - b_lo;   // (this key is inside: b_len >= 1)
-    bloom_slot(cu, row >> 5, b_lo, b_len, word, bits);                // level 1: (molecule, block of 32 SNPs)
-    atomicOr(&bloom[word], bits);
-    bloom_slot(cu, 0x80000000u | row, b_lo, b_len, word, bits);      // level 2: (molecule, SNP)
-    atomicOr(&bloom[word], bits);
+    bloom_slot(cu, row >> 5, b_lo, b_len, word, r1, r2);
+    atomicOr(&bloom[word], (1ull << ((row + r1) & 31u)) | (1ull << (32u + ((row + r2) & 31u))));
 }
 // every gap record (first SNP, cell, UMI | ordinal, count - 1): for each of its SNPs, if (SNP, cell, UMI) has a run and
 // this read comes EARLIER in fetch order than the run's first read with a base, the key belongs to this read
@@ -1152,12 +1152,15 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
         for (uint32_t blk = k1 >> 5; blk <= (k2 - 1) >> 5; blk++) {
             const unsigned long long b_lo = blk_lo[blk], b_len = blk_lo[blk + 1] - b_lo;
             if (!b_len) continue;                                       // no read shows a base anywhere in this block of SNPs
-            unsigned long long word, bits;
-            bloom_slot((unsigned long long)cellumi, blk, b_lo, b_len, word, bits);
-            if ((bloom[word] & bits) != bits) continue;                 // this molecule shows no base in this block of SNPs
-            for (uint32_t srow = max(k1, blk << 5); srow < min(k2, (blk + 1) << 5); srow++) {
-                bloom_slot((unsigned long long)cellumi, 0x80000000u | srow, b_lo, b_len, word, bits);
-                if ((bloom[word] & bits) != bits) continue;             // ... and none at this SNP
+            unsigned long long word; uint32_t r1, r2;
+            bloom_slot((unsigned long long)cellumi, blk, b_lo, b_len, word, r1, r2);
+            const uint32_t o0 = max(k1, blk << 5) & 31u, o1 = (min(k2, (blk + 1) << 5) - 1u) & 31u;     // the gap's SNPs inside this block: offsets o0 .. o1
+            const unsigned long long w = bloom[word];
+            const uint32_t h1 = (uint32_t)w, h2 = (uint32_t)(w >> 32);
+            uint32_t m = ((h1 >> r1) | (h1 << ((32u - r1) & 31u))) & ((h2 >> r2) | (h2 << ((32u - r2) & 31u))) & ((0xffffffffu >> (31u - o1)) & (0xffffffffu << o0));
+            while (m) {                                                 // SNPs at which this molecule (or one that shares both words) shows a base
+                const uint32_t srow = (blk << 5) + (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
                 unsigned long long lo = row_lo[srow], hi = row_hi[srow];
                 if (lo >= hi) continue;
                 const unsigned long long end = hi;
@@ -1173,8 +1176,9 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
 // byte per key; neighbouring SNPs are neighbouring slices, so a wave reads one contiguous stretch), three shuffles put the five
 // counts together and lanes 0..4 of the group store them.  (The first form - one thread per key, ballots per wave segment, atomics
 // on the SNP's counters - spent 0.77 ms at configs[2] queueing on counter lines shared by neighbouring SNPs.)
-// A SNP deeper than TALLY_LONG keys (bulk input) is queued and counted by one block (k_tally_long).
-constexpr unsigned long long TALLY_LONG = 2048;
+// A SNP deeper than TALLY_LONG keys (a hot gene: 100 k keys at configs[2]; bulk input) is queued in pieces of TALLY_PIECE keys, one
+// block per piece (k_tally_long), which add their counts to the SNP's (zeroed) counters.
+constexpr unsigned long long TALLY_LONG = 2048, TALLY_PIECE = 4096;
 __device__ __forceinline__ void tally_code(uint32_t code, uint32_t (&c)[5]) {
     const int b = code ? nib_bucket(int(code) - 1) : -1;
 #pragma unroll
@@ -1186,7 +1190,13 @@ __global__ void __launch_bounds__(256) k_tally_rows(const uint8_t* __restrict__ 
     unsigned long long lo = 0, len = 0;
     if (s < n_rows) { lo = row_lo[s]; const unsigned long long hi = row_hi[s]; len = hi > lo ? hi - lo : 0; }
     const bool is_long = len > TALLY_LONG;
-    if (is_long) { if (sub == 0) long_rows[1 + atomicAdd(&long_rows[0], 1ull)] = s; len = 0; }
+    if (is_long) {
+        if (sub == 0) {
+            const unsigned long long np = (len + TALLY_PIECE - 1) / TALLY_PIECE, at = atomicAdd(&long_rows[0], np);
+            for (unsigned long long q = 0; q < np; q++) long_rows[1 + at + q] = (s << 32) | q;      // (at most len / 2048 entries per SNP: the list holds n / 64)
+        }
+        len = 0;
+    }
     uint32_t c[5] = {0, 0, 0, 0, 0};
     for (unsigned long long t = sub; t < len; t += 8) tally_code(al[lo + t], c);
 #pragma unroll
@@ -1198,15 +1208,16 @@ __global__ void __launch_bounds__(256) k_tally_long(const uint8_t* __restrict__ 
     __shared__ uint32_t s_c[4][5];
     const unsigned long long n_long = long_rows[0];
     for (unsigned long long r = blockIdx.x; r < n_long; r += gridDim.x) {
-        const size_t s = (size_t)long_rows[1 + r];
-        const unsigned long long lo = row_lo[s], hi = row_hi[s];
+        const unsigned long long ent = long_rows[1 + r];
+        const size_t s = (size_t)(ent >> 32);
+        const unsigned long long lo = row_lo[s] + (ent & 0xffffffffull) * TALLY_PIECE, hi = min(row_hi[s], lo + TALLY_PIECE);
         uint32_t c[5] = {0, 0, 0, 0, 0};
         for (unsigned long long t = lo + threadIdx.x; t < hi; t += 256) tally_code(al[t], c);
 #pragma unroll
         for (int q = 0; q < 5; q++) { for (int d = 32; d; d >>= 1) c[q] += __shfl_xor(c[q], d); }
         if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 5; q++) s_c[threadIdx.x >> 6][q] = c[q]; }
         __syncthreads();
-        if (threadIdx.x < 5) tally[s * 5 + threadIdx.x] = s_c[0][threadIdx.x] + s_c[1][threadIdx.x] + s_c[2][threadIdx.x] + s_c[3][threadIdx.x];
+        if (threadIdx.x < 5) { const uint32_t v = s_c[0][threadIdx.x] + s_c[1][threadIdx.x] + s_c[2][threadIdx.x] + s_c[3][threadIdx.x]; if (v) atomicAdd(&tally[s * 5 + threadIdx.x], v); }
         __syncthreads();
     }
 }
@@ -2258,9 +2269,9 @@ static int finish_t(EngineImpl* im) {
         // 128-bit keys, take the radix sort
         bool sorted = false;
         if constexpr (sizeof(K) == 8) {
-            // (opt-in: at configs[2] the partition + LDS item sort takes 2.6 ms against the radix sort's 2.2 ms - the bitonic network moves
-            // every pair through LDS 66 times)
-            const bool want_part = getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "partition");
+            // (default since the items are sorted by an LDS radix sort: 1.7 ms at configs[2] against 2.3 ms for pack + rocPRIM's eight passes;
+            // XCK_PILEUP_SORT=radix forces the library sort)
+            const bool want_part = !(getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "radix"));
             if (want_part) {
                 KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
                 rc = pileup_partition_sort(im, kl8, n, (unsigned long long*)alt, valt);

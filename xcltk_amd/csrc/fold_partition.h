@@ -1095,7 +1095,8 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     int lgC = 0;
     { const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }
     PartGeom g; memset(&g, 0, sizeof g); g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.sb = PF_SB_MAX; g.n_cells = (uint32_t)im->n_cells;
-    const int lg_max = std::max(0, std::min(pf_env_int("XCK_FOLD_LGG", 6), kl.cbits));
+    // (there is no second level here: a SNP of a hot gene - 100 k hits at configs[2] - must come apart in the first one, so up to 2^10 groups per SNP)
+    const int lg_max = std::max(0, std::min(pf_env_int("XCK_PILEUP_LGG", 10), kl.cbits));
     ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
     const unsigned n_chunks = sc.chunk0[NSHARD];
