@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define XCK_ABI_VERSION 3   /* 3: xck_stats.fold_path / fold_fallbacks / pileup_sort_path; 2: xck_config.n_excl_pairs / excl_region / excl_snp, xck_ingest_opts.pause_records (older, shorter structs are still accepted) */
+#define XCK_ABI_VERSION 3   /* 3: xck_stats.fold_path / fold_fallbacks / pileup_sort_path / fold_refinements / pileup_sort2_path; 2: xck_config.n_excl_pairs / excl_region / excl_snp, xck_ingest_opts.pause_records (older, shorter structs are still accepted) */
 
 /* status codes */
 #define XCK_OK            0
@@ -167,6 +167,8 @@ typedef struct xck_stats {
     int32_t fold_fallbacks;     /* finishes of this handle in which the partition fold handed over to the radix-sort fold   */
     int32_t pileup_sort_path;   /* pileup hits of the last xck_finish: 0 none yet, 1 row partition + LDS sort per item, 2 radix sort */
     int32_t fold_refinements;   /* partition fold of the last xck_finish: times the level-2 geometry had to be refined (uneven cells) */
+    int32_t pileup_sort2_path;  /* pileup, region-level hits of the last xck_finish: 0 none, 1 partition + LDS sort per item, 2 radix sort */
+    int32_t reserved0;
 } xck_stats;
 
 typedef struct xck_engine xck_engine;     /* opaque: one per GPU */

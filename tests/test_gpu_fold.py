@@ -149,7 +149,7 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
         fold_env.pop(k, None)
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
-    assert st["pileup_sort_path"] == 1 and len(exp["dp"][0]) > 1000
+    assert st["pileup_sort_path"] == 1 and st["pileup_sort2_path"] == 1 and len(exp["dp"][0]) > 1000
     for item_sort in ("radix", "bitonic"):              # the LDS radix sort of an item (default) and the bitonic network
         fold_env["XCK_PILEUP_ITEM_SORT"] = item_sort
         for page in ("1024", "64", "8"):
@@ -161,7 +161,7 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
     fold_env["XCK_PILEUP_SORT"] = "radix"
     got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
-    assert st["pileup_sort_path"] == 2
+    assert st["pileup_sort_path"] == 2 and st["pileup_sort2_path"] == 2
 
 
 def test_uneven_cells_refine_the_level_two_geometry(fold_env):

@@ -18,7 +18,7 @@
 //                 UMIs of a run told apart by an LDS hash set) straight into COO; classic path: full sort + k_fold_emit.
 //                 pileup: sort of the hits with a base, k_first_base (first read per key, Bloom filter; k_first_long for
 //                 runs longer than 64), k_claim (gap records that hold a key earlier in fetch order), k_tally_rows, k_expand
-//                 (per-SNP filters, SNP -> region fan-out), k_hap_class / k_hap_sum / k_hap_final (haplotype set algebra
+//                 (per-SNP filters, SNP -> region fan-out), k_hap_class / k_hap_sum / k_hap_count / k_hap_scatter (haplotype set algebra
 //                 by block scans), k_cp_* (ordered compaction); 128-bit keys: k_first_read.
 //                 Copy-out on the copy stream (xck_finish_async).
 //
@@ -132,7 +132,7 @@ static_assert(sizeof(JoinArgs<unsigned __int128>) <= 4000, "kernel arguments mus
 // its own slice [shard*cap, (shard+1)*cap) of the hit buffer; finish() packs the slices.
 constexpr int NSHARD = 16;
 constexpr int CTL_OVERFLOW = 1, CTL_GIANT = 2, CTL_SCRATCH = 3, CTL_SHARD0 = 16, CTL_STRIDE = 16;
-constexpr int XSHARD = 32;                 // k_expand: sharded totals / cursors (one shared word serialises at ~90 atomics/us)
+constexpr int XSHARD = NSHARD;            // k_expand: sharded totals / cursors (one shared word serialises at ~90 atomics/us); = NSHARD: its output slices feed the partition sort
 constexpr int CTL_X0 = CTL_SHARD0 + 2 * NSHARD * CTL_STRIDE;
 constexpr int CTL_WORDS = CTL_X0 + XSHARD * CTL_STRIDE;
 struct XBases { unsigned long long base[XSHARD]; };
@@ -1238,11 +1238,11 @@ __device__ __forceinline__ bool snp_passes(const uint32_t* tally, const uint32_t
 
 // BAF step 2: expand each surviving (snp, cell, umi, allele) to the regions that contain the SNP
 // (baf/fc/main.py:92-101, core.py:156-166).  COUNT pass sums the fan-out, EMIT pass writes.
-template <class K, bool EMIT>
+template <class K, bool EMIT, class V>
 __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, const uint8_t* __restrict__ al, long long n,
                                   KeyLayout<K> kl, const uint32_t* __restrict__ tally, const uint32_t* __restrict__ info,
                                   SnpFilter f, const int32_t* __restrict__ csr_off, const int32_t* __restrict__ csr_reg,
-                                  K* __restrict__ k2, uint8_t* __restrict__ v2, unsigned long long* ctl, XBases xb) {
+                                  K* __restrict__ k2, V* __restrict__ v2, unsigned long long* ctl, XBases xb) {
     __shared__ uint32_t s_wave[JOIN_BLOCK / 64];
     __shared__ unsigned long long s_base;
     long long i = (long long)blockIdx.x * JOIN_BLOCK + threadIdx.x;
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
     int idx = -1;                                        // snp.gt = {ref: ref_idx, alt: alt_idx}: alt wins if equal
     if (nib == int(inf & 15)) idx = int((inf >> 8) & 1);
     if (nib == int((inf >> 4) & 15)) idx = int((inf >> 9) & 1);
-    uint8_t bits = idx == 0 ? 1 : idx == 1 ? 2 : 4;
+    const V bits = idx == 0 ? 1 : idx == 1 ? 2 : 4;
     uint32_t cell = kl.cell(me); uint64_t umi = kl.umi(me);
     for (int32_t c = csr_off[s]; c < csr_off[s + 1]; c++, dst++) {
         k2[dst] = kl.make((uint32_t)csr_reg[c], cell, umi);
@@ -1283,23 +1283,23 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
 //   k_hap_class: head of every (row, cell, UMI) run: OR of the run's haplotype bits (one entry per SNP the molecule meets: a few)
 //   k_hap_sum  : per 2048-key tile, ONE block scan of four packed counters (REF-hap, ALT-hap, either, other-only keys); a run
 //                that starts in the tile gets its counts up to the tile end, what later tiles hold of it arrives by atomicAdd
-//   k_hap_final: the no_dup_hap arithmetic on the per-run sums -> AD / DP / OTH per run
-template <class K>
-__global__ void k_hap_class(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, uint8_t* __restrict__ cls, unsigned long long* __restrict__ long_runs) {
+//   k_hap_count / k_hap_scatter: the no_dup_hap arithmetic on the per-run sums -> AD / DP / OTH, compacted into COO
+template <class K, class V>
+__global__ void k_hap_class(const K* __restrict__ k, const V* __restrict__ v, long long n, uint8_t* __restrict__ cls, unsigned long long* __restrict__ long_runs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const K me = k[i];
     if (i > 0 && k[i - 1] == me) { cls[i] = 0; return; }
-    uint32_t bits = v[i];
+    uint32_t bits = (uint32_t)v[i];
     long long j = i + 1;
-    for (; j < n && j <= i + RUN_WALK && k[j] == me; j++) bits |= v[j];
+    for (; j < n && j <= i + RUN_WALK && k[j] == me; j++) bits |= (uint32_t)v[j];
     // a molecule that meets more than RUN_WALK SNPs of one region (constant UMI tags, bulk input: thousands) is not walked by its
     // head lane: the head queues the run and one block per run finishes it (k_hap_class_long)
     if (j < n && j > i + RUN_WALK && k[j] == me) { cls[i] = 4; long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = (unsigned long long)i; return; }
     cls[i] = (uint8_t)bits;                                               // 1 REF haplotype, 2 ALT haplotype, 4 other allele; never 0 at a head
 }
-template <class K>
-__global__ void __launch_bounds__(256) k_hap_class_long(const K* __restrict__ k, const uint8_t* __restrict__ v, long long n, const unsigned long long* __restrict__ long_runs, uint8_t* __restrict__ cls) {
+template <class K, class V>
+__global__ void __launch_bounds__(256) k_hap_class_long(const K* __restrict__ k, const V* __restrict__ v, long long n, const unsigned long long* __restrict__ long_runs, uint8_t* __restrict__ cls) {
     __shared__ uint32_t s_or[4];
     const unsigned long long n_long = long_runs[0];
     for (unsigned long long r = blockIdx.x; r < n_long; r += gridDim.x) {
@@ -1308,7 +1308,7 @@ __global__ void __launch_bounds__(256) k_hap_class_long(const K* __restrict__ k,
         long long lo = h + 1, hi = n;                                     // first index past the run
         while (lo < hi) { const long long mid = lo + ((hi - lo) >> 1); if (k[mid] == me) lo = mid + 1; else hi = mid; }
         uint32_t bits = 0;
-        for (long long j = h + threadIdx.x; j < lo; j += blockDim.x) bits |= v[j];
+        for (long long j = h + threadIdx.x; j < lo; j += blockDim.x) bits |= (uint32_t)v[j];
         for (int d = 32; d; d >>= 1) bits |= __shfl_xor(bits, d);
         if ((threadIdx.x & 63) == 0) s_or[threadIdx.x >> 6] = bits;
         __syncthreads();
@@ -1387,19 +1387,6 @@ __global__ __launch_bounds__(FD_BLOCK) void k_hap_sum(const K* __restrict__ k, c
         const unsigned long long lead = n_heads ? s_x[0] : tot;          // keys of the run that the previous tiles started
         if (lead && out > 0) add(out - 1, lead, true);
     }
-}
-
-__global__ void k_hap_final(const uint32_t* __restrict__ acc, long long n_runs_max, const unsigned long long* __restrict__ n_runs, long long stride, int no_dup_hap,
-                            int32_t* __restrict__ ad, int32_t* __restrict__ dp, int32_t* __restrict__ oth) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_runs_max || (unsigned long long)i >= *n_runs) return;     // (ad / dp / oth are zero beyond the runs)
-    int32_t ref = (int32_t)acc[i], alt = (int32_t)acc[stride + i], d = (int32_t)acc[2 * stride + i]; const int32_t ot = (int32_t)acc[3 * stride + i];
-    if (ref + alt != d) {
-        if (no_dup_hap) { const int32_t share = ref + alt - d; ref -= share; alt -= share; }
-        d = ref + alt;
-    }
-    if (d + ot <= 0) return;
-    ad[i] = alt > 0 ? alt : 0; dp[i] = d > 0 ? d : 0; oth[i] = ot > 0 ? ot : 0;
 }
 
 // Control words go to the host through MAPPED pinned memory written by a tiny kernel, never through the
@@ -1498,6 +1485,77 @@ __global__ __launch_bounds__(CP_BLOCK) void k_cp_scatter(const int32_t* __restri
     }
 }
 
+// The haplotype matrices straight from the per-run sums: the no_dup_hap arithmetic (baf/fc/core.py:173-192) is done by the count pass
+// and by the scatter pass instead of going through three dense arrays (written once, read twice, 2 x the runs long because the arrays
+// were sized for the keys).  Eight consecutive runs per thread (two 16-byte loads per sum array; `stride` is a multiple of 8 and the
+// arrays are zero beyond the runs, so nothing is bounds-checked per element); tiles beyond the runs leave at once.  One block scan
+// of the three counts packed into one 64-bit word.  Output order = run order = (row, cell) order.
+struct HapSrc { const uint32_t* acc; long long stride; const unsigned long long* n_runs; int no_dup_hap; };
+__device__ __forceinline__ void hap_load8(const HapSrc& h, long long i0, int32_t (&ad)[CP_ITEMS], int32_t (&dp)[CP_ITEMS], int32_t (&oth)[CP_ITEMS]) {
+    static_assert(CP_ITEMS == 8, "two uint4 per array");
+    uint32_t a[4][CP_ITEMS];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const uint4* p = reinterpret_cast<const uint4*>(h.acc + (size_t)f * h.stride + i0);
+        const uint4 x = p[0], y = p[1];
+        a[f][0] = x.x; a[f][1] = x.y; a[f][2] = x.z; a[f][3] = x.w; a[f][4] = y.x; a[f][5] = y.y; a[f][6] = y.z; a[f][7] = y.w;
+    }
+#pragma unroll
+    for (int t = 0; t < CP_ITEMS; t++) {
+        int32_t ref = (int32_t)a[0][t], alt = (int32_t)a[1][t], d = (int32_t)a[2][t]; const int32_t ot = (int32_t)a[3][t];
+        if (ref + alt != d) {
+            if (h.no_dup_hap) { const int32_t share = ref + alt - d; ref -= share; alt -= share; }
+            d = ref + alt;
+        }
+        const bool keep = d + ot > 0;
+        ad[t] = keep && alt > 0 ? alt : 0; dp[t] = keep && d > 0 ? d : 0; oth[t] = keep && ot > 0 ? ot : 0;
+    }
+}
+__global__ __launch_bounds__(CP_BLOCK) void k_hap_count(HapSrc h, uint32_t* __restrict__ blk) {
+    __shared__ unsigned long long s_w[CP_BLOCK / 64];
+    const long long n = (long long)*h.n_runs, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
+    if ((long long)blockIdx.x * CP_TILE >= n) { if (threadIdx.x < 3) blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = 0; return; }
+    unsigned long long c = 0;
+    if (i0 < n) {
+        int32_t ad[CP_ITEMS], dp[CP_ITEMS], oth[CP_ITEMS];
+        hap_load8(h, i0, ad, dp, oth);
+#pragma unroll
+        for (int t = 0; t < CP_ITEMS; t++) c += (unsigned long long)(ad[t] > 0) | ((unsigned long long)(dp[t] > 0) << 21) | ((unsigned long long)(oth[t] > 0) << 42);
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x < 3) { const unsigned long long t = s_w[0] + s_w[1] + s_w[2] + s_w[3]; blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (uint32_t)(t >> (21 * threadIdx.x)) & 0x1fffffu; }
+}
+template <class K>
+__global__ __launch_bounds__(CP_BLOCK) void k_hap_scatter(HapSrc h, const K* __restrict__ k, KeyLayout<K> kl, const unsigned long long* __restrict__ off, CooOut3 out) {
+    __shared__ unsigned long long s_w[FD_BLOCK / 64];
+    static_assert(FD_BLOCK == CP_BLOCK, "block_excl_scan64 is written for FD_BLOCK threads");
+    const long long n = (long long)*h.n_runs, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
+    if ((long long)blockIdx.x * CP_TILE >= n) return;
+    int32_t v[3][CP_ITEMS];
+    unsigned long long c = 0;
+    if (i0 < n) {
+        hap_load8(h, i0, v[0], v[1], v[2]);
+#pragma unroll
+        for (int t = 0; t < CP_ITEMS; t++) c += (unsigned long long)(v[0][t] > 0) | ((unsigned long long)(v[1][t] > 0) << 21) | ((unsigned long long)(v[2][t] > 0) << 42);
+    }
+    unsigned long long total;
+    const unsigned long long excl = block_excl_scan64(c, s_w, total);
+    if (!c) return;
+    K key[CP_ITEMS];
+#pragma unroll
+    for (int t = 0; t < CP_ITEMS; t++) key[t] = k[i0 + t];               // (c != 0: the thread's runs exist; `k` holds one key per run and is at least stride long)
+#pragma unroll
+    for (int y = 0; y < 3; y++) {
+        int32_t* __restrict__ row = out.o[y]; int32_t* __restrict__ col = row + out.total[y]; int32_t* __restrict__ val = col + out.total[y];
+        unsigned long long d = off[(size_t)y * gridDim.x + blockIdx.x] + ((excl >> (21 * y)) & 0x1fffffull);
+#pragma unroll
+        for (int t = 0; t < CP_ITEMS; t++)
+            if (v[y][t] > 0) { row[d] = (int32_t)kl.row(key[t]); col[d] = (int32_t)kl.cell(key[t]); val[d] = v[y][t]; d++; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1560,6 +1618,7 @@ struct EngineImpl {
     int fold_extra_digits = 0;                 // basefc hash fold: extra radix digits that earlier finishes needed (giant runs)
     int fold_path = 0, fold_fallbacks = 0;     // xck_stats: which basefc fold ran last (1 partition, 2 radix sort), hand-overs so far
     int pileup_sort_path = 0;                  // pileup hits of the last finish: 1 sorted by partition + LDS sort, 2 by the radix sort
+    int pileup_sort2_path = 0;                 // ... and its region-level hits
     int fold_refinements = 0;                  // partition fold of the last finish: refinements of the level-2 geometry
     // fused launch queue
     std::vector<BatchDesc> queue;              // not yet launched (device-resident pushes are deferred)
@@ -2045,12 +2104,13 @@ static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total);
 // ordered compaction of dense[y][i] > 0 (y = 0..nm-1, arrays n apart) into the COO blocks of matrices m0..m0+nm-1:
 // counts and scans of all matrices first, ONE read-back of the totals, then the scatters and the copy-out
 template <class K>
-static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m0, int nm) {
+static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m0, int nm, const HapSrc* hap = nullptr) {
     size_t nb = (n + CP_TILE - 1) / CP_TILE;
     uint32_t* d_blk = ws.get<uint32_t>(nb * nm); unsigned long long* d_off = ws.get<unsigned long long>(nb * nm);
     if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (compaction)"; return XCK_E_NOMEM; }
     unsigned long long* d_tot = im->d_ctl + CTL_X0;                       // the k_expand words are free again at this point
-    hipLaunchKernelGGL(k_cp_count, dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
+    if (hap) hipLaunchKernelGGL(k_hap_count, dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, *hap, d_blk);      // (nm == 3: AD, DP, OTH from the per-run sums)
+    else hipLaunchKernelGGL(k_cp_count, dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
     hipLaunchKernelGGL(k_cp_scan, dim3(nm), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, d_tot);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)d_tot, im->d_hctl + CTL_X0, nm);
@@ -2068,7 +2128,8 @@ static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K*
         any = true;
     }
     if (!any) return 0;
-    hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off, out);
+    if (hap) hipLaunchKernelGGL((k_hap_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, *hap, keys, kl, (const unsigned long long*)d_off, out);
+    else hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off, out);
     HIP_TRY(hipGetLastError());
     // copy-out: large blocks go through copy_out() (copy stream); the small ones share one store kernel into mapped pinned memory
     CopySeg3 sg; memset(&sg, 0, sizeof sg); size_t mx = 0;
@@ -2274,7 +2335,8 @@ static int finish_t(EngineImpl* im) {
             const bool want_part = !(getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "radix"));
             if (want_part) {
                 KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
-                rc = pileup_partition_sort(im, kl8, n, (unsigned long long*)alt, valt);
+                rc = pileup_partition_sort(im, im->ws2, true, kl8, (const unsigned long long*)im->d_keys, (const uint64_t*)im->d_vals, im->hit_cap, im->cur,
+                                           (uint32_t)std::max(im->n_snps_sorted, 1), n, (unsigned long long*)alt, valt);
                 if (rc == 0) { sorted = true; im->pileup_sort_path = 1; }
                 else if (rc != PF_FALLBACK) return rc;
             }
@@ -2330,47 +2392,78 @@ static int finish_t(EngineImpl* im) {
         hipLaunchKernelGGL((k_first_long<K, false>), dim3(1024), dim3(256), 0, im->s_comp, alt, valt, (long long)n, kl, (const unsigned long long*)long_runs, al, (uint64_t*)nullptr, im->d_tally);
         HIP_TRY(hipGetLastError());
         }
+        // region-level values: 64-bit words beside 64-bit keys (the partition sort carries 64-bit values), bytes beside 128-bit keys
+        typedef typename std::conditional<sizeof(K) == 8, uint64_t, uint8_t>::type V2;
         XBases xb; memset(&xb, 0, sizeof xb);
         HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_X0, 0, XSHARD * CTL_STRIDE * sizeof(unsigned long long), im->s_comp));
-        hipLaunchKernelGGL((k_expand<K, false>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (uint8_t*)nullptr, im->d_ctl, xb);
+        hipLaunchKernelGGL((k_expand<K, false, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
+                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (V2*)nullptr, im->d_ctl, xb);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_X0), im->d_hctl + CTL_X0, XSHARD * CTL_STRIDE);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(im->s_comp));
-        size_t n2 = 0;
-        for (int sh = 0; sh < XSHARD; sh++) { xb.base[sh] = n2; n2 += im->h_ctl[CTL_X0 + sh * CTL_STRIDE]; }
+        size_t n2 = 0; unsigned long long tot2[XSHARD], cap2 = 0;
+        for (int sh = 0; sh < XSHARD; sh++) { tot2[sh] = im->h_ctl[CTL_X0 + sh * CTL_STRIDE]; n2 += tot2[sh]; cap2 = std::max(cap2, tot2[sh]); }
+        cap2 = (cap2 + 63) & ~63ull;
         if (n2) {
-            const size_t tmpb2 = sort_tmp_bytes<K, uint8_t>(n2, top);
+            // 64-bit keys: k_expand writes its 16 slices at a fixed stride and the partition sort (fold_partition.h) orders them; when it hands
+            // back PF_FALLBACK (a (region, cell group) deeper than an item), or with 128-bit keys, k_expand writes the slices back to back and
+            // the library radix sort orders them.  XCK_PILEUP_SORT=radix forces the latter.
+            const bool try_part = sizeof(K) == 8 && !(getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "radix"));
+            const size_t n2s = try_part ? std::max<size_t>((size_t)XSHARD * cap2, n2) : n2;      // entries of the unsorted buffers
+            const size_t tmpb2 = sort_tmp_bytes<K, V2>(n2, top);
             const size_t nb2 = (n2 + CP_TILE - 1) / CP_TILE;
-            if ((rc = arena_begin(im, im->ws2, 2 * n2 * sizeof(K) + 2 * n2 + 3 * n2 * 4 + 4 * n2 * 4 + tmpb2 + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (n2 / RUN_WALK + 2) * 8 + (1 << 16)))) return rc;
-            K* k2 = im->ws2.get<K>(n2); K* k2b = im->ws2.get<K>(n2); uint8_t* v2 = im->ws2.get<uint8_t>(n2); uint8_t* v2b = im->ws2.get<uint8_t>(n2);
-            void* tmp2 = im->ws2.get<char>(tmpb2); int32_t* dense = im->ws2.get<int32_t>(3 * n2);
-            hipLaunchKernelGGL((k_expand<K, true>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                               im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
-            HIP_TRY(hipGetLastError());
-            if ((rc = sort_run<K, uint8_t>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
+            const size_t part_bytes = try_part ? partition_sort_scratch(n2, (size_t)std::max(im->n_regions, 1)) : 0;
+            if ((rc = arena_begin(im, im->ws2, (n2s + n2 + 8) * (sizeof(K) + sizeof(V2)) + n2 + 4 * (n2 + 8) * 4 + std::max(tmpb2, part_bytes) + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (n2 / RUN_WALK + 2) * 8 + (1 << 16)))) return rc;
+            K* k2 = im->ws2.get<K>(n2s + 8); K* k2b = im->ws2.get<K>(n2); V2* v2 = im->ws2.get<V2>(n2s); V2* v2b = im->ws2.get<V2>(n2);
+            uint8_t* cls = im->ws2.get<uint8_t>(n2);
+            const size_t ws2_mark = im->ws2.off;
+            bool sorted2 = false;
+            if constexpr (sizeof(K) == 8) {
+                if (try_part) {
+                    for (int sh = 0; sh < XSHARD; sh++) xb.base[sh] = (unsigned long long)sh * cap2;
+                    hipLaunchKernelGGL((k_expand<K, true, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
+                                       im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
+                    HIP_TRY(hipGetLastError());
+                    KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
+                    rc = pileup_partition_sort(im, im->ws2, false, kl8, (const unsigned long long*)k2, (const uint64_t*)v2, (size_t)cap2, tot2,
+                                               (uint32_t)std::max(im->n_regions, 1), n2, (unsigned long long*)k2b, (uint64_t*)v2b);
+                    im->ws2.off = ws2_mark;                                    // (its scratch is free again; the kernels that used it are ordered before the next ones)
+                    if (rc == 0) { sorted2 = true; im->pileup_sort2_path = 1; }
+                    else if (rc != PF_FALLBACK) return rc;
+                    else {                                                 // the cursors of the emit pass start again
+                        for (int sh = 0; sh < XSHARD; sh++) HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_X0 + sh * CTL_STRIDE + 1, 0, sizeof(unsigned long long), im->s_comp));
+                    }
+                }
+            }
+            if (!sorted2) {
+                im->pileup_sort2_path = 2;
+                void* tmp2 = im->ws2.get<char>(tmpb2);
+                { unsigned long long at = 0; for (int sh = 0; sh < XSHARD; sh++) { xb.base[sh] = at; at += tot2[sh]; } }
+                hipLaunchKernelGGL((k_expand<K, true, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
+                                   im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
+                HIP_TRY(hipGetLastError());
+                if ((rc = sort_run<K, V2>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
+            }
             const unsigned gs2 = (unsigned)((n2 + 255) / 256);
             const size_t nt2 = (n2 + FD_TILE - 1) / FD_TILE;
-            uint8_t* cls = v2;                                              // (the unsorted values are dead after the sort)
             uint32_t* d_blk2 = im->ws2.get<uint32_t>(nt2); unsigned long long* d_off2 = im->ws2.get<unsigned long long>(nt2);
-            uint32_t* acc = im->ws2.get<uint32_t>(4 * n2); K* run_key = k2;  // (so are the unsorted keys)
+            const long long stride2 = (long long)((n2 + 7) & ~size_t(7));  // (k_hap_count / k_hap_scatter read eight runs with two 16-byte loads)
+            uint32_t* acc = im->ws2.get<uint32_t>(4 * (size_t)stride2); K* run_key = k2;  // (the unsorted keys are dead after the sort)
             if (!d_blk2 || !d_off2 || !acc) { im->eng->err = "workspace exhausted (haplotype sums)"; return XCK_E_NOMEM; }
-            HIP_TRY(hipMemsetAsync(acc, 0, 4 * n2 * sizeof(uint32_t), im->s_comp));
-            HIP_TRY(hipMemsetAsync(dense, 0, 3 * n2 * sizeof(int32_t), im->s_comp));
+            HIP_TRY(hipMemsetAsync(acc, 0, 4 * (size_t)stride2 * sizeof(uint32_t), im->s_comp));
             unsigned long long* long2 = im->ws2.get<unsigned long long>(n2 / (size_t)RUN_WALK + 2);   // [0] = count, then the heads of the (row, cell, UMI) runs longer than RUN_WALK
             if (!long2) { im->eng->err = "workspace exhausted (haplotype classes)"; return XCK_E_NOMEM; }
             HIP_TRY(hipMemsetAsync(long2, 0, sizeof(unsigned long long), im->s_comp));
-            hipLaunchKernelGGL((k_hap_class<K>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const uint8_t*)v2b, (long long)n2, cls, long2);
-            hipLaunchKernelGGL((k_hap_class_long<K>), dim3(256), dim3(256), 0, im->s_comp, (const K*)k2b, (const uint8_t*)v2b, (long long)n2, (const unsigned long long*)long2, cls);
+            hipLaunchKernelGGL((k_hap_class<K, V2>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const V2*)v2b, (long long)n2, cls, long2);
+            hipLaunchKernelGGL((k_hap_class_long<K, V2>), dim3(256), dim3(256), 0, im->s_comp, (const K*)k2b, (const V2*)v2b, (long long)n2, (const unsigned long long*)long2, cls);
             hipLaunchKernelGGL((k_fold_heads<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (long long)n2, kl, d_blk2);
             hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk2, (long long)nt2, d_off2, im->d_ctl + CTL_SCRATCH);
             hipLaunchKernelGGL((k_hap_sum<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (const uint8_t*)cls, (long long)n2, kl,
-                               (const unsigned long long*)d_off2, run_key, acc, (long long)n2);
-            hipLaunchKernelGGL(k_hap_final, dim3(gs2), dim3(256), 0, im->s_comp, (const uint32_t*)acc, (long long)n2, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH),
-                               (long long)n2, im->no_dup_hap, dense, dense + n2, dense + 2 * n2);
+                               (const unsigned long long*)d_off2, run_key, acc, stride2);
             HIP_TRY(hipGetLastError());
-            if ((rc = compact_coo<K>(im, im->ws2, dense, run_key, n2, kl, 1, 3))) return rc;          // AD, DP, OTH together (one entry per run; zeros beyond the runs)
+            const HapSrc hs{(const uint32_t*)acc, stride2, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->no_dup_hap};
+            if ((rc = compact_coo<K>(im, im->ws2, (const int32_t*)nullptr, run_key, n2, kl, 1, 3, &hs))) return rc;   // AD, DP, OTH together, from the per-run sums
         }
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     }
@@ -2457,6 +2550,7 @@ int engine_stats(const xck_engine* e, xck_stats* out) {
     *out = im->st; out->key_bits = im->key_bits; out->umi_bits = im->ubits;
     out->n_join_launches = im->n_join_launches;
     out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks; out->pileup_sort_path = im->pileup_sort_path; out->fold_refinements = im->fold_refinements;
+    out->pileup_sort2_path = im->pileup_sort2_path; out->reserved0 = 0;
     return 0;
 }
 

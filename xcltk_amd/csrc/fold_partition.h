@@ -1084,45 +1084,57 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
     for (int r = 0; r < RS_EPT; r++) { const uint32_t e = e0 + r * 64; if (e < n) { keys[off + e] = key[r]; vals[off + e] = val[r]; } }
 }
 
-// (key, value) hits in the shard slices of im->d_keys / d_vals -> out_keys / out_vals (n entries each) sorted by (key, value).
-// Cells as in the basefc fold: every SNP gets 2^l cell groups so that a group holds about C / 2 hits (a SNP in a hot gene is tens of
-// thousands of reads deep); the groups of a SNP are in cell order, so cell order = key order.  0 = done, PF_FALLBACK = use the radix
-// sort (the shard slices are untouched either way), < 0 = error.  Scratch from im->ws2.
-static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> kl, size_t n, unsigned long long* out_keys, uint64_t* out_vals) {
+// (key, value) pairs in 16 slices (slice sh = src[sh * cap .. + cnt[sh]); the slices filled round-robin by the blocks of a kernel that walks
+// a position-ordered stream) -> out_keys / out_vals (n entries each) sorted by key; equal keys in any order.  Used for the pileup's hits
+// with a base (rows = SNPs; slices = the join's shard slices) and for its region-level hits (rows = regions; slices = k_expand's).
+// Cells as in the basefc fold: every row gets 2^l cell groups so that a group holds about C / 2 hits (a SNP in a hot gene is tens of
+// thousands of reads deep); the groups of a row are in cell order, so cell order = key order.  0 = done, PF_FALLBACK = use the radix
+// sort (the source slices are untouched either way), < 0 = error.  Scratch: `ar`, begun here when `own_arena`, else reserved by the
+// caller (partition_sort_scratch()).
+struct PartSortSizes { size_t rs, z_cap, zs_cap, wi_cap, sb, bytes; };
+static PartSortSizes partition_sort_sizes(size_t n, size_t n_rows, int lgC) {
+    PartSortSizes q;
+    q.rs = n_rows + 1;
+    q.z_cap = n_rows + 4 * ((n + (size_t)NSHARD * 16 * PT_CHUNK) >> lgC) + 64;      // (16 = the largest sampling stride of the row histogram)
+    q.zs_cap = q.z_cap + 1; q.wi_cap = 3 * (n >> lgC) + 8;
+    q.sb = (std::max(std::max(q.zs_cap, q.rs), q.wi_cap + 1) + SC_TILE - 1) / SC_TILE + 8;
+    q.bytes = 3 * (q.rs * 4 + 256) + 2 * (q.zs_cap * 4 + 256) + (q.wi_cap + 1) * 4 + q.sb * 4 + 64 * 4 + (1 << 16);
+    return q;
+}
+static int partition_sort_lgC() { int lgC = 0; const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; return lgC; }
+static size_t partition_sort_scratch(size_t n, size_t n_rows) { return partition_sort_sizes(n, n_rows, partition_sort_lgC()).bytes; }
+static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyLayout<unsigned long long> kl, const unsigned long long* src_keys, const uint64_t* src_vals,
+                                 size_t src_cap, const unsigned long long* src_cnt, uint32_t n_rows, size_t n, unsigned long long* out_keys, uint64_t* out_vals) {
     typedef unsigned long long K;
     if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;
-    const uint32_t n_rows = (uint32_t)std::max(im->n_snps_sorted, 1);
-    int lgC = 0;
-    { const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }
+    const int lgC = partition_sort_lgC();
     PartGeom g; memset(&g, 0, sizeof g); g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.sb = PF_SB_MAX; g.n_cells = (uint32_t)im->n_cells;
     // (there is no second level here: a SNP of a hot gene - 100 k hits at configs[2] - must come apart in the first one, so up to 2^10 groups per SNP)
     const int lg_max = std::max(0, std::min(pf_env_int("XCK_PILEUP_LGG", 10), kl.cbits));
-    ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
-    for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
+    ShardChunks sc; sc.cap = src_cap; sc.chunk0[0] = 0;
+    for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)src_cnt[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((src_cnt[sh] + PT_CHUNK - 1) / PT_CHUNK); }
     const unsigned n_chunks = sc.chunk0[NSHARD];
-    size_t max_cur = 0; for (int sh = 0; sh < NSHARD; sh++) max_cur = std::max<size_t>(max_cur, im->cur[sh]);
+    size_t max_cur = 0; for (int sh = 0; sh < NSHARD; sh++) max_cur = std::max<size_t>(max_cur, src_cnt[sh]);
     const unsigned n_blocks1 = (unsigned)((max_cur + PT_THREADS - 1) / PT_THREADS);
     const uint32_t stride = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n_chunks / 4096));
     ShardChunks scs = sc;
-    for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((im->cur[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
+    for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((src_cnt[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
     BigChunks bc0; memset(&bc0, 0, sizeof bc0);
-    const size_t rs = (size_t)n_rows + 1;
-    const size_t z_cap = (size_t)n_rows + 4 * ((n + (size_t)NSHARD * stride * PT_CHUNK) >> lgC) + 64;
+    const PartSortSizes q = partition_sort_sizes(n, n_rows, lgC);
+    const size_t rs = q.rs, z_cap = q.z_cap, zs_cap = q.zs_cap, wi_cap = q.wi_cap, sb = q.sb;
     if (z_cap > (size_t(1) << 26)) return PF_FALLBACK;
-    const size_t zs_cap = z_cap + 1, wi_cap = 3 * (n >> lgC) + 8;
-    const size_t sb = (std::max(std::max(zs_cap, rs), wi_cap + 1) + SC_TILE - 1) / SC_TILE + 8;
     int rc;
-    if ((rc = arena_begin(im, im->ws2, 3 * (rs * 4 + 256) + 2 * (zs_cap * 4 + 256) + (wi_cap + 1) * 4 + sb * 4 + 64 * 4 + (1 << 16)))) return rc;
-    uint32_t* rowcnt = im->ws2.get<uint32_t>(rs); uint32_t* zb = im->ws2.get<uint32_t>(rs); uint32_t* rowtab = im->ws2.get<uint32_t>(rs);
-    uint32_t* S = im->ws2.get<uint32_t>(zs_cap); uint32_t* fs = im->ws2.get<uint32_t>(zs_cap); uint32_t* item_off = im->ws2.get<uint32_t>(wi_cap + 1);
-    uint32_t* bsum = im->ws2.get<uint32_t>(sb); uint32_t* ctr = im->ws2.get<uint32_t>(64);
+    if (own_arena && (rc = arena_begin(im, ar, q.bytes))) return rc;
+    uint32_t* rowcnt = ar.get<uint32_t>(rs); uint32_t* zb = ar.get<uint32_t>(rs); uint32_t* rowtab = ar.get<uint32_t>(rs);
+    uint32_t* S = ar.get<uint32_t>(zs_cap); uint32_t* fs = ar.get<uint32_t>(zs_cap); uint32_t* item_off = ar.get<uint32_t>(wi_cap + 1);
+    uint32_t* bsum = ar.get<uint32_t>(sb); uint32_t* ctr = ar.get<uint32_t>(64);
     if (!rowcnt || !zb || !rowtab || !S || !fs || !item_off || !bsum || !ctr) { im->eng->err = "workspace exhausted (pileup partition)"; return XCK_E_NOMEM; }
     g.rowtab = rowtab;
     unsigned long long* h_ctr = im->h_ctl + CTL_X0; unsigned long long* d_hctr = im->d_hctl + CTL_X0;   // (the k_expand words: not in use yet)
     const unsigned gr = (unsigned)((rs + 255) / 256);
     HIP_TRY(hipMemsetAsync(rowcnt, 0, rs * 4, im->s_comp));
     HIP_TRY(hipMemsetAsync(ctr, 0, 64 * 4, im->s_comp));
-    hipLaunchKernelGGL(k_pf_rowhist, dim3(scs.chunk0[NSHARD]), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, scs, stride, kl.ubits + kl.cbits, rowcnt);
+    hipLaunchKernelGGL(k_pf_rowhist, dim3(scs.chunk0[NSHARD]), dim3(PT_THREADS), 0, im->s_comp, (const K*)src_keys, scs, stride, kl.ubits + kl.cbits, rowcnt);
     hipLaunchKernelGGL(k_pf_rowplan, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)rowcnt, n_rows, stride, 0, lg_max, lgC, zb);
     HIP_TRY(hipGetLastError());
     if ((rc = pf_scan(im, zb, rs, bsum, ctr + 8))) return rc;
@@ -1135,7 +1147,7 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     const unsigned gz = (unsigned)((zs + 255) / 256);
     hipLaunchKernelGGL(k_pf_rowtab, dim3(gr), dim3(256), 0, im->s_comp, (const uint32_t*)zb, n_rows, kl.cbits, rowtab, (uint32_t*)nullptr);
     HIP_TRY(hipMemsetAsync(S, 0, zs * 4, im->s_comp));
-    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S);
+    hipLaunchKernelGGL((k_pf_hist<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)src_keys, sc, bc0, g, 0, S);
     HIP_TRY(hipGetLastError());
     if ((rc = pf_scan(im, S, zs, bsum, nullptr))) return rc;
     hipLaunchKernelGGL(k_pf_plan0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, lgC, fs, ctr);
@@ -1151,7 +1163,7 @@ static int pileup_partition_sort(EngineImpl* im, KeyLayout<unsigned long long> k
     const size_t n_items = h_ctr[0];
     if (n_items > wi_cap) { im->eng->err = "internal: pileup items exceed their bound"; return XCK_E_STATE; }
     hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
-    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, 0, S, out_keys, (const uint64_t*)im->d_vals, out_vals);
+    hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)src_keys, sc, bc0, g, 0, S, out_keys, src_vals, out_vals);
     const bool bitonic = getenv("XCK_PILEUP_ITEM_SORT") && !strcmp(getenv("XCK_PILEUP_ITEM_SORT"), "bitonic");
     if (bitonic) hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     else hipLaunchKernelGGL(k_pf_radix_items, dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
