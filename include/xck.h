@@ -167,7 +167,7 @@ typedef struct xck_stats {
     int32_t fold_fallbacks;     /* finishes of this handle in which the partition fold handed over to the radix-sort fold   */
     int32_t pileup_sort_path;   /* pileup hits of the last xck_finish: 0 none yet, 1 row partition + LDS sort per item, 2 radix sort */
     int32_t fold_refinements;   /* partition fold of the last xck_finish: times the level-2 geometry had to be refined (uneven cells) */
-    int32_t pileup_sort2_path;  /* pileup, region-level hits of the last xck_finish: 0 none, 1 partition + LDS sort per item, 2 radix sort */
+    int32_t pileup_sort2_path;  /* pileup, region-level hits of the last xck_finish: 0 none, 1 partition + per-item hash classification (no sort), 2 radix sort, 3 partition + LDS sort per item */
     int32_t reserved0;
 } xck_stats;
 

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def fold_env():
-    saved = {k: os.environ.get(k) for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT", "XCK_PILEUP_ITEM_SORT")}
+    saved = {k: os.environ.get(k) for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT", "XCK_PILEUP_ITEM_SORT", "XCK_PILEUP_HAP")}
     yield os.environ
     for k, v in saved.items():
         if v is None:
@@ -145,7 +145,7 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
     regions, snps, names = soa.make_tables(120, 4000, [1500000], seed=51, max_len=150000)
     bs = soa.gen_reads(regions, names, 150000, 300, seed=52)
     batches = [util.batch_from_dict(b) for b in bs]
-    for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT", "XCK_PILEUP_ITEM_SORT"):
+    for k in ("XCK_FOLD", "XCK_FOLD_C", "XCK_FOLD_LGG", "XCK_PILEUP_SORT", "XCK_PILEUP_ITEM_SORT", "XCK_PILEUP_HAP"):
         fold_env.pop(k, None)
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
@@ -157,7 +157,14 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
             got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
             util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
             assert st["pileup_sort_path"] in (1, 2)
-    fold_env.pop("XCK_FOLD_C"); fold_env.pop("XCK_PILEUP_ITEM_SORT")
+    fold_env.pop("XCK_PILEUP_ITEM_SORT")
+    fold_env["XCK_PILEUP_HAP"] = "sorted"               # region-level items sorted completely + k_hap_class / k_hap_sum, instead of k_hap_items
+    for page in ("1024", "8"):
+        fold_env["XCK_FOLD_C"] = page
+        got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
+        util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+        assert st["pileup_sort2_path"] in (3, 2)
+    fold_env.pop("XCK_FOLD_C"); fold_env.pop("XCK_PILEUP_HAP")
     fold_env["XCK_PILEUP_SORT"] = "radix"
     got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])

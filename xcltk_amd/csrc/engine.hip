@@ -1417,21 +1417,8 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const K* __restrict__ sk, co
     }
 }
 
-// ordered compaction of the non-zero entries of a dense int32 array into COO --------------------
+// ordered compaction of the haplotype matrices into COO -------------------------------------------
 constexpr int CP_BLOCK = 256, CP_ITEMS = 8, CP_TILE = CP_BLOCK * CP_ITEMS;
-
-// (the three haplotype matrices AD / DP / OTH are compacted together: blockIdx.y = matrix, dense arrays n apart)
-__global__ __launch_bounds__(CP_BLOCK) void k_cp_count(const int32_t* __restrict__ v, long long n, uint32_t* __restrict__ blk) {
-    __shared__ uint32_t s_wave[CP_BLOCK / 64];
-    v += (long long)blockIdx.y * n; blk += (size_t)blockIdx.y * gridDim.x;
-    long long base = (long long)blockIdx.x * CP_TILE;
-    uint32_t c = 0;
-    for (int t = 0; t < CP_ITEMS; t++) { long long i = base + t * CP_BLOCK + threadIdx.x; if (i < n && v[i] > 0) c++; }
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) blk[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-}
 
 // single block: exclusive scan of nb block counts (64-bit running sum), total -> out_total
 __global__ __launch_bounds__(1024) void k_cp_scan(const uint32_t* __restrict__ blk, long long nb, unsigned long long* __restrict__ off,
@@ -1460,37 +1447,12 @@ __global__ __launch_bounds__(1024) void k_cp_scan(const uint32_t* __restrict__ b
 }
 
 struct CooOut3 { int32_t* o[3]; unsigned long long total[3]; };       // per matrix: [row | col | val] block and its nnz
-template <class K>
-__global__ __launch_bounds__(CP_BLOCK) void k_cp_scatter(const int32_t* __restrict__ v, const K* __restrict__ k, long long n,
-                                                         KeyLayout<K> kl, const unsigned long long* __restrict__ off, CooOut3 out) {
-    __shared__ uint32_t s_wave[CP_BLOCK / 64];
-    v += (long long)blockIdx.y * n; off += (size_t)blockIdx.y * gridDim.x;
-    int32_t* __restrict__ row = out.o[blockIdx.y]; int32_t* __restrict__ col = row + out.total[blockIdx.y]; int32_t* __restrict__ val = col + out.total[blockIdx.y];
-    long long base = (long long)blockIdx.x * CP_TILE;
-    unsigned long long o = off[blockIdx.x];
-    // blocked arrangement keeps output order == input order
-    long long i0 = base + (long long)threadIdx.x * CP_ITEMS;
-    int32_t loc[CP_ITEMS]; uint32_t c = 0;
-#pragma unroll
-    for (int t = 0; t < CP_ITEMS; t++) { long long i = i0 + t; loc[t] = (i < n) ? v[i] : 0; if (loc[t] > 0) c++; }
-    uint32_t total;
-    uint32_t excl = block_excl_scan(c, s_wave, total);
-    unsigned long long d = o + excl;
-#pragma unroll
-    for (int t = 0; t < CP_ITEMS; t++) {
-        if (loc[t] > 0) {
-            K key = k[i0 + t];
-            row[d] = (int32_t)kl.row(key); col[d] = (int32_t)kl.cell(key); val[d] = loc[t]; d++;
-        }
-    }
-}
-
 // The haplotype matrices straight from the per-run sums: the no_dup_hap arithmetic (baf/fc/core.py:173-192) is done by the count pass
 // and by the scatter pass instead of going through three dense arrays (written once, read twice, 2 x the runs long because the arrays
 // were sized for the keys).  Eight consecutive runs per thread (two 16-byte loads per sum array; `stride` is a multiple of 8 and the
 // arrays are zero beyond the runs, so nothing is bounds-checked per element); tiles beyond the runs leave at once.  One block scan
 // of the three counts packed into one 64-bit word.  Output order = run order = (row, cell) order.
-struct HapSrc { const uint32_t* acc; long long stride; const unsigned long long* n_runs; int no_dup_hap; };
+struct HapSrc { const uint32_t* acc; long long stride; const unsigned long long* n_runs; long long n_fixed; int no_dup_hap; };   // runs: *n_runs, or n_fixed (staging area with holes) when n_runs is null
 __device__ __forceinline__ void hap_load8(const HapSrc& h, long long i0, int32_t (&ad)[CP_ITEMS], int32_t (&dp)[CP_ITEMS], int32_t (&oth)[CP_ITEMS]) {
     static_assert(CP_ITEMS == 8, "two uint4 per array");
     uint32_t a[4][CP_ITEMS];
@@ -1513,7 +1475,7 @@ __device__ __forceinline__ void hap_load8(const HapSrc& h, long long i0, int32_t
 }
 __global__ __launch_bounds__(CP_BLOCK) void k_hap_count(HapSrc h, uint32_t* __restrict__ blk) {
     __shared__ unsigned long long s_w[CP_BLOCK / 64];
-    const long long n = (long long)*h.n_runs, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
+    const long long n = h.n_runs ? (long long)*h.n_runs : h.n_fixed, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
     if ((long long)blockIdx.x * CP_TILE >= n) { if (threadIdx.x < 3) blk[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = 0; return; }
     unsigned long long c = 0;
     if (i0 < n) {
@@ -1531,7 +1493,7 @@ template <class K>
 __global__ __launch_bounds__(CP_BLOCK) void k_hap_scatter(HapSrc h, const K* __restrict__ k, KeyLayout<K> kl, const unsigned long long* __restrict__ off, CooOut3 out) {
     __shared__ unsigned long long s_w[FD_BLOCK / 64];
     static_assert(FD_BLOCK == CP_BLOCK, "block_excl_scan64 is written for FD_BLOCK threads");
-    const long long n = (long long)*h.n_runs, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
+    const long long n = h.n_runs ? (long long)*h.n_runs : h.n_fixed, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
     if ((long long)blockIdx.x * CP_TILE >= n) return;
     int32_t v[3][CP_ITEMS];
     unsigned long long c = 0;
@@ -2101,16 +2063,16 @@ static int sort_run(EngineImpl* im, void* tmp, size_t tmp_bytes, K* kin, K* kout
 
 static int copy_out(EngineImpl* im, int m, int32_t* d_o, size_t total);
 
-// ordered compaction of dense[y][i] > 0 (y = 0..nm-1, arrays n apart) into the COO blocks of matrices m0..m0+nm-1:
-// counts and scans of all matrices first, ONE read-back of the totals, then the scatters and the copy-out
+// ordered compaction of the runs' AD / DP / OTH (hap: per-run sums, n staging entries) into the COO blocks of matrices m0..m0+2:
+// counts and scans of all three first, ONE read-back of the totals, then the scatter and the copy-out
 template <class K>
-static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K* keys, size_t n, KeyLayout<K> kl, int m0, int nm, const HapSrc* hap = nullptr) {
+static int compact_coo(EngineImpl* im, Arena& ws, const HapSrc& hap, const K* keys, size_t n, KeyLayout<K> kl, int m0) {
+    const int nm = 3;
     size_t nb = (n + CP_TILE - 1) / CP_TILE;
     uint32_t* d_blk = ws.get<uint32_t>(nb * nm); unsigned long long* d_off = ws.get<unsigned long long>(nb * nm);
     if (!d_blk || !d_off) { im->eng->err = "workspace exhausted (compaction)"; return XCK_E_NOMEM; }
     unsigned long long* d_tot = im->d_ctl + CTL_X0;                       // the k_expand words are free again at this point
-    if (hap) hipLaunchKernelGGL(k_hap_count, dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, *hap, d_blk);      // (nm == 3: AD, DP, OTH from the per-run sums)
-    else hipLaunchKernelGGL(k_cp_count, dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, (long long)n, d_blk);
+    hipLaunchKernelGGL(k_hap_count, dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, hap, d_blk);
     hipLaunchKernelGGL(k_cp_scan, dim3(nm), dim3(1024), 0, im->s_comp, d_blk, (long long)nb, d_off, d_tot);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)d_tot, im->d_hctl + CTL_X0, nm);
@@ -2128,8 +2090,7 @@ static int compact_coo(EngineImpl* im, Arena& ws, const int32_t* dense, const K*
         any = true;
     }
     if (!any) return 0;
-    if (hap) hipLaunchKernelGGL((k_hap_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, *hap, keys, kl, (const unsigned long long*)d_off, out);
-    else hipLaunchKernelGGL((k_cp_scatter<K>), dim3(nb, nm), dim3(CP_BLOCK), 0, im->s_comp, dense, keys, (long long)n, kl, d_off, out);
+    hipLaunchKernelGGL((k_hap_scatter<K>), dim3(nb), dim3(CP_BLOCK), 0, im->s_comp, hap, keys, kl, (const unsigned long long*)d_off, out);
     HIP_TRY(hipGetLastError());
     // copy-out: large blocks go through copy_out() (copy stream); the small ones share one store kernel into mapped pinned memory
     CopySeg3 sg; memset(&sg, 0, sizeof sg); size_t mx = 0;
@@ -2417,8 +2378,13 @@ static int finish_t(EngineImpl* im) {
             if ((rc = arena_begin(im, im->ws2, (n2s + n2 + 8) * (sizeof(K) + sizeof(V2)) + n2 + 4 * (n2 + 8) * 4 + std::max(tmpb2, part_bytes) + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (n2 / RUN_WALK + 2) * 8 + (1 << 16)))) return rc;
             K* k2 = im->ws2.get<K>(n2s + 8); K* k2b = im->ws2.get<K>(n2); V2* v2 = im->ws2.get<V2>(n2s); V2* v2b = im->ws2.get<V2>(n2);
             uint8_t* cls = im->ws2.get<uint8_t>(n2);
+            const long long stride2 = (long long)((n2 + 7) & ~size_t(7));  // (k_hap_count / k_hap_scatter read eight runs with two 16-byte loads)
+            uint32_t* acc = im->ws2.get<uint32_t>(4 * (size_t)stride2);      // per run: REF-hap, ALT-hap, either, other-only keys
+            if (!k2 || !k2b || !v2 || !v2b || !cls || !acc) { im->eng->err = "workspace exhausted (region-level hits)"; return XCK_E_NOMEM; }
+            HIP_TRY(hipMemsetAsync(acc, 0, 4 * (size_t)stride2 * sizeof(uint32_t), im->s_comp));
+            K* run_key = k2;                                                // (the unsorted keys are dead once they are partitioned / sorted)
             const size_t ws2_mark = im->ws2.off;
-            bool sorted2 = false;
+            bool sorted2 = false, summed2 = false;
             if constexpr (sizeof(K) == 8) {
                 if (try_part) {
                     for (int sh = 0; sh < XSHARD; sh++) xb.base[sh] = (unsigned long long)sh * cap2;
@@ -2426,10 +2392,13 @@ static int finish_t(EngineImpl* im) {
                                        im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
                     HIP_TRY(hipGetLastError());
                     KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
+                    // (XCK_PILEUP_HAP=sorted: sort the items completely and run k_hap_class / k_hap_sum on them, as after the radix sort)
+                    const bool hap_items = !(getenv("XCK_PILEUP_HAP") && !strcmp(getenv("XCK_PILEUP_HAP"), "sorted"));
+                    const HapItemsOut ho{acc, stride2, (unsigned long long*)run_key};
                     rc = pileup_partition_sort(im, im->ws2, false, kl8, (const unsigned long long*)k2, (const uint64_t*)v2, (size_t)cap2, tot2,
-                                               (uint32_t)std::max(im->n_regions, 1), n2, (unsigned long long*)k2b, (uint64_t*)v2b);
+                                               (uint32_t)std::max(im->n_regions, 1), n2, (unsigned long long*)k2b, (uint64_t*)v2b, hap_items ? &ho : nullptr);
                     im->ws2.off = ws2_mark;                                    // (its scratch is free again; the kernels that used it are ordered before the next ones)
-                    if (rc == 0) { sorted2 = true; im->pileup_sort2_path = 1; }
+                    if (rc == 0) { sorted2 = true; summed2 = hap_items; im->pileup_sort2_path = hap_items ? 1 : 3; }
                     else if (rc != PF_FALLBACK) return rc;
                     else {                                                 // the cursors of the emit pass start again
                         for (int sh = 0; sh < XSHARD; sh++) HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_X0 + sh * CTL_STRIDE + 1, 0, sizeof(unsigned long long), im->s_comp));
@@ -2445,25 +2414,24 @@ static int finish_t(EngineImpl* im) {
                 HIP_TRY(hipGetLastError());
                 if ((rc = sort_run<K, V2>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
             }
-            const unsigned gs2 = (unsigned)((n2 + 255) / 256);
-            const size_t nt2 = (n2 + FD_TILE - 1) / FD_TILE;
-            uint32_t* d_blk2 = im->ws2.get<uint32_t>(nt2); unsigned long long* d_off2 = im->ws2.get<unsigned long long>(nt2);
-            const long long stride2 = (long long)((n2 + 7) & ~size_t(7));  // (k_hap_count / k_hap_scatter read eight runs with two 16-byte loads)
-            uint32_t* acc = im->ws2.get<uint32_t>(4 * (size_t)stride2); K* run_key = k2;  // (the unsorted keys are dead after the sort)
-            if (!d_blk2 || !d_off2 || !acc) { im->eng->err = "workspace exhausted (haplotype sums)"; return XCK_E_NOMEM; }
-            HIP_TRY(hipMemsetAsync(acc, 0, 4 * (size_t)stride2 * sizeof(uint32_t), im->s_comp));
-            unsigned long long* long2 = im->ws2.get<unsigned long long>(n2 / (size_t)RUN_WALK + 2);   // [0] = count, then the heads of the (row, cell, UMI) runs longer than RUN_WALK
-            if (!long2) { im->eng->err = "workspace exhausted (haplotype classes)"; return XCK_E_NOMEM; }
-            HIP_TRY(hipMemsetAsync(long2, 0, sizeof(unsigned long long), im->s_comp));
-            hipLaunchKernelGGL((k_hap_class<K, V2>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const V2*)v2b, (long long)n2, cls, long2);
-            hipLaunchKernelGGL((k_hap_class_long<K, V2>), dim3(256), dim3(256), 0, im->s_comp, (const K*)k2b, (const V2*)v2b, (long long)n2, (const unsigned long long*)long2, cls);
-            hipLaunchKernelGGL((k_fold_heads<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (long long)n2, kl, d_blk2);
-            hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk2, (long long)nt2, d_off2, im->d_ctl + CTL_SCRATCH);
-            hipLaunchKernelGGL((k_hap_sum<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (const uint8_t*)cls, (long long)n2, kl,
-                               (const unsigned long long*)d_off2, run_key, acc, stride2);
-            HIP_TRY(hipGetLastError());
-            const HapSrc hs{(const uint32_t*)acc, stride2, (const unsigned long long*)(im->d_ctl + CTL_SCRATCH), im->no_dup_hap};
-            if ((rc = compact_coo<K>(im, im->ws2, (const int32_t*)nullptr, run_key, n2, kl, 1, 3, &hs))) return rc;   // AD, DP, OTH together, from the per-run sums
+            HapSrc hs{(const uint32_t*)acc, stride2, (const unsigned long long*)nullptr, (long long)n2, im->no_dup_hap};   // k_hap_items: runs staged at their items' offsets
+            if (!summed2) {                                                 // sorted keys: classes per (row, cell, UMI) run, sums per (row, cell) run
+                const unsigned gs2 = (unsigned)((n2 + 255) / 256);
+                const size_t nt2 = (n2 + FD_TILE - 1) / FD_TILE;
+                uint32_t* d_blk2 = im->ws2.get<uint32_t>(nt2); unsigned long long* d_off2 = im->ws2.get<unsigned long long>(nt2);
+                unsigned long long* long2 = im->ws2.get<unsigned long long>(n2 / (size_t)RUN_WALK + 2);   // [0] = count, then the heads of the (row, cell, UMI) runs longer than RUN_WALK
+                if (!d_blk2 || !d_off2 || !long2) { im->eng->err = "workspace exhausted (haplotype classes)"; return XCK_E_NOMEM; }
+                HIP_TRY(hipMemsetAsync(long2, 0, sizeof(unsigned long long), im->s_comp));
+                hipLaunchKernelGGL((k_hap_class<K, V2>), dim3(gs2), dim3(256), 0, im->s_comp, (const K*)k2b, (const V2*)v2b, (long long)n2, cls, long2);
+                hipLaunchKernelGGL((k_hap_class_long<K, V2>), dim3(256), dim3(256), 0, im->s_comp, (const K*)k2b, (const V2*)v2b, (long long)n2, (const unsigned long long*)long2, cls);
+                hipLaunchKernelGGL((k_fold_heads<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (long long)n2, kl, d_blk2);
+                hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(1024), 0, im->s_comp, d_blk2, (long long)nt2, d_off2, im->d_ctl + CTL_SCRATCH);
+                hipLaunchKernelGGL((k_hap_sum<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (const uint8_t*)cls, (long long)n2, kl,
+                                   (const unsigned long long*)d_off2, run_key, acc, stride2);
+                HIP_TRY(hipGetLastError());
+                hs.n_runs = (const unsigned long long*)(im->d_ctl + CTL_SCRATCH);
+            }
+            if ((rc = compact_coo<K>(im, im->ws2, hs, run_key, n2, kl, 1))) return rc;   // AD, DP, OTH together, from the per-run sums
         }
         if ((rc = tm.stop(&im->st.ms_sort))) return rc;
     }

@@ -1002,20 +1002,19 @@ __global__ __launch_bounds__(PS_THREADS) void k_pf_sort_items(unsigned long long
 // registers.  Stable, so equal keys keep their order and the padding (~0 keys) stays behind.  ~0.5 MB of LDS traffic per item
 // against the network's 4.3 MB.
 constexpr int RS_THREADS = 512, RS_WAVES = RS_THREADS / 64, RS_EPT = PS_CAP / RS_THREADS, RS_SEG = PS_CAP / RS_WAVES;
-__global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long long* __restrict__ keys, uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off, uint32_t* __restrict__ ctr) {
-    static_assert(RS_EPT * RS_THREADS == PS_CAP && RS_SEG == RS_EPT * 64, "item capacity = threads x elements per thread");
-    __shared__ unsigned long long sk[PS_CAP];
-    __shared__ unsigned long long sv[PS_CAP];
-    __shared__ uint32_t hist[RS_WAVES][256];
-    __shared__ uint32_t s_wtot[4];
-    __shared__ unsigned long long s_diff;
-    const uint32_t off = item_off[blockIdx.x], n = item_off[blockIdx.x + 1] - off;
-    if (n < 2) return;
-    if (n > (uint32_t)PS_CAP) { if (threadIdx.x == 0) ctr[7] = 1u; return; }
+static_assert(RS_EPT * RS_THREADS == PS_CAP && RS_SEG == RS_EPT * 64, "item capacity = threads x elements per thread");
+struct RsShared {
+    unsigned long long sk[PS_CAP];
+    unsigned long long sv[PS_CAP];                                        // (sk + sv = the 4096-slot key table of k_hap_items)
+    uint32_t hist[RS_WAVES][256];                                         // (= the slot payloads of k_hap_items)
+    uint32_t s_wtot[RS_WAVES];
+    unsigned long long s_diff;
+};
+// the item's pairs into registers (padding: ~0), OR of (key ^ first key) over the block -> which digits differ at all
+__device__ __forceinline__ unsigned long long rs_load(RsShared& sm, const unsigned long long* __restrict__ keys, const uint64_t* __restrict__ vals, uint32_t off, uint32_t n,
+                                                      unsigned long long (&key)[RS_EPT], unsigned long long (&val)[RS_EPT]) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
-    const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);   // rounds of this wave that hold anything (wave-uniform)
-    unsigned long long key[RS_EPT], val[RS_EPT];
-    if (threadIdx.x == 0) s_diff = 0;
+    if (threadIdx.x == 0) sm.s_diff = 0;
     const unsigned long long first = keys[off];
     unsigned long long diff = 0;
 #pragma unroll
@@ -1026,62 +1025,175 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
     }
     for (int d = 32; d; d >>= 1) diff |= __shfl_xor(diff, d);
     __syncthreads();
-    if (lane == 0 && diff) atomicOr(&s_diff, diff);
+    if (lane == 0 && diff) atomicOr(&sm.s_diff, diff);
     __syncthreads();
-    diff = s_diff;
+    return sm.s_diff;
+}
+// one stable counting pass on the digit (key >> shift) & 255; the pairs come back in registers in their new order
+__device__ __forceinline__ void rs_pass(RsShared& sm, unsigned long long (&key)[RS_EPT], unsigned long long (&val)[RS_EPT], int shift, int n_rounds) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
+#pragma unroll
+    for (int q = 0; q < 256 / 64; q++) sm.hist[wave][q * 64 + lane] = 0;
+    uint32_t rank[RS_EPT];
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        if (r < n_rounds) {
+            const uint32_t dg = (uint32_t)(key[r] >> shift) & 0xffu;
+            unsigned long long m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; b++) { const bool on = (dg >> b) & 1u; const unsigned long long bal = __ballot(on); m &= on ? bal : ~bal; }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t prev = sm.hist[wave][dg];                      // (the lanes of a group read one word; LDS operations of a wave stay in order)
+            if (below == 0) sm.hist[wave][dg] = prev + (uint32_t)__popcll(m);
+            rank[r] = prev + below;
+        }
+    }
+    __syncthreads();
+    uint32_t c[RS_WAVES], tot = 0, inc = 0;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { c[w] = sm.hist[w][threadIdx.x]; tot += c[w]; }
+        inc = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t; }
+        if (lane == 63) sm.s_wtot[wave] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t base = inc - tot;
+        for (uint32_t w = 0; w < wave; w++) base += sm.s_wtot[w];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { sm.hist[w][threadIdx.x] = base; base += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        if (r < n_rounds) {
+            const uint32_t pos = sm.hist[wave][(uint32_t)(key[r] >> shift) & 0xffu] + rank[r];
+            sm.sk[pos] = key[r]; sm.sv[pos] = val[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        const uint32_t e = e0 + r * 64;
+        if (r < n_rounds) { key[r] = sm.sk[e]; val[r] = sm.sv[e]; }        // (places >= n hold this pass's padding: ~0 again)
+    }
+}
+__global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long long* __restrict__ keys, uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off, uint32_t* __restrict__ ctr) {
+    __shared__ RsShared sm;
+    const uint32_t off = item_off[blockIdx.x], n = item_off[blockIdx.x + 1] - off;
+    if (n < 2) return;
+    if (n > (uint32_t)PS_CAP) { if (threadIdx.x == 0) ctr[7] = 1u; return; }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
+    const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);   // rounds of this wave that hold anything (wave-uniform)
+    unsigned long long key[RS_EPT], val[RS_EPT];
+    const unsigned long long diff = rs_load(sm, keys, vals, off, n, key, val);
     if (!diff) return;                                                    // one key: sorted as it is
     for (int shift = 0; shift < 64; shift += 8) {
         if (!((diff >> shift) & 0xffull)) continue;                       // (block-uniform)
-#pragma unroll
-        for (int q = 0; q < 256 / 64; q++) hist[wave][q * 64 + lane] = 0;
-        uint32_t rank[RS_EPT];
-#pragma unroll
-        for (int r = 0; r < RS_EPT; r++) {
-            if (r < n_rounds) {
-                const uint32_t dg = (uint32_t)(key[r] >> shift) & 0xffu;
-                unsigned long long m = ~0ull;
-#pragma unroll
-                for (int b = 0; b < 8; b++) { const bool on = (dg >> b) & 1u; const unsigned long long bal = __ballot(on); m &= on ? bal : ~bal; }
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t prev = hist[wave][dg];                     // (the lanes of a group read one word; LDS operations of a wave stay in order)
-                if (below == 0) hist[wave][dg] = prev + (uint32_t)__popcll(m);
-                rank[r] = prev + below;
-            }
-        }
-        __syncthreads();
-        uint32_t c[RS_WAVES], tot = 0, inc = 0;
-        if (threadIdx.x < 256) {
-#pragma unroll
-            for (int w = 0; w < RS_WAVES; w++) { c[w] = hist[w][threadIdx.x]; tot += c[w]; }
-            inc = tot;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t; }
-            if (lane == 63) s_wtot[wave] = inc;
-        }
-        __syncthreads();
-        if (threadIdx.x < 256) {
-            uint32_t base = inc - tot;
-            for (uint32_t w = 0; w < wave; w++) base += s_wtot[w];
-#pragma unroll
-            for (int w = 0; w < RS_WAVES; w++) { hist[w][threadIdx.x] = base; base += c[w]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RS_EPT; r++) {
-            if (r < n_rounds) {
-                const uint32_t pos = hist[wave][(uint32_t)(key[r] >> shift) & 0xffu] + rank[r];
-                sk[pos] = key[r]; sv[pos] = val[r];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RS_EPT; r++) {
-            const uint32_t e = e0 + r * 64;
-            if (r < n_rounds) { key[r] = sk[e]; val[r] = sv[e]; }          // (places >= n hold this pass's padding: ~0 again)
-        }
+        rs_pass(sm, key, val, shift, n_rounds);
     }
 #pragma unroll
     for (int r = 0; r < RS_EPT; r++) { const uint32_t e = e0 + r * 64; if (e < n) { keys[off + e] = key[r]; vals[off + e] = val[r]; } }
+}
+
+// Region-level hits of the pileup (key = region | cell | UMI, value = haplotype bits 1 REF / 2 ALT / 4 other): the items of the
+// partition are NOT sorted by UMI.  Per item: (1) the radix passes above on the (region, cell) digits only (one pass where an item is
+// one hot region, three where it is many cold ones) - the (region, cell) runs are now contiguous and in order; (2) run numbers from
+// head flags; (3) every key into an LDS hash set (sized to the item, load <= 0.5) whose slot payload collects run number | OR of the
+// key's haplotype bits - the set algebra of baf/fc/core.py:173-192 per molecule, however many SNPs it meets; (4) a sweep over the
+// slots adds each molecule's class to its run's four packed counters (REF-hap, ALT-hap, either, other-only keys); (5) the run's
+// head key and its four sums go to run_key / acc at [item offset + run number] - a staging area with holes (an item has fewer runs
+// than keys), zero where nothing is written; k_hap_count / k_hap_scatter skip the holes.  Replaces the UMI digits of the sort,
+// k_hap_class (+ _long), k_fold_heads and k_hap_sum of the sorted path.
+struct HapItemsOut { uint32_t* acc; long long stride; unsigned long long* run_key; };
+__global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long long* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off,
+                                                          int ubits, HapItemsOut out, uint32_t* __restrict__ ctr) {
+    __shared__ RsShared sm;
+    __shared__ unsigned long long cnt[PS_CAP];                            // per run: 4 x 16-bit counters (an item holds at most 2048 keys)
+    __shared__ uint32_t s_wheads[RS_WAVES];
+    __shared__ uint32_t s_ff;                                             // the one key that equals the table's "empty" word
+    const uint32_t off = item_off[blockIdx.x], n = item_off[blockIdx.x + 1] - off;
+    if (n == 0) return;
+    if (n > (uint32_t)PS_CAP) { if (threadIdx.x == 0) ctr[7] = 1u; return; }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
+    const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);
+    unsigned long long key[RS_EPT], val[RS_EPT];
+    const unsigned long long diff = rs_load(sm, keys, vals, off, n, key, val);
+    for (int shift = ubits; shift < 64; shift += 8) {
+        if (!((diff >> shift) & 0xffull)) continue;
+        rs_pass(sm, key, val, shift, n_rounds);
+    }
+    // (2) heads of the (region, cell) runs, run numbers in element order
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) { const uint32_t e = e0 + r * 64; if (e < n) sm.sk[e] = key[r]; }
+    __syncthreads();
+    uint32_t runid[RS_EPT], heads_w = 0;
+    bool head[RS_EPT];
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        const uint32_t e = e0 + r * 64;
+        head[r] = e < n && (e == 0 || (sm.sk[e - 1] >> ubits) != (key[r] >> ubits));
+        const unsigned long long bal = __ballot(head[r]);
+        runid[r] = heads_w + (uint32_t)__popcll(bal & ((2ull << lane) - 1ull));      // heads up to and including me, inside this wave
+        heads_w += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) s_wheads[wave] = heads_w;
+    if (threadIdx.x == 0) s_ff = 0;
+    __syncthreads();
+    uint32_t wbase = 0, n_runs = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; w++) { const uint32_t t = s_wheads[w]; if ((uint32_t)w < wave) wbase += t; n_runs += t; }
+    int lg_slots = 8; while ((1u << lg_slots) < 2 * n) lg_slots++;        // <= 4096 = sk + sv
+    const uint32_t smask = (1u << lg_slots) - 1u;
+    unsigned long long* __restrict__ tab = sm.sk;
+    uint32_t* __restrict__ pay = &sm.hist[0][0];                          // 16 bits per slot: run number << 3 | haplotype bits (0 = empty)
+    for (uint32_t q = threadIdx.x; q <= smask; q += RS_THREADS) tab[q] = ~0ull;
+    for (uint32_t q = threadIdx.x; q <= (smask >> 1); q += RS_THREADS) pay[q] = 0u;
+    for (uint32_t q = threadIdx.x; q < n_runs; q += RS_THREADS) cnt[q] = 0ull;
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        runid[r] = wbase + runid[r] - 1u;
+        if (head[r]) out.run_key[(size_t)off + runid[r]] = key[r];
+    }
+    __syncthreads();
+    // (3) molecules: hash set on the whole key, payload OR
+#pragma unroll
+    for (int r = 0; r < RS_EPT; r++) {
+        const uint32_t e = e0 + r * 64;
+        if (e >= n) continue;
+        const uint32_t p = (runid[r] << 3) | ((uint32_t)val[r] & 7u);
+        if (key[r] == ~0ull) { atomicOr(&s_ff, 0x80000000u | p); continue; }
+        uint32_t slot = set_slot<PF_SLOTS>(key[r]) & smask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&tab[slot], ~0ull, key[r]);
+            if (prev == ~0ull || prev == key[r]) break;
+            slot = (slot + 1) & smask;
+        }
+        atomicOr(&pay[slot >> 1], p << ((slot & 1u) * 16));
+    }
+    __syncthreads();
+    // (4) classes -> run counters
+    auto add_class = [&](uint32_t p) {
+        const uint32_t bits = p & 7u, run = (p >> 3) & 0x7ffu;
+        const unsigned long long c = (unsigned long long)(bits & 1u) | ((unsigned long long)((bits >> 1) & 1u) << 16) | ((unsigned long long)((bits & 3u) ? 1u : 0u) << 32)
+                                   | ((unsigned long long)((!(bits & 3u) && (bits & 4u)) ? 1u : 0u) << 48);
+        atomicAdd(&cnt[run], c);
+    };
+    for (uint32_t q = threadIdx.x; q <= smask; q += RS_THREADS) {
+        const uint32_t p = (pay[q >> 1] >> ((q & 1u) * 16)) & 0xffffu;
+        if (p) add_class(p);
+    }
+    if (threadIdx.x == 0 && s_ff) add_class(s_ff & 0xffffu);
+    __syncthreads();
+    // (5) the runs of this item
+    for (uint32_t q = threadIdx.x; q < n_runs; q += RS_THREADS) {
+        const unsigned long long c = cnt[q];
+#pragma unroll
+        for (int f = 0; f < 4; f++) { const uint32_t v = (uint32_t)(c >> (16 * f)) & 0xffffu; if (v) out.acc[(size_t)f * out.stride + off + q] = v; }
+    }
 }
 
 // (key, value) pairs in 16 slices (slice sh = src[sh * cap .. + cnt[sh]); the slices filled round-robin by the blocks of a kernel that walks
@@ -1090,7 +1202,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
 // Cells as in the basefc fold: every row gets 2^l cell groups so that a group holds about C / 2 hits (a SNP in a hot gene is tens of
 // thousands of reads deep); the groups of a row are in cell order, so cell order = key order.  0 = done, PF_FALLBACK = use the radix
 // sort (the source slices are untouched either way), < 0 = error.  Scratch: `ar`, begun here when `own_arena`, else reserved by the
-// caller (partition_sort_scratch()).
+// caller (partition_sort_scratch()).  With `hap` the items are not sorted: k_hap_items classifies them in place (region-level hits).
 struct PartSortSizes { size_t rs, z_cap, zs_cap, wi_cap, sb, bytes; };
 static PartSortSizes partition_sort_sizes(size_t n, size_t n_rows, int lgC) {
     PartSortSizes q;
@@ -1104,7 +1216,8 @@ static PartSortSizes partition_sort_sizes(size_t n, size_t n_rows, int lgC) {
 static int partition_sort_lgC() { int lgC = 0; const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; return lgC; }
 static size_t partition_sort_scratch(size_t n, size_t n_rows) { return partition_sort_sizes(n, n_rows, partition_sort_lgC()).bytes; }
 static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyLayout<unsigned long long> kl, const unsigned long long* src_keys, const uint64_t* src_vals,
-                                 size_t src_cap, const unsigned long long* src_cnt, uint32_t n_rows, size_t n, unsigned long long* out_keys, uint64_t* out_vals) {
+                                 size_t src_cap, const unsigned long long* src_cnt, uint32_t n_rows, size_t n, unsigned long long* out_keys, uint64_t* out_vals,
+                                 const HapItemsOut* hap = nullptr) {
     typedef unsigned long long K;
     if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;
     const int lgC = partition_sort_lgC();
@@ -1165,7 +1278,8 @@ static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyL
     hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)src_keys, sc, bc0, g, 0, S, out_keys, src_vals, out_vals);
     const bool bitonic = getenv("XCK_PILEUP_ITEM_SORT") && !strcmp(getenv("XCK_PILEUP_ITEM_SORT"), "bitonic");
-    if (bitonic) hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
+    if (hap) hipLaunchKernelGGL(k_hap_items, dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, (const unsigned long long*)out_keys, (const uint64_t*)out_vals, (const uint32_t*)item_off, kl.ubits, *hap, ctr);
+    else if (bitonic) hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     else hipLaunchKernelGGL(k_pf_radix_items, dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pf_publish, dim3(1), dim3(64), 0, im->s_comp, (const uint32_t*)ctr, d_hctr, 16);

@@ -75,8 +75,10 @@ inline int bits_for_count(int64_t n) { int b = 1; while ((int64_t(1) << b) < n) 
 inline KeyBits key_layout(const xck_config* cfg) {
     KeyBits k;
     k.cbits = bits_for_count(cfg->n_cells > 2 ? cfg->n_cells : 2);
-    k.rbits = bits_for_count(cfg->n_regions > 2 ? cfg->n_regions : 2);
-    if ((cfg->mode & XCK_MODE_BAF) || (cfg->flags & XCK_F_LAYOUT_BOTH)) { int sb = bits_for_count(cfg->n_snps > 2 ? cfg->n_snps : 2); if (sb > k.rbits) k.rbits = sb; }
+    // (rows are sized for one more than there are: the row field is then never all ones, so no key equals ~0 - the "empty" word of the
+    // LDS hash sets of the folds - whatever the cell and UMI fields hold)
+    k.rbits = bits_for_count((int64_t)(cfg->n_regions > 2 ? cfg->n_regions : 2) + 1);
+    if ((cfg->mode & XCK_MODE_BAF) || (cfg->flags & XCK_F_LAYOUT_BOTH)) { int sb = bits_for_count((int64_t)(cfg->n_snps > 2 ? cfg->n_snps : 2) + 1); if (sb > k.rbits) k.rbits = sb; }
     int ub = 64 - k.rbits - k.cbits;
     if ((cfg->flags & XCK_F_FORCE_KEY128) || ub < 26) { k.key_bits = 128; k.ubits = 64; }
     else { k.key_bits = 64; k.ubits = ub; }
