@@ -725,7 +725,9 @@ def device_resident(args, names, regions, snps, dev_idx, device, log):
                     pipeline="serial: basefc pass then pileup pass, matrices copied out to pinned host memory inside the pass",
                     stage_ms_per_pass={a: round(b, 3) for a, b in k.items()},
                     nnz={m: int(len(res[m][0])) for m in ("count", "ad", "dp", "oth")},
-                    hits=dict(basefc=int(hits_fc), pileup=int(hits_baf), basefc_after_lds_dedup=int(sfc["n_hits_unique"]), pileup_after_lds_dedup=int(sbaf["n_hits_unique"])))
+                    hits=dict(basefc=int(hits_fc), pileup=int(hits_baf), basefc_after_lds_dedup=int(sfc["n_hits_unique"]), pileup_after_lds_dedup=int(sbaf["n_hits_unique"])),
+                    # which fold ran (include/xck.h xck_stats): 1 = the sort-free partition paths, 2 = the radix-sort fallbacks
+                    fold_paths=dict(basefc=int(sfc.get("fold_path", 0)), pileup_hits=int(sbaf.get("pileup_sort_path", 0)), pileup_region_level=int(sbaf.get("pileup_sort2_path", 0))))
     log("resident: %.2f ms/pass %s" % (dt * 1e3, resident["stage_ms_per_pass"]))
     eng_fc.close(); eng_baf.close()
     return resident, roofline

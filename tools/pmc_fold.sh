@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass as the MI355X guide prescribes) of the fold kernels on the
+# HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass as the MI355X guide prescribes) of this library's kernels (joins, both folds) on the
 # HBM-resident form of configs[2].  usage: tools/pmc_fold.sh OUTDIR -> OUTDIR/pmc_fold_summary.txt
 out=$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -14,7 +14,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(out + '/' + ctr + '/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if not any(x in k for x in ('k_pf_', 'k_join', 'k_scan')) or r['Counter_Name'] != ctr: continue
+            if 'xck::' not in k or r['Counter_Name'] != ctr: continue
             name = k.split('(')[0].replace('void xck::', '').replace('xck::', '') + ' grid=' + r['Grid_Size']
             d = int(r['Dispatch_Id'])
             if ctr not in last[name] or d > last[name][ctr][0]: last[name][ctr] = (d, float(r['Counter_Value']))
