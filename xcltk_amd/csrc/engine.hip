@@ -1135,7 +1135,8 @@ template <class K>
 __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp, unsigned long long n_units,
                                                  const K* __restrict__ keys, KeyLayout<K> kl, const unsigned long long* __restrict__ row_lo, const unsigned long long* __restrict__ row_hi,
                                                  const uint64_t* __restrict__ ord, uint8_t* __restrict__ al,
-                                                 const unsigned long long* __restrict__ bloom, const unsigned long long* __restrict__ blk_lo, uint32_t n_rows) {
+                                                 const unsigned long long* __restrict__ bloom, const unsigned long long* __restrict__ blk_lo, uint32_t n_rows,
+                                                 const uint32_t* __restrict__ p_rowtab, const uint32_t* __restrict__ p_end) {
     const int low = kl.cbits + kl.ubits;
     // unit u = records [256 * (u / NSHARD), + 256) of shard slice u % NSHARD: the slices are filled round-robin by consecutive join
     // tiles, so the blocks in flight together hold ONE narrow position range of the file (and one window of the Bloom table)
@@ -1144,8 +1145,8 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
         const unsigned long long idx = (u / NSHARD) * 256 + threadIdx.x;
         if (idx >= sp.start[sh + 1] - sp.start[sh]) continue;
         const unsigned long long j = (unsigned long long)sh * cap + idx;
-        const K rec = nk[j];
-        const uint64_t v = nv[j];
+        const K rec = __builtin_nontemporal_load(&nk[j]);               // (read once: keep the L2 for the table window and the key look-ups)
+        const uint64_t v = __builtin_nontemporal_load(&nv[j]);
         const uint64_t ordn = v >> ALLELE_BITS;
         const uint32_t k1 = kl.row(rec), k2 = min(k1 + (uint32_t)(v & ((1u << ALLELE_BITS) - 1)) + 1u, n_rows);
         const K cellumi = rec & ((K(1) << low) - 1);
@@ -1161,7 +1162,14 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
             while (m) {                                                 // SNPs at which this molecule (or one that shares both words) shows a base
                 const uint32_t srow = (blk << 5) + (uint32_t)__builtin_ctz(m);
                 m &= m - 1;
-                unsigned long long lo = row_lo[srow], hi = row_hi[srow];
+                // the key's place: inside its (SNP, cell group) cell of the partition sort where there was one (<= 2048 entries: ~9 probes
+                // on a few lines; a hot SNP's whole range is 100 k entries, 17 probes on 17 lines - 5.5 GB of HBM reads per pass), else
+                // inside the SNP's range
+                unsigned long long lo, hi;
+                if (p_rowtab) {
+                    const uint32_t t = p_rowtab[srow], z = (t >> 5) + ((uint32_t)((unsigned long long)cellumi >> kl.ubits) >> (t & 31u));
+                    lo = z ? p_end[z - 1] : 0u; hi = p_end[z];
+                } else { lo = row_lo[srow]; hi = row_hi[srow]; }
                 if (lo >= hi) continue;
                 const unsigned long long end = hi;
                 const K key = (K(srow) << low) | cellumi;
@@ -1452,15 +1460,27 @@ struct CooOut3 { int32_t* o[3]; unsigned long long total[3]; };       // per mat
 // were sized for the keys).  Eight consecutive runs per thread (two 16-byte loads per sum array; `stride` is a multiple of 8 and the
 // arrays are zero beyond the runs, so nothing is bounds-checked per element); tiles beyond the runs leave at once.  One block scan
 // of the three counts packed into one 64-bit word.  Output order = run order = (row, cell) order.
-struct HapSrc { const uint32_t* acc; long long stride; const unsigned long long* n_runs; long long n_fixed; int no_dup_hap; };   // runs: *n_runs, or n_fixed (staging area with holes) when n_runs is null
+struct HapSrc { const uint32_t* acc; long long stride; const unsigned long long* n_runs; long long n_fixed; int no_dup_hap; const unsigned long long* packed; };
+// runs: *n_runs, or n_fixed (staging area with holes) when n_runs is null.  packed != null: the four sums of a run as 4 x 16 bits of one
+// word (k_hap_items: an item holds at most 2048 keys), instead of the four 32-bit arrays `acc` (k_hap_sum: a run can be millions of keys)
 __device__ __forceinline__ void hap_load8(const HapSrc& h, long long i0, int32_t (&ad)[CP_ITEMS], int32_t (&dp)[CP_ITEMS], int32_t (&oth)[CP_ITEMS]) {
     static_assert(CP_ITEMS == 8, "two uint4 per array");
     uint32_t a[4][CP_ITEMS];
+    if (h.packed) {
+        const uint4* p = reinterpret_cast<const uint4*>(h.packed + i0);
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
-        const uint4* p = reinterpret_cast<const uint4*>(h.acc + (size_t)f * h.stride + i0);
-        const uint4 x = p[0], y = p[1];
-        a[f][0] = x.x; a[f][1] = x.y; a[f][2] = x.z; a[f][3] = x.w; a[f][4] = y.x; a[f][5] = y.y; a[f][6] = y.z; a[f][7] = y.w;
+        for (int q = 0; q < 4; q++) {
+            const uint4 x = p[q];
+            a[0][2 * q] = x.x & 0xffffu; a[1][2 * q] = x.x >> 16; a[2][2 * q] = x.y & 0xffffu; a[3][2 * q] = x.y >> 16;
+            a[0][2 * q + 1] = x.z & 0xffffu; a[1][2 * q + 1] = x.z >> 16; a[2][2 * q + 1] = x.w & 0xffffu; a[3][2 * q + 1] = x.w >> 16;
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const uint4* p = reinterpret_cast<const uint4*>(h.acc + (size_t)f * h.stride + i0);
+            const uint4 x = p[0], y = p[1];
+            a[f][0] = x.x; a[f][1] = x.y; a[f][2] = x.z; a[f][3] = x.w; a[f][4] = y.x; a[f][5] = y.y; a[f][6] = y.z; a[f][7] = y.w;
+        }
     }
 #pragma unroll
     for (int t = 0; t < CP_ITEMS; t++) {
@@ -2290,6 +2310,7 @@ static int finish_t(EngineImpl* im) {
         // the hits sorted by (key, value): by row partition + one LDS sort per item (fold_partition.h); a SNP deeper than an item, or
         // 128-bit keys, take the radix sort
         bool sorted = false;
+        PartIndex pidx{nullptr, nullptr};                                    // the partition's cells, for k_claim's look-ups (stays null after the radix sort)
         if constexpr (sizeof(K) == 8) {
             // (default since the items are sorted by an LDS radix sort: 1.7 ms at configs[2] against 2.3 ms for pack + rocPRIM's eight passes;
             // XCK_PILEUP_SORT=radix forces the library sort)
@@ -2297,7 +2318,7 @@ static int finish_t(EngineImpl* im) {
             if (want_part) {
                 KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
                 rc = pileup_partition_sort(im, im->ws2, true, kl8, (const unsigned long long*)im->d_keys, (const uint64_t*)im->d_vals, im->hit_cap, im->cur,
-                                           (uint32_t)std::max(im->n_snps_sorted, 1), n, (unsigned long long*)alt, valt);
+                                           (uint32_t)std::max(im->n_snps_sorted, 1), n, (unsigned long long*)alt, valt, nullptr, &pidx);
                 if (rc == 0) { sorted = true; im->pileup_sort_path = 1; }
                 else if (rc != PF_FALLBACK) return rc;
             }
@@ -2335,10 +2356,12 @@ static int finish_t(EngineImpl* im) {
                 ShardSpan nsp; nsp.start[0] = 0; unsigned long long mx = 0;
                 for (int sh = 0; sh < NSHARD; sh++) { nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh]; mx = std::max(mx, im->ncur[sh]); }
                 const unsigned long long n_units = ((mx + 255) / 256) * NSHARD;
-                hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<unsigned long long>(n_units, 16384)), dim3(256), 0, im->s_comp,
+                // (one block per unit: blocks start in index order, so the resident ones hold consecutive units = ONE window of the table; a grid-stride
+                // loop over 16 k blocks mixed up to 11 windows and every probe went to HBM: 5.5 GB read for 0.74 GB of records)
+                hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<unsigned long long>(n_units, 1ull << 30)), dim3(256), 0, im->s_comp,
                                    (const K*)im->d_nkeys, (const uint64_t*)im->d_nvals, (unsigned long long)im->hit_cap, nsp, n_units,
                                    (const K*)alt, kl, (const unsigned long long*)row_lo, (const unsigned long long*)row_hi, (const uint64_t*)ordv, al,
-                                   (const unsigned long long*)bloom, (const unsigned long long*)blk_lo, (uint32_t)ns);
+                                   (const unsigned long long*)bloom, (const unsigned long long*)blk_lo, (uint32_t)ns, pidx.rowtab, pidx.end);
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipMemsetAsync(long_runs, 0, sizeof(unsigned long long), im->s_comp));   // (k_first_long is done with the list: now the SNPs deeper than TALLY_LONG)
@@ -2381,7 +2404,7 @@ static int finish_t(EngineImpl* im) {
             const long long stride2 = (long long)((n2 + 7) & ~size_t(7));  // (k_hap_count / k_hap_scatter read eight runs with two 16-byte loads)
             uint32_t* acc = im->ws2.get<uint32_t>(4 * (size_t)stride2);      // per run: REF-hap, ALT-hap, either, other-only keys
             if (!k2 || !k2b || !v2 || !v2b || !cls || !acc) { im->eng->err = "workspace exhausted (region-level hits)"; return XCK_E_NOMEM; }
-            HIP_TRY(hipMemsetAsync(acc, 0, 4 * (size_t)stride2 * sizeof(uint32_t), im->s_comp));
+            HIP_TRY(hipMemsetAsync(acc, 0, 2 * (size_t)stride2 * sizeof(uint32_t), im->s_comp));   // (the half that k_hap_items' packed sums use; the rest below, if k_hap_sum runs)
             K* run_key = k2;                                                // (the unsorted keys are dead once they are partitioned / sorted)
             const size_t ws2_mark = im->ws2.off;
             bool sorted2 = false, summed2 = false;
@@ -2394,7 +2417,7 @@ static int finish_t(EngineImpl* im) {
                     KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
                     // (XCK_PILEUP_HAP=sorted: sort the items completely and run k_hap_class / k_hap_sum on them, as after the radix sort)
                     const bool hap_items = !(getenv("XCK_PILEUP_HAP") && !strcmp(getenv("XCK_PILEUP_HAP"), "sorted"));
-                    const HapItemsOut ho{acc, stride2, (unsigned long long*)run_key};
+                    const HapItemsOut ho{(unsigned long long*)acc, (unsigned long long*)run_key};   // (the packed sums use the first half of acc)
                     rc = pileup_partition_sort(im, im->ws2, false, kl8, (const unsigned long long*)k2, (const uint64_t*)v2, (size_t)cap2, tot2,
                                                (uint32_t)std::max(im->n_regions, 1), n2, (unsigned long long*)k2b, (uint64_t*)v2b, hap_items ? &ho : nullptr);
                     im->ws2.off = ws2_mark;                                    // (its scratch is free again; the kernels that used it are ordered before the next ones)
@@ -2414,8 +2437,9 @@ static int finish_t(EngineImpl* im) {
                 HIP_TRY(hipGetLastError());
                 if ((rc = sort_run<K, V2>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
             }
-            HapSrc hs{(const uint32_t*)acc, stride2, (const unsigned long long*)nullptr, (long long)n2, im->no_dup_hap};   // k_hap_items: runs staged at their items' offsets
+            HapSrc hs{(const uint32_t*)acc, stride2, (const unsigned long long*)nullptr, (long long)n2, im->no_dup_hap, (const unsigned long long*)acc};   // k_hap_items: runs staged (packed) at their items' offsets
             if (!summed2) {                                                 // sorted keys: classes per (row, cell, UMI) run, sums per (row, cell) run
+                HIP_TRY(hipMemsetAsync(acc + 2 * (size_t)stride2, 0, 2 * (size_t)stride2 * sizeof(uint32_t), im->s_comp));
                 const unsigned gs2 = (unsigned)((n2 + 255) / 256);
                 const size_t nt2 = (n2 + FD_TILE - 1) / FD_TILE;
                 uint32_t* d_blk2 = im->ws2.get<uint32_t>(nt2); unsigned long long* d_off2 = im->ws2.get<unsigned long long>(nt2);
@@ -2429,7 +2453,7 @@ static int finish_t(EngineImpl* im) {
                 hipLaunchKernelGGL((k_hap_sum<K>), dim3((unsigned)nt2), dim3(FD_BLOCK), 0, im->s_comp, (const K*)k2b, (const uint8_t*)cls, (long long)n2, kl,
                                    (const unsigned long long*)d_off2, run_key, acc, stride2);
                 HIP_TRY(hipGetLastError());
-                hs.n_runs = (const unsigned long long*)(im->d_ctl + CTL_SCRATCH);
+                hs.n_runs = (const unsigned long long*)(im->d_ctl + CTL_SCRATCH); hs.packed = nullptr;
             }
             if ((rc = compact_coo<K>(im, im->ws2, hs, run_key, n2, kl, 1))) return rc;   // AD, DP, OTH together, from the per-run sums
         }

@@ -995,8 +995,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_pf_sort_items(unsigned long long
 }
 
 // The same items sorted by an LSD radix sort in LDS (default; XCK_PILEUP_ITEM_SORT=bitonic keeps the network above).  512 threads, four
-// pairs per thread held in REGISTERS between the passes; element e = wave * 256 + round * 64 + lane.  One pass per 8-bit digit in which
-// the item's keys differ at all (an item spans 2^14 (SNP, cell) pairs: ~5 of the 8 digits): every wave ranks its 256 elements round by
+// pairs per thread held in REGISTERS between the passes; element e = wave * 256 + round * 64 + lane.  One pass per 8-bit window of key
+// bits in which the item's keys differ at all (4 windows where an item is one hot SNP, ~6 where it is many cold ones): every wave ranks its 256 elements round by
 // round with ballots (lanes of equal digit: eight ballots; rank = the wave's running count of the digit + lanes of the group below me),
 // the 8 x 256 wave counts are scanned digit-major, and the pairs go through ONE LDS buffer to their new places and back into
 // registers.  Stable, so equal keys keep their order and the padding (~0 keys) stays behind.  ~0.5 MB of LDS traffic per item
@@ -1090,9 +1090,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
     unsigned long long key[RS_EPT], val[RS_EPT];
     const unsigned long long diff = rs_load(sm, keys, vals, off, n, key, val);
     if (!diff) return;                                                    // one key: sorted as it is
-    for (int shift = 0; shift < 64; shift += 8) {
-        if (!((diff >> shift) & 0xffull)) continue;                       // (block-uniform)
+    // 8-bit windows that start at the lowest differing bit not yet sorted on (block-uniform): an item of one hot SNP differs in the
+    // 24 UMI bits in use and in 4 cell bits six bits further up - 4 windows, where windows at multiples of 8 take 5
+    for (unsigned long long rem = diff; rem; ) {
+        const int shift = __builtin_ctzll(rem);
         rs_pass(sm, key, val, shift, n_rounds);
+        rem = shift >= 56 ? 0ull : rem & ~(0xffull << shift);
     }
 #pragma unroll
     for (int r = 0; r < RS_EPT; r++) { const uint32_t e = e0 + r * 64; if (e < n) { keys[off + e] = key[r]; vals[off + e] = val[r]; } }
@@ -1104,10 +1107,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
 // head flags; (3) every key into an LDS hash set (sized to the item, load <= 0.5) whose slot payload collects run number | OR of the
 // key's haplotype bits - the set algebra of baf/fc/core.py:173-192 per molecule, however many SNPs it meets; (4) a sweep over the
 // slots adds each molecule's class to its run's four packed counters (REF-hap, ALT-hap, either, other-only keys); (5) the run's
-// head key and its four sums go to run_key / acc at [item offset + run number] - a staging area with holes (an item has fewer runs
+// head key and its four sums (one packed word) go to run_key / sums at [item offset + run number] - a staging area with holes (an item has fewer runs
 // than keys), zero where nothing is written; k_hap_count / k_hap_scatter skip the holes.  Replaces the UMI digits of the sort,
 // k_hap_class (+ _long), k_fold_heads and k_hap_sum of the sorted path.
-struct HapItemsOut { uint32_t* acc; long long stride; unsigned long long* run_key; };
+struct HapItemsOut { unsigned long long* sums; unsigned long long* run_key; };   // per staging entry: 4 x 16-bit sums in one word (zero = hole), the run's head key
+// what a finished partition sort leaves behind for look-ups by key: cell z of (row, cell) = (rowtab[row] >> 5) + (cell >> (rowtab[row] & 31)),
+// its entries in the sorted output = [z ? end[z - 1] : 0, end[z]) (k_pf_part turned the scanned counts into end offsets).  Lives in the
+// sort's scratch arena: valid until that arena is begun again.
+struct PartIndex { const uint32_t* rowtab; const uint32_t* end; };
 __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long long* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off,
                                                           int ubits, HapItemsOut out, uint32_t* __restrict__ ctr) {
     __shared__ RsShared sm;
@@ -1121,9 +1128,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
     const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);
     unsigned long long key[RS_EPT], val[RS_EPT];
     const unsigned long long diff = rs_load(sm, keys, vals, off, n, key, val);
-    for (int shift = ubits; shift < 64; shift += 8) {
-        if (!((diff >> shift) & 0xffull)) continue;
+    for (unsigned long long rem = (diff >> ubits) << ubits; rem; ) {      // windows from the lowest differing (region, cell) bit upwards
+        const int shift = __builtin_ctzll(rem);
         rs_pass(sm, key, val, shift, n_rounds);
+        rem = shift >= 56 ? 0ull : rem & ~(0xffull << shift);
     }
     // (2) heads of the (region, cell) runs, run numbers in element order
     __syncthreads();
@@ -1190,9 +1198,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
     __syncthreads();
     // (5) the runs of this item
     for (uint32_t q = threadIdx.x; q < n_runs; q += RS_THREADS) {
-        const unsigned long long c = cnt[q];
-#pragma unroll
-        for (int f = 0; f < 4; f++) { const uint32_t v = (uint32_t)(c >> (16 * f)) & 0xffffu; if (v) out.acc[(size_t)f * out.stride + off + q] = v; }
+        out.sums[(size_t)off + q] = cnt[q];
     }
 }
 
@@ -1217,7 +1223,7 @@ static int partition_sort_lgC() { int lgC = 0; const int c = pf_env_int("XCK_FOL
 static size_t partition_sort_scratch(size_t n, size_t n_rows) { return partition_sort_sizes(n, n_rows, partition_sort_lgC()).bytes; }
 static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyLayout<unsigned long long> kl, const unsigned long long* src_keys, const uint64_t* src_vals,
                                  size_t src_cap, const unsigned long long* src_cnt, uint32_t n_rows, size_t n, unsigned long long* out_keys, uint64_t* out_vals,
-                                 const HapItemsOut* hap = nullptr) {
+                                 const HapItemsOut* hap = nullptr, PartIndex* index = nullptr) {
     typedef unsigned long long K;
     if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;
     const int lgC = partition_sort_lgC();
@@ -1286,6 +1292,7 @@ static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyL
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     if (h_ctr[7]) { im->eng->err = "internal: a pileup item exceeds its capacity"; return XCK_E_STATE; }
+    if (index) { index->rowtab = rowtab; index->end = S; }
     if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] pileup partition sort: n=%zu snps=%u cells=%u items=%zu C=%d\n", n, n_rows, Z, n_items, 1 << lgC);
     return 0;
 }
