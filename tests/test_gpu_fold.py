@@ -158,12 +158,15 @@ def test_pileup_hits_sorted_by_partition_equal_the_radix_sort(fold_env):
             util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
             assert st["pileup_sort_path"] in (1, 2)
     fold_env.pop("XCK_PILEUP_ITEM_SORT")
-    fold_env["XCK_PILEUP_HAP"] = "sorted"               # region-level items sorted completely + k_hap_class / k_hap_sum, instead of k_hap_items
-    for page in ("1024", "8"):
-        fold_env["XCK_FOLD_C"] = page
-        got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
-        util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
-        assert st["pileup_sort2_path"] in (3, 2)
+    # region-level items: "values" = the haplotype class in a value word beside the key (default: in two free bits of the UMI field);
+    # "sorted" = items sorted completely + k_hap_class / k_hap_sum, instead of k_hap_items
+    for hap, paths in (("values", (1, 2)), ("sorted", (3, 2))):
+        fold_env["XCK_PILEUP_HAP"] = hap
+        for page in ("1024", "8"):
+            fold_env["XCK_FOLD_C"] = page
+            got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)
+            util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
+            assert st["pileup_sort2_path"] in paths
     fold_env.pop("XCK_FOLD_C"); fold_env.pop("XCK_PILEUP_HAP")
     fold_env["XCK_PILEUP_SORT"] = "radix"
     got, _, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 300, batches)

@@ -763,6 +763,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
                 for (uint32_t u = tid; u < cx_n; u += JOIN_BLOCK)
                     n_gap += pileup_complex<K, MODE>(a, d, sm, sm.cx_pos[u], sm.cx_end[u], sm.cx_c0[u], sm.cx_c1[u], sm.cx_cell[u], sm.cx_umi[u], sm.cx_s0[u], sm.cx_sl[u], sm.cx_idx[u]);
             }
+            if (r.ok) uor |= r.umi;                                   // (finish() puts the haplotype class of the region-level keys into UMI-field bits no code uses)
             acc += c + n_gap;
         } else {
             if (r.ok) uor |= r.umi;
@@ -783,8 +784,8 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     // accepted (read, region|SNP) pairs before the LDS de-duplication: the algorithmic unit of the join
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd, 64);
-    if (MODE == XCK_MODE_BASEFC) {
-        // highest UMI-code bit in use: finish() drops the dead bits between the UMI codes and the cell field before the sort
+    {
+        // highest UMI-code bit in use: the radix-sort fold drops the dead bits between the UMI codes and the cell field before the sort
         uint32_t ulo = (uint32_t)uor, uhi = (uint32_t)(uor >> 32);
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) { ulo |= __shfl_xor(ulo, dd, 64); uhi |= __shfl_xor(uhi, dd, 64); }
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     }
     if (lane == 0) sm.wcnt[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0 && MODE == XCK_MODE_BASEFC) {
+    if (tid == 0) {
         uor = 0;
 #pragma unroll
         for (int w = 0; w < JOIN_BLOCK / 64; w++) uor |= ((unsigned long long)sm.wuor[2 * w + 1] << 32) | sm.wuor[2 * w];
@@ -1131,6 +1132,7 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
 // (baf/fc/mcount.py:118-119) and the run contributes nothing.  The Bloom filter answers "no" for almost every record;
 // the exact lookups that remain are binary searches inside one SNP's run (the stream is in tile order, so
 // neighbouring threads search the same few SNPs and stay in L2).
+constexpr int CL_U = 4;                    // gap records per thread
 template <class K>
 __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const uint64_t* __restrict__ nv, unsigned long long cap, ShardSpan sp, unsigned long long n_units,
                                                  const K* __restrict__ keys, KeyLayout<K> kl, const unsigned long long* __restrict__ row_lo, const unsigned long long* __restrict__ row_hi,
@@ -1138,44 +1140,67 @@ __global__ void __launch_bounds__(256) k_claim(const K* __restrict__ nk, const u
                                                  const unsigned long long* __restrict__ bloom, const unsigned long long* __restrict__ blk_lo, uint32_t n_rows,
                                                  const uint32_t* __restrict__ p_rowtab, const uint32_t* __restrict__ p_end) {
     const int low = kl.cbits + kl.ubits;
-    // unit u = records [256 * (u / NSHARD), + 256) of shard slice u % NSHARD: the slices are filled round-robin by consecutive join
-    // tiles, so the blocks in flight together hold ONE narrow position range of the file (and one window of the Bloom table)
+    // unit u = records [256 * CL_U * (u / NSHARD), + 256 * CL_U) of shard slice u % NSHARD: the slices are filled round-robin by consecutive
+    // join tiles, so the blocks in flight together hold ONE narrow position range of the file (and one window of the filter table).
+    // The kernel is a chain of dependent loads per record (record -> block bounds -> filter word, then for the few survivors cell bounds
+    // -> ~9 bisection probes -> ordinal), and nearly every wave holds a survivor: a thread therefore takes CL_U records - all their filter
+    // probes are in flight together (a gap covers at most 32 SNPs: two blocks), and the survivors of all of them are looked up in ONE
+    // loop whose trip count is the most survivors any lane has, not a loop per record.
     for (unsigned long long u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int sh = (int)(u % NSHARD);
-        const unsigned long long idx = (u / NSHARD) * 256 + threadIdx.x;
-        if (idx >= sp.start[sh + 1] - sp.start[sh]) continue;
-        const unsigned long long j = (unsigned long long)sh * cap + idx;
-        const K rec = __builtin_nontemporal_load(&nk[j]);               // (read once: keep the L2 for the table window and the key look-ups)
-        const uint64_t v = __builtin_nontemporal_load(&nv[j]);
-        const uint64_t ordn = v >> ALLELE_BITS;
-        const uint32_t k1 = kl.row(rec), k2 = min(k1 + (uint32_t)(v & ((1u << ALLELE_BITS) - 1)) + 1u, n_rows);
-        const K cellumi = rec & ((K(1) << low) - 1);
-        for (uint32_t blk = k1 >> 5; blk <= (k2 - 1) >> 5; blk++) {
-            const unsigned long long b_lo = blk_lo[blk], b_len = blk_lo[blk + 1] - b_lo;
-            if (!b_len) continue;                                       // no read shows a base anywhere in this block of SNPs
-            unsigned long long word; uint32_t r1, r2;
-            bloom_slot((unsigned long long)cellumi, blk, b_lo, b_len, word, r1, r2);
-            const uint32_t o0 = max(k1, blk << 5) & 31u, o1 = (min(k2, (blk + 1) << 5) - 1u) & 31u;     // the gap's SNPs inside this block: offsets o0 .. o1
-            const unsigned long long w = bloom[word];
-            const uint32_t h1 = (uint32_t)w, h2 = (uint32_t)(w >> 32);
-            uint32_t m = ((h1 >> r1) | (h1 << ((32u - r1) & 31u))) & ((h2 >> r2) | (h2 << ((32u - r2) & 31u))) & ((0xffffffffu >> (31u - o1)) & (0xffffffffu << o0));
-            while (m) {                                                 // SNPs at which this molecule (or one that shares both words) shows a base
-                const uint32_t srow = (blk << 5) + (uint32_t)__builtin_ctz(m);
-                m &= m - 1;
-                // the key's place: inside its (SNP, cell group) cell of the partition sort where there was one (<= 2048 entries: ~9 probes
-                // on a few lines; a hot SNP's whole range is 100 k entries, 17 probes on 17 lines - 5.5 GB of HBM reads per pass), else
-                // inside the SNP's range
-                unsigned long long lo, hi;
-                if (p_rowtab) {
-                    const uint32_t t = p_rowtab[srow], z = (t >> 5) + ((uint32_t)((unsigned long long)cellumi >> kl.ubits) >> (t & 31u));
-                    lo = z ? p_end[z - 1] : 0u; hi = p_end[z];
-                } else { lo = row_lo[srow]; hi = row_hi[srow]; }
-                if (lo >= hi) continue;
-                const unsigned long long end = hi;
-                const K key = (K(srow) << low) | cellumi;
-                while (lo < hi) { const unsigned long long mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
-                if (lo < end && keys[lo] == key && ordn < ord[lo]) al[lo] = 0;   // benign race: every writer stores 0
+        const unsigned long long n_sh = sp.start[sh + 1] - sp.start[sh], idx0 = (u / NSHARD) * (256 * CL_U) + threadIdx.x;
+        K cu[CL_U]; uint64_t ordn[CL_U]; uint32_t k1[CL_U], m[CL_U][2];
+#pragma unroll
+        for (int q = 0; q < CL_U; q++) {
+            const unsigned long long idx = idx0 + (unsigned long long)q * 256;
+            cu[q] = 0; ordn[q] = 0; k1[q] = 0; m[q][0] = m[q][1] = 0;
+            if (idx >= n_sh) continue;
+            const unsigned long long j = (unsigned long long)sh * cap + idx;
+            const K rec = __builtin_nontemporal_load(&nk[j]);           // (read once: keep the L2 for the table window and the key look-ups)
+            const uint64_t v = __builtin_nontemporal_load(&nv[j]);
+            ordn[q] = v >> ALLELE_BITS;
+            k1[q] = kl.row(rec);
+            const uint32_t k2 = min(k1[q] + (uint32_t)(v & ((1u << ALLELE_BITS) - 1)) + 1u, n_rows);
+            cu[q] = rec & ((K(1) << low) - 1);
+#pragma unroll
+            for (int b = 0; b < 2; b++) {                               // (at most 32 SNPs from k1: the block of k1 and the next)
+                const uint32_t blk = (k1[q] >> 5) + b;
+                if (blk > (k2 - 1) >> 5) continue;
+                const unsigned long long b_lo = blk_lo[blk], b_len = blk_lo[blk + 1] - b_lo;
+                if (!b_len) continue;                                   // no read shows a base anywhere in this block of SNPs
+                unsigned long long word; uint32_t r1, r2;
+                bloom_slot((unsigned long long)cu[q], blk, b_lo, b_len, word, r1, r2);
+                const uint32_t o0 = max(k1[q], blk << 5) & 31u, o1 = (min(k2, (blk + 1) << 5) - 1u) & 31u;     // the gap's SNPs inside this block: offsets o0 .. o1
+                const unsigned long long w = bloom[word];
+                const uint32_t h1 = (uint32_t)w, h2 = (uint32_t)(w >> 32);
+                m[q][b] = ((h1 >> r1) | (h1 << ((32u - r1) & 31u))) & ((h2 >> r2) | (h2 << ((32u - r2) & 31u))) & ((0xffffffffu >> (31u - o1)) & (0xffffffffu << o0));
             }
+        }
+        // SNPs at which one of this thread's molecules (or one that shares its filter word) shows a base
+        for (;;) {
+            int sq = -1, sb = 0;
+#pragma unroll
+            for (int q = CL_U - 1; q >= 0; q--) { if (m[q][1]) { sq = q; sb = 1; } if (m[q][0]) { sq = q; sb = 0; } }
+            if (sq < 0) break;
+            K cellumi = 0; uint64_t my_ord = 0; uint32_t my_k1 = 0, mm = 0;
+#pragma unroll
+            for (int q = 0; q < CL_U; q++) if (q == sq) { cellumi = cu[q]; my_ord = ordn[q]; my_k1 = k1[q]; mm = m[q][sb]; }
+            const uint32_t srow = (((my_k1 >> 5) + (uint32_t)sb) << 5) + (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1;
+#pragma unroll
+            for (int q = 0; q < CL_U; q++) if (q == sq) m[q][sb] = mm;
+            // the key's place: inside its (SNP, cell group) cell of the partition sort where there was one (<= 2048 entries: ~9 probes
+            // on a few lines; a hot SNP's whole range is 100 k entries), else inside the SNP's range
+            unsigned long long lo, hi;
+            if (p_rowtab) {
+                const uint32_t t = p_rowtab[srow], z = (t >> 5) + ((uint32_t)((unsigned long long)cellumi >> kl.ubits) >> (t & 31u));
+                lo = z ? p_end[z - 1] : 0u; hi = p_end[z];
+            } else { lo = row_lo[srow]; hi = row_hi[srow]; }
+            if (lo >= hi) continue;
+            const unsigned long long end = hi;
+            const K key = (K(srow) << low) | cellumi;
+            while (lo < hi) { const unsigned long long mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+            if (lo < end && keys[lo] == key && my_ord < ord[lo]) al[lo] = 0;   // benign race: every writer stores 0
         }
     }
 }
@@ -1250,7 +1275,9 @@ template <class K, bool EMIT, class V>
 __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, const uint8_t* __restrict__ al, long long n,
                                   KeyLayout<K> kl, const uint32_t* __restrict__ tally, const uint32_t* __restrict__ info,
                                   SnpFilter f, const int32_t* __restrict__ csr_off, const int32_t* __restrict__ csr_reg,
-                                  K* __restrict__ k2, V* __restrict__ v2, unsigned long long* ctl, XBases xb) {
+                                  K* __restrict__ k2, V* __restrict__ v2, unsigned long long* ctl, XBases xb, int pack_shift) {
+    // pack_shift >= 0 (emit pass, 64-bit keys): no values are written - the haplotype class goes into two UMI-field bits that no UMI code
+    // uses (k_join ORs the UMI codes of the reads it accepts into ctl_umi_or; the host finds the free bits)
     __shared__ uint32_t s_wave[JOIN_BLOCK / 64];
     __shared__ unsigned long long s_base;
     long long i = (long long)blockIdx.x * JOIN_BLOCK + threadIdx.x;
@@ -1280,9 +1307,10 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
     if (nib == int((inf >> 4) & 15)) idx = int((inf >> 9) & 1);
     const V bits = idx == 0 ? 1 : idx == 1 ? 2 : 4;
     uint32_t cell = kl.cell(me); uint64_t umi = kl.umi(me);
+    if (pack_shift >= 0) umi |= (uint64_t)(idx == 0 ? 0u : idx == 1 ? 1u : 2u) << pack_shift;
     for (int32_t c = csr_off[s]; c < csr_off[s + 1]; c++, dst++) {
         k2[dst] = kl.make((uint32_t)csr_reg[c], cell, umi);
-        v2[dst] = bits;
+        if (pack_shift < 0) v2[dst] = bits;
     }
 }
 
@@ -2355,7 +2383,7 @@ static int finish_t(EngineImpl* im) {
             if (im->ncursor) {
                 ShardSpan nsp; nsp.start[0] = 0; unsigned long long mx = 0;
                 for (int sh = 0; sh < NSHARD; sh++) { nsp.start[sh + 1] = nsp.start[sh] + im->ncur[sh]; mx = std::max(mx, im->ncur[sh]); }
-                const unsigned long long n_units = ((mx + 255) / 256) * NSHARD;
+                const unsigned long long n_units = ((mx + 256 * CL_U - 1) / (256 * CL_U)) * NSHARD;
                 // (one block per unit: blocks start in index order, so the resident ones hold consecutive units = ONE window of the table; a grid-stride
                 // loop over 16 k blocks mixed up to 11 windows and every probe went to HBM: 5.5 GB read for 0.74 GB of records)
                 hipLaunchKernelGGL((k_claim<K>), dim3((unsigned)std::min<unsigned long long>(n_units, 1ull << 30)), dim3(256), 0, im->s_comp,
@@ -2381,13 +2409,16 @@ static int finish_t(EngineImpl* im) {
         XBases xb; memset(&xb, 0, sizeof xb);
         HIP_TRY(hipMemsetAsync(im->d_ctl + CTL_X0, 0, XSHARD * CTL_STRIDE * sizeof(unsigned long long), im->s_comp));
         hipLaunchKernelGGL((k_expand<K, false, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (V2*)nullptr, im->d_ctl, xb);
+                           im->sf, im->d_csr_off, im->d_csr_reg, (K*)nullptr, (V2*)nullptr, im->d_ctl, xb, -1);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_X0), im->d_hctl + CTL_X0, XSHARD * CTL_STRIDE);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(im->s_comp));
         size_t n2 = 0; unsigned long long tot2[XSHARD], cap2 = 0;
+        unsigned long long uor2 = 0;
         for (int sh = 0; sh < XSHARD; sh++) { tot2[sh] = im->h_ctl[CTL_X0 + sh * CTL_STRIDE]; n2 += tot2[sh]; cap2 = std::max(cap2, tot2[sh]); }
+        for (int sh = 0; sh < NSHARD; sh++) uor2 |= im->h_ctl[ctl_umi_or(sh)];
+        const int used2 = uor2 ? 64 - __builtin_clzll(uor2) : 0;            // UMI-field bits in use by the reads the join accepted (a superset of the region-level keys')
         cap2 = (cap2 + 63) & ~63ull;
         if (n2) {
             // 64-bit keys: k_expand writes its 16 slices at a fixed stride and the partition sort (fold_partition.h) orders them; when it hands
@@ -2411,15 +2442,18 @@ static int finish_t(EngineImpl* im) {
             if constexpr (sizeof(K) == 8) {
                 if (try_part) {
                     for (int sh = 0; sh < XSHARD; sh++) xb.base[sh] = (unsigned long long)sh * cap2;
+                    // (XCK_PILEUP_HAP=sorted: sort the items completely and run k_hap_class / k_hap_sum on them, as after the radix sort;
+                    //  XCK_PILEUP_HAP=values: keep the haplotype class in a value word beside the key, as when the UMI field has no two free bits)
+                    const char* hap_env = getenv("XCK_PILEUP_HAP");
+                    const bool hap_items = !(hap_env && !strcmp(hap_env, "sorted"));
+                    const int pack_shift = hap_items && !(hap_env && !strcmp(hap_env, "values")) && used2 + 2 <= im->ubits ? used2 : -1;
                     hipLaunchKernelGGL((k_expand<K, true, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                                       im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
+                                       im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb, pack_shift);
                     HIP_TRY(hipGetLastError());
                     KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
-                    // (XCK_PILEUP_HAP=sorted: sort the items completely and run k_hap_class / k_hap_sum on them, as after the radix sort)
-                    const bool hap_items = !(getenv("XCK_PILEUP_HAP") && !strcmp(getenv("XCK_PILEUP_HAP"), "sorted"));
-                    const HapItemsOut ho{(unsigned long long*)acc, (unsigned long long*)run_key};   // (the packed sums use the first half of acc)
-                    rc = pileup_partition_sort(im, im->ws2, false, kl8, (const unsigned long long*)k2, (const uint64_t*)v2, (size_t)cap2, tot2,
-                                               (uint32_t)std::max(im->n_regions, 1), n2, (unsigned long long*)k2b, (uint64_t*)v2b, hap_items ? &ho : nullptr);
+                    const HapItemsOut ho{(unsigned long long*)acc, (unsigned long long*)run_key, pack_shift};   // (the packed sums use the first half of acc)
+                    rc = pileup_partition_sort(im, im->ws2, false, kl8, (const unsigned long long*)k2, pack_shift >= 0 ? (const uint64_t*)nullptr : (const uint64_t*)v2, (size_t)cap2, tot2,
+                                               (uint32_t)std::max(im->n_regions, 1), n2, (unsigned long long*)k2b, pack_shift >= 0 ? (uint64_t*)nullptr : (uint64_t*)v2b, hap_items ? &ho : nullptr);
                     im->ws2.off = ws2_mark;                                    // (its scratch is free again; the kernels that used it are ordered before the next ones)
                     if (rc == 0) { sorted2 = true; summed2 = hap_items; im->pileup_sort2_path = hap_items ? 1 : 3; }
                     else if (rc != PF_FALLBACK) return rc;
@@ -2433,7 +2467,7 @@ static int finish_t(EngineImpl* im) {
                 void* tmp2 = im->ws2.get<char>(tmpb2);
                 { unsigned long long at = 0; for (int sh = 0; sh < XSHARD; sh++) { xb.base[sh] = at; at += tot2[sh]; } }
                 hipLaunchKernelGGL((k_expand<K, true, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
-                                   im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb);
+                                   im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb, -1);
                 HIP_TRY(hipGetLastError());
                 if ((rc = sort_run<K, V2>(im, tmp2, tmpb2, k2, k2b, v2, v2b, n2, top))) return rc;
             }

@@ -1011,6 +1011,7 @@ struct RsShared {
     unsigned long long s_diff;
 };
 // the item's pairs into registers (padding: ~0), OR of (key ^ first key) over the block -> which digits differ at all
+template <bool HAS_VAL>
 __device__ __forceinline__ unsigned long long rs_load(RsShared& sm, const unsigned long long* __restrict__ keys, const uint64_t* __restrict__ vals, uint32_t off, uint32_t n,
                                                       unsigned long long (&key)[RS_EPT], unsigned long long (&val)[RS_EPT]) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
@@ -1021,7 +1022,7 @@ __device__ __forceinline__ unsigned long long rs_load(RsShared& sm, const unsign
     for (int r = 0; r < RS_EPT; r++) {
         const uint32_t e = e0 + r * 64;
         key[r] = ~0ull; val[r] = ~0ull;
-        if (e < n) { key[r] = keys[off + e]; val[r] = vals[off + e]; diff |= key[r] ^ first; }
+        if (e < n) { key[r] = keys[off + e]; if (HAS_VAL) val[r] = vals[off + e]; diff |= key[r] ^ first; }
     }
     for (int d = 32; d; d >>= 1) diff |= __shfl_xor(diff, d);
     __syncthreads();
@@ -1030,6 +1031,7 @@ __device__ __forceinline__ unsigned long long rs_load(RsShared& sm, const unsign
     return sm.s_diff;
 }
 // one stable counting pass on the digit (key >> shift) & 255; the pairs come back in registers in their new order
+template <bool HAS_VAL>
 __device__ __forceinline__ void rs_pass(RsShared& sm, unsigned long long (&key)[RS_EPT], unsigned long long (&val)[RS_EPT], int shift, int n_rounds) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
 #pragma unroll
@@ -1070,14 +1072,14 @@ __device__ __forceinline__ void rs_pass(RsShared& sm, unsigned long long (&key)[
     for (int r = 0; r < RS_EPT; r++) {
         if (r < n_rounds) {
             const uint32_t pos = sm.hist[wave][(uint32_t)(key[r] >> shift) & 0xffu] + rank[r];
-            sm.sk[pos] = key[r]; sm.sv[pos] = val[r];
+            sm.sk[pos] = key[r]; if (HAS_VAL) sm.sv[pos] = val[r];
         }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_EPT; r++) {
         const uint32_t e = e0 + r * 64;
-        if (r < n_rounds) { key[r] = sm.sk[e]; val[r] = sm.sv[e]; }        // (places >= n hold this pass's padding: ~0 again)
+        if (r < n_rounds) { key[r] = sm.sk[e]; if (HAS_VAL) val[r] = sm.sv[e]; }   // (places >= n hold this pass's padding: ~0 again)
     }
 }
 __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long long* __restrict__ keys, uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off, uint32_t* __restrict__ ctr) {
@@ -1088,13 +1090,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
     const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);   // rounds of this wave that hold anything (wave-uniform)
     unsigned long long key[RS_EPT], val[RS_EPT];
-    const unsigned long long diff = rs_load(sm, keys, vals, off, n, key, val);
+    const unsigned long long diff = rs_load<true>(sm, keys, vals, off, n, key, val);
     if (!diff) return;                                                    // one key: sorted as it is
     // 8-bit windows that start at the lowest differing bit not yet sorted on (block-uniform): an item of one hot SNP differs in the
     // 24 UMI bits in use and in 4 cell bits six bits further up - 4 windows, where windows at multiples of 8 take 5
     for (unsigned long long rem = diff; rem; ) {
         const int shift = __builtin_ctzll(rem);
-        rs_pass(sm, key, val, shift, n_rounds);
+        rs_pass<true>(sm, key, val, shift, n_rounds);
         rem = shift >= 56 ? 0ull : rem & ~(0xffull << shift);
     }
 #pragma unroll
@@ -1110,11 +1112,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_pf_radix_items(unsigned long lon
 // head key and its four sums (one packed word) go to run_key / sums at [item offset + run number] - a staging area with holes (an item has fewer runs
 // than keys), zero where nothing is written; k_hap_count / k_hap_scatter skip the holes.  Replaces the UMI digits of the sort,
 // k_hap_class (+ _long), k_fold_heads and k_hap_sum of the sorted path.
-struct HapItemsOut { unsigned long long* sums; unsigned long long* run_key; };   // per staging entry: 4 x 16-bit sums in one word (zero = hole), the run's head key
+// per staging entry: 4 x 16-bit sums in one word (zero = hole), the run's head key.  pack_shift >= 0: there are no values - the haplotype
+// class (0 REF-hap, 1 ALT-hap, 2 other) rides in two unused bits of the key's UMI field, at pack_shift (k_expand put it there)
+struct HapItemsOut { unsigned long long* sums; unsigned long long* run_key; int pack_shift; };
 // what a finished partition sort leaves behind for look-ups by key: cell z of (row, cell) = (rowtab[row] >> 5) + (cell >> (rowtab[row] & 31)),
 // its entries in the sorted output = [z ? end[z - 1] : 0, end[z]) (k_pf_part turned the scanned counts into end offsets).  Lives in the
 // sort's scratch arena: valid until that arena is begun again.
 struct PartIndex { const uint32_t* rowtab; const uint32_t* end; };
+template <bool PACKED>
 __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long long* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off,
                                                           int ubits, HapItemsOut out, uint32_t* __restrict__ ctr) {
     __shared__ RsShared sm;
@@ -1127,11 +1132,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e0 = wave * RS_SEG + lane;
     const int n_rounds = (int)min((uint32_t)RS_EPT, wave * RS_SEG >= n ? 0u : (n - wave * RS_SEG + 63) / 64);
     unsigned long long key[RS_EPT], val[RS_EPT];
-    const unsigned long long diff = rs_load(sm, keys, vals, off, n, key, val);
+    const unsigned long long diff = rs_load<!PACKED>(sm, keys, vals, off, n, key, val);
     for (unsigned long long rem = (diff >> ubits) << ubits; rem; ) {      // windows from the lowest differing (region, cell) bit upwards
         const int shift = __builtin_ctzll(rem);
-        rs_pass(sm, key, val, shift, n_rounds);
+        rs_pass<!PACKED>(sm, key, val, shift, n_rounds);
         rem = shift >= 56 ? 0ull : rem & ~(0xffull << shift);
+    }
+    if (PACKED) {                                                         // the class leaves the key: from here on as with values
+#pragma unroll
+        for (int r = 0; r < RS_EPT; r++) { val[r] = 1ull << ((key[r] >> out.pack_shift) & 3ull); if (e0 + r * 64 < n) key[r] &= ~(3ull << out.pack_shift); }
     }
     // (2) heads of the (region, cell) runs, run numbers in element order
     __syncthreads();
@@ -1284,7 +1293,8 @@ static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyL
     hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)src_keys, sc, bc0, g, 0, S, out_keys, src_vals, out_vals);
     const bool bitonic = getenv("XCK_PILEUP_ITEM_SORT") && !strcmp(getenv("XCK_PILEUP_ITEM_SORT"), "bitonic");
-    if (hap) hipLaunchKernelGGL(k_hap_items, dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, (const unsigned long long*)out_keys, (const uint64_t*)out_vals, (const uint32_t*)item_off, kl.ubits, *hap, ctr);
+    if (hap && hap->pack_shift >= 0) hipLaunchKernelGGL((k_hap_items<true>), dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, (const unsigned long long*)out_keys, (const uint64_t*)nullptr, (const uint32_t*)item_off, kl.ubits, *hap, ctr);
+    else if (hap) hipLaunchKernelGGL((k_hap_items<false>), dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, (const unsigned long long*)out_keys, (const uint64_t*)out_vals, (const uint32_t*)item_off, kl.ubits, *hap, ctr);
     else if (bitonic) hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     else hipLaunchKernelGGL(k_pf_radix_items, dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
     HIP_TRY(hipGetLastError());
