@@ -1108,14 +1108,27 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
                              unsigned long long* __restrict__ bloom, const unsigned long long* __restrict__ blk_lo, unsigned long long* __restrict__ long_runs) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const K me = k[i];
+    // The kernel waits for memory 91 % of its wave cycles (profiles/r03_X_sq_counters_resident.txt): a wave's time is the number of
+    // DEPENDENT load stages.  Everything a short run needs - the neighbours' keys and the next two values - is therefore loaded up front,
+    // without looking at the keys first (the lines are the neighbouring lanes' own), and the filter block's bounds as soon as the row is known.
+    const long long ip = i > 0 ? i - 1 : 0, i1 = i + 1 < n ? i + 1 : n - 1, i2 = i + 2 < n ? i + 2 : n - 1;
+    const K kp = k[ip], me = k[i], kn1 = k[i1], kn2 = k[i2];
+    const uint64_t v0 = v[i], v1 = v[i1], v2 = v[i2];
     const uint32_t row = kl.row(me);
-    if (i == 0 || kl.row(k[i - 1]) != row) row_lo[row] = (unsigned long long)i;
-    if (i + 1 == n || kl.row(k[i + 1]) != row) row_hi[row] = (unsigned long long)(i + 1);
-    if (i > 0 && k[i - 1] == me) { al_out[i] = 0; return; }
-    uint64_t best = v[i];
+    const unsigned long long b_lo = blk_lo[row >> 5], b_len = blk_lo[(row >> 5) + 1] - b_lo;   // (this key is inside: b_len >= 1)
+    if (i == 0 || kl.row(kp) != row) row_lo[row] = (unsigned long long)i;
+    if (i + 1 == n || kl.row(kn1) != row) row_hi[row] = (unsigned long long)(i + 1);
+    if (i > 0 && kp == me) { al_out[i] = 0; return; }
+    uint64_t best = v0;
     long long j = i + 1;
-    for (; j < n && j <= i + RUN_WALK && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
+    if (j < n && kn1 == me) {
+        if (v1 < best) best = v1;
+        j = i + 2;
+        if (j < n && kn2 == me) {
+            if (v2 < best) best = v2;
+            for (j = i + 3; j < n && j <= i + RUN_WALK && k[j] == me; j++) { uint64_t x = v[j]; if (x < best) best = x; }
+        }
+    }
     if (j < n && j > i + RUN_WALK && k[j] == me) long_runs[1 + atomicAdd(&long_runs[0], 1ull)] = (unsigned long long)i;   // al / ord of this head: k_first_long
     else {
         al_out[i] = (uint8_t)(best & ((1u << ALLELE_BITS) - 1));      // nibble + 1 (never 0 here)
@@ -1123,7 +1136,6 @@ __global__ void k_first_base(const K* __restrict__ k, const uint64_t* __restrict
     }
     unsigned long long word; uint32_t r1, r2;
     const unsigned long long cu = (unsigned long long)(me & ((K(1) << (kl.cbits + kl.ubits)) - 1));
-    const unsigned long long b_lo = blk_lo[row >> 5], b_len = blk_lo[(row >> 5) + 1] - b_lo;   // (this key is inside: b_len >= 1)
     bloom_slot(cu, row >> 5, b_lo, b_len, word, r1, r2);
     atomicOr(&bloom[word], (1ull << ((row + r1) & 31u)) | (1ull << (32u + ((row + r2) & 31u))));
 }

@@ -1006,7 +1006,7 @@ static_assert(RS_EPT * RS_THREADS == PS_CAP && RS_SEG == RS_EPT * 64, "item capa
 struct RsShared {
     unsigned long long sk[PS_CAP];
     unsigned long long sv[PS_CAP];                                        // (sk + sv = the 4096-slot key table of k_hap_items)
-    uint32_t hist[RS_WAVES][256];                                         // (= the slot payloads of k_hap_items)
+    uint16_t hist[RS_WAVES][256];                                         // (counts and places of an item: <= 2048.  16-bit: 36.9 KB per block, four blocks per CU)
     uint32_t s_wtot[RS_WAVES];
     unsigned long long s_diff;
 };
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void rs_pass(RsShared& sm, unsigned long long (&key)[
             for (int b = 0; b < 8; b++) { const bool on = (dg >> b) & 1u; const unsigned long long bal = __ballot(on); m &= on ? bal : ~bal; }
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             const uint32_t prev = sm.hist[wave][dg];                      // (the lanes of a group read one word; LDS operations of a wave stay in order)
-            if (below == 0) sm.hist[wave][dg] = prev + (uint32_t)__popcll(m);
+            if (below == 0) sm.hist[wave][dg] = (uint16_t)(prev + (uint32_t)__popcll(m));
             rank[r] = prev + below;
         }
     }
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void rs_pass(RsShared& sm, unsigned long long (&key)[
         uint32_t base = inc - tot;
         for (uint32_t w = 0; w < wave; w++) base += sm.s_wtot[w];
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) { sm.hist[w][threadIdx.x] = base; base += c[w]; }
+        for (int w = 0; w < RS_WAVES; w++) { sm.hist[w][threadIdx.x] = (uint16_t)base; base += c[w]; }
     }
     __syncthreads();
 #pragma unroll
@@ -1123,9 +1123,8 @@ template <bool PACKED>
 __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long long* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ item_off,
                                                           int ubits, HapItemsOut out, uint32_t* __restrict__ ctr) {
     __shared__ RsShared sm;
-    __shared__ unsigned long long cnt[PS_CAP];                            // per run: 4 x 16-bit counters (an item holds at most 2048 keys)
+    __shared__ uint32_t pay[PS_CAP];                                      // 16 bits per slot of the 4096-slot table: run number << 3 | haplotype bits (0 = empty)
     __shared__ uint32_t s_wheads[RS_WAVES];
-    __shared__ uint32_t s_ff;                                             // the one key that equals the table's "empty" word
     const uint32_t off = item_off[blockIdx.x], n = item_off[blockIdx.x + 1] - off;
     if (n == 0) return;
     if (n > (uint32_t)PS_CAP) { if (threadIdx.x == 0) ctr[7] = 1u; return; }
@@ -1158,7 +1157,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
         heads_w += (uint32_t)__popcll(bal);
     }
     if (lane == 0) s_wheads[wave] = heads_w;
-    if (threadIdx.x == 0) s_ff = 0;
     __syncthreads();
     uint32_t wbase = 0, n_runs = 0;
 #pragma unroll
@@ -1166,23 +1164,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
     int lg_slots = 8; while ((1u << lg_slots) < 2 * n) lg_slots++;        // <= 4096 = sk + sv
     const uint32_t smask = (1u << lg_slots) - 1u;
     unsigned long long* __restrict__ tab = sm.sk;
-    uint32_t* __restrict__ pay = &sm.hist[0][0];                          // 16 bits per slot: run number << 3 | haplotype bits (0 = empty)
     for (uint32_t q = threadIdx.x; q <= smask; q += RS_THREADS) tab[q] = ~0ull;
     for (uint32_t q = threadIdx.x; q <= (smask >> 1); q += RS_THREADS) pay[q] = 0u;
-    for (uint32_t q = threadIdx.x; q < n_runs; q += RS_THREADS) cnt[q] = 0ull;
 #pragma unroll
     for (int r = 0; r < RS_EPT; r++) {
         runid[r] = wbase + runid[r] - 1u;
         if (head[r]) out.run_key[(size_t)off + runid[r]] = key[r];
     }
     __syncthreads();
-    // (3) molecules: hash set on the whole key, payload OR
+    // (3) molecules: hash set on the whole key, payload OR (no key equals the empty word ~0: key_layout() sizes the row field so that it is never all ones)
 #pragma unroll
     for (int r = 0; r < RS_EPT; r++) {
         const uint32_t e = e0 + r * 64;
         if (e >= n) continue;
         const uint32_t p = (runid[r] << 3) | ((uint32_t)val[r] & 7u);
-        if (key[r] == ~0ull) { atomicOr(&s_ff, 0x80000000u | p); continue; }
         uint32_t slot = set_slot<PF_SLOTS>(key[r]) & smask;
         for (;;) {
             const unsigned long long prev = atomicCAS(&tab[slot], ~0ull, key[r]);
@@ -1192,7 +1187,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
         atomicOr(&pay[slot >> 1], p << ((slot & 1u) * 16));
     }
     __syncthreads();
-    // (4) classes -> run counters
+    // (4) classes -> run counters: 4 x 16 bits per run (an item holds at most 2048 keys), in the memory of the key table - the keys are
+    // dead, the sweep reads the payloads only (44 KB of LDS per block instead of 60: three blocks per CU)
+    unsigned long long* __restrict__ cnt = sm.sk;
+    for (uint32_t q = threadIdx.x; q < n_runs; q += RS_THREADS) cnt[q] = 0ull;
+    __syncthreads();
     auto add_class = [&](uint32_t p) {
         const uint32_t bits = p & 7u, run = (p >> 3) & 0x7ffu;
         const unsigned long long c = (unsigned long long)(bits & 1u) | ((unsigned long long)((bits >> 1) & 1u) << 16) | ((unsigned long long)((bits & 3u) ? 1u : 0u) << 32)
@@ -1203,7 +1202,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
         const uint32_t p = (pay[q >> 1] >> ((q & 1u) * 16)) & 0xffffu;
         if (p) add_class(p);
     }
-    if (threadIdx.x == 0 && s_ff) add_class(s_ff & 0xffffu);
     __syncthreads();
     // (5) the runs of this item
     for (uint32_t q = threadIdx.x; q < n_runs; q += RS_THREADS) {
