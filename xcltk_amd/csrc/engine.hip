@@ -1294,12 +1294,13 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
     __shared__ unsigned long long s_base;
     long long i = (long long)blockIdx.x * JOIN_BLOCK + threadIdx.x;
     uint32_t cnt = 0, s = 0, code = 0; K me = 0;
+    int32_t c0 = 0, c1 = 0;
     if (i < n) {
-        code = al[i];
-        if (code) {
-            me = k[i]; s = kl.row(me);
-            if (snp_passes(tally, info, s, f)) cnt = uint32_t(csr_off[s + 1] - csr_off[s]);
-        }
+        // (the kernel waits for memory 83 % of its wave cycles: key and allele code are loaded together, and the SNP's region list bounds
+        // together with its tallies - three dependent stages instead of five)
+        code = al[i]; me = k[i]; s = kl.row(me);
+        c0 = csr_off[s]; c1 = csr_off[s + 1];
+        if (code && snp_passes(tally, info, s, f)) cnt = uint32_t(c1 - c0);
     }
     uint32_t total;
     uint32_t excl = block_excl_scan(cnt, s_wave, total);
@@ -1320,7 +1321,7 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_expand(const K* __restrict__ k, 
     const V bits = idx == 0 ? 1 : idx == 1 ? 2 : 4;
     uint32_t cell = kl.cell(me); uint64_t umi = kl.umi(me);
     if (pack_shift >= 0) umi |= (uint64_t)(idx == 0 ? 0u : idx == 1 ? 1u : 2u) << pack_shift;
-    for (int32_t c = csr_off[s]; c < csr_off[s + 1]; c++, dst++) {
+    for (int32_t c = c0; c < c1; c++, dst++) {
         k2[dst] = kl.make((uint32_t)csr_reg[c], cell, umi);
         if (pack_shift < 0) v2[dst] = bits;
     }
@@ -1552,6 +1553,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_hap_count(HapSrc h, uint32_t* __re
 template <class K>
 __global__ __launch_bounds__(CP_BLOCK) void k_hap_scatter(HapSrc h, const K* __restrict__ k, KeyLayout<K> kl, const unsigned long long* __restrict__ off, CooOut3 out) {
     __shared__ unsigned long long s_w[FD_BLOCK / 64];
+    __shared__ int32_t s_row[CP_TILE], s_col[CP_TILE], s_val[CP_TILE];    // one matrix's entries of this tile, compacted: they leave with coalesced stores
     static_assert(FD_BLOCK == CP_BLOCK, "block_excl_scan64 is written for FD_BLOCK threads");
     const long long n = h.n_runs ? (long long)*h.n_runs : h.n_fixed, i0 = (long long)blockIdx.x * CP_TILE + (long long)threadIdx.x * CP_ITEMS;
     if ((long long)blockIdx.x * CP_TILE >= n) return;
@@ -1561,20 +1563,32 @@ __global__ __launch_bounds__(CP_BLOCK) void k_hap_scatter(HapSrc h, const K* __r
         hap_load8(h, i0, v[0], v[1], v[2]);
 #pragma unroll
         for (int t = 0; t < CP_ITEMS; t++) c += (unsigned long long)(v[0][t] > 0) | ((unsigned long long)(v[1][t] > 0) << 21) | ((unsigned long long)(v[2][t] > 0) << 42);
+    } else {
+#pragma unroll
+        for (int t = 0; t < CP_ITEMS; t++) v[0][t] = v[1][t] = v[2][t] = 0;
     }
     unsigned long long total;
     const unsigned long long excl = block_excl_scan64(c, s_w, total);
-    if (!c) return;
-    K key[CP_ITEMS];
+    int32_t krow[CP_ITEMS], kcol[CP_ITEMS];
 #pragma unroll
-    for (int t = 0; t < CP_ITEMS; t++) key[t] = k[i0 + t];               // (c != 0: the thread's runs exist; `k` holds one key per run and is at least stride long)
+    for (int t = 0; t < CP_ITEMS; t++) {                                 // (`k` holds one key per staging entry and is at least stride long; only entries with a value are used)
+        krow[t] = 0; kcol[t] = 0;
+        if (c && (v[0][t] > 0 || v[1][t] > 0 || v[2][t] > 0)) { const K key = k[i0 + t]; krow[t] = (int32_t)kl.row(key); kcol[t] = (int32_t)kl.cell(key); }
+    }
+    // (a thread's entries sit next to each other, eight threads' worth apart: stored straight from the registers they kept the address
+    // unit busy 62 % of the wave cycles)
 #pragma unroll
     for (int y = 0; y < 3; y++) {
-        int32_t* __restrict__ row = out.o[y]; int32_t* __restrict__ col = row + out.total[y]; int32_t* __restrict__ val = col + out.total[y];
-        unsigned long long d = off[(size_t)y * gridDim.x + blockIdx.x] + ((excl >> (21 * y)) & 0x1fffffull);
+        uint32_t d = (uint32_t)((excl >> (21 * y)) & 0x1fffffull);
+        const uint32_t tot = (uint32_t)((total >> (21 * y)) & 0x1fffffull);
 #pragma unroll
         for (int t = 0; t < CP_ITEMS; t++)
-            if (v[y][t] > 0) { row[d] = (int32_t)kl.row(key[t]); col[d] = (int32_t)kl.cell(key[t]); val[d] = v[y][t]; d++; }
+            if (v[y][t] > 0) { s_row[d] = krow[t]; s_col[d] = kcol[t]; s_val[d] = v[y][t]; d++; }
+        __syncthreads();
+        int32_t* __restrict__ row = out.o[y]; int32_t* __restrict__ col = row + out.total[y]; int32_t* __restrict__ val = col + out.total[y];
+        const unsigned long long base = off[(size_t)y * gridDim.x + blockIdx.x];
+        for (uint32_t j = threadIdx.x; j < tot; j += CP_BLOCK) { row[base + j] = s_row[j]; col[base + j] = s_col[j]; val[base + j] = s_val[j]; }
+        __syncthreads();
     }
 }
 
