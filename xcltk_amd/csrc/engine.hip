@@ -14,12 +14,14 @@
 //                 processed together after the sweeps ((read, SNP) pairs dealt evenly over each wave's lanes); hits with
 //                 a base and "gap records" (SNPs inside N / D gaps) leave in two streams.
 //                 Fragments are appended through sharded cursors.
-//   finish      : basefc: radix sort (rocPRIM) over the (row, cell) bits, k_fold_heads / k_fold_emit_unsorted (distinct
-//                 UMIs of a run told apart by an LDS hash set) straight into COO; classic path: full sort + k_fold_emit.
-//                 pileup: sort of the hits with a base, k_first_base (first read per key, Bloom filter; k_first_long for
-//                 runs longer than 64), k_claim (gap records that hold a key earlier in fetch order), k_tally_rows, k_expand
-//                 (per-SNP filters, SNP -> region fan-out), k_hap_class / k_hap_sum / k_hap_count / k_hap_scatter (haplotype set algebra
-//                 by block scans), k_cp_* (ordered compaction); 128-bit keys: k_first_read.
+//   finish      : basefc: the partition fold of fold_partition.h (no sort); fallback: radix sort (rocPRIM) over the (row, cell) bits,
+//                 k_fold_heads / k_fold_emit_unsorted (distinct UMIs of a run told apart by an LDS hash set) straight into COO.
+//                 pileup: hits with a base sorted by row partition + LDS radix sort per item (fold_partition.h; fallback: rocPRIM),
+//                 k_first_base (first read per key, SNP-mask filter laid out along the sorted stream; k_first_long for runs longer
+//                 than 64), k_claim (gap records that hold a key earlier in fetch order), k_tally_rows, k_expand (per-SNP filters,
+//                 SNP -> region fan-out), region-level hits partitioned again and classified per item by an LDS hash set
+//                 (k_hap_items; fallback: sort + k_hap_class / k_hap_sum), k_hap_count / k_hap_scatter (AD / DP / OTH -> COO);
+//                 128-bit keys: k_first_read and the sorted path.
 //                 Copy-out on the copy stream (xck_finish_async).
 //
 // Integer / byte work only - HBM-bound, no MFMA.  See DESIGN.md for layouts, byte counts and measurements.

@@ -938,8 +938,8 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
 // The hits with a base leave k_join<pileup> in position order and a key's top field is the SNP's index in position order: the
 // stream is almost sorted by row already.  The radix sort took 8 passes over the 25 M pairs of configs[2] (4.0 of the pileup
 // fold's 11 ms); here the pairs are partitioned by row (one pass, the kernels above with z = row) into items of whole SNPs of at
-// most 2C pairs, and every item is sorted in LDS (bitonic network on (key, value)).  A SNP deeper than an item (UMI-less deep
-// pileups) returns PF_FALLBACK: the radix sort handles it.  Reference semantics: first read per (SNP, cell, UMI) in fetch order,
+// most 2C pairs, and every item is sorted in LDS (k_pf_radix_items below; the bitonic network k_pf_sort_items was the first form and
+// stays selectable).  A (SNP, cell group) deeper than an item (UMI-less deep pileups) returns PF_FALLBACK: the radix sort handles it.  Reference semantics: first read per (SNP, cell, UMI) in fetch order,
 // xcltk/baf/fc/mcount.py:109-127 - the order inside a key run is irrelevant to what follows (k_first_base takes the minimum).
 constexpr int PS_CAP = PF_CAP_MAX, PS_THREADS = 256;
 __global__ void k_pf_plan0(const uint32_t* __restrict__ S, uint32_t Z, int lgC, uint32_t* __restrict__ fs, uint32_t* __restrict__ ctr) {
