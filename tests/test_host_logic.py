@@ -45,6 +45,21 @@ def test_struct_layouts_match_header_sizes(lib):
     assert b"struct_size" in lib.xck_last_error(None)
 
 
+def test_ctypes_stats_mirror_matches_the_header(tmp_path):
+    """capi.Stats is filled by xck_get_stats through a plain pointer: its size and field offsets must be the C header's."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    fields = [n for n, _ in capi.Stats._fields_]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xck.h"\nint main(void) { printf("%zu", sizeof(xck_stats));\n'
+                   + "".join('printf(" %%zu", offsetof(xck_stats, %s));\n' % n for n in fields) + "return 0; }\n")
+    exe = tmp_path / "sz"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, "-o", str(exe), str(src)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got[0] == C.sizeof(capi.Stats)
+    assert got[1:] == [getattr(capi.Stats, n).offset for n in fields]
+
+
 def test_no_cpu_fallback(lib):
     """Without a HIP device the engine must refuse to exist (no silent CPU path)."""
     if lib.xck_device_count() > 0:
