@@ -13,6 +13,23 @@
  * different handles may be used from different host threads.  No global state, no callbacks.
  * There is NO CPU fallback: if no HIP device is usable xck_create() fails.
  */
+/* Environment.  A handle reads its knobs ONCE, at xck_create() (csrc/api.cpp Knobs::from_env): later changes of the
+ * environment do not reach a live handle, and no push / finish call looks at the environment.  None of them changes a result.
+ *   XCK_DEBUG_TIMING          (set)       stage timings and path decisions on stderr
+ *   XCK_FOLD=sort                         basefc fold by radix sort instead of the partition fold (tests; xck_stats.fold_path says which ran)
+ *   XCK_FOLD_C=<keys>                     page size of the partition folds (tests: small pages reach every path with small inputs)
+ *   XCK_FOLD_LGG=<l>                      at most 2^l cell groups per row in the basefc fold (default 6, or one per cell up to 512 cells)
+ *   XCK_FOLD_COPIES_LG=<l>                2^l copies of the level-1 counters / cursors (default 4)
+ *   XCK_FOLD_BUCKET_BLOCKS, XCK_FOLD_OVERLAP=0|1, XCK_FOLD_OVERLAP_BLOCKS      grids of the work-item pass, its second stream
+ *   XCK_FULL_SORT=1                       radix-sort fold over all key bits
+ *   XCK_PILEUP_SORT=radix                 library radix sorts for both pileup stages (the fallback path, forced)
+ *   XCK_PILEUP_HAP=sorted|values          region-level hits: sorted items + k_hap_class, or class in a value word instead of packed bits
+ *   XCK_PILEUP_ITEM_SORT=bitonic          LDS item sort by the bitonic network
+ *   XCK_PILEUP_LGG=<l>                    at most 2^l cell groups per SNP in the pileup partitions (default 10)
+ *   XCK_HIT_CAP0, XCK_HIT_SLACK           first capacity / head room of the hit accumulators (tests: reach the overflow-replay path)
+ *   XCK_PUSH_STAGE=0|1, XCK_PUSH_STAGE_BYTES   xck_push_batch: packed one-copy form always / never / below this size (default 2 MB)
+ * Decoder (read when a BAM is opened or once per process): XCK_THREADS, XCK_NUMA=0, XCK_INFLATE=zlib, XCK_CHUNK_BYTES,
+ * XCK_WRITE_THREADS (writer threads of xck_write_mtx), XCK_TEST_INTERN_LIMIT (tests). */
 #ifndef XCK_H
 #define XCK_H
 
@@ -23,7 +40,7 @@
 extern "C" {
 #endif
 
-#define XCK_ABI_VERSION 3   /* 3: xck_stats.fold_path / fold_fallbacks / pileup_sort_path / fold_refinements / pileup_sort2_path; 2: xck_config.n_excl_pairs / excl_region / excl_snp, xck_ingest_opts.pause_records (older, shorter structs are still accepted) */
+#define XCK_ABI_VERSION 3   /* 3: xck_stats.fold_path / fold_fallbacks / pileup_sort_path / fold_refinements / pileup_sort2_path; 2: xck_config.n_excl_pairs / excl_region / excl_snp, xck_ingest_opts.pause_records (older, shorter xck_config / xck_ingest_opts are still accepted: they carry struct_size.  xck_stats does not: xck_get_stats writes the whole ABI-3 struct, so its caller must be built against this header - check xck_abi_version() first) */
 
 /* status codes */
 #define XCK_OK            0

@@ -263,6 +263,20 @@ def ds_phasing(d):
         with open(os.path.join(d, "cellsnp_short", "cellSNP.tag.%s.mtx" % name), "w") as fp:
             fp.write("%%%%MatrixMarket matrix coordinate integer general\n%%\n%d\t%d\t%d\n" % (n_snp, n_cell, len(rr)))
             fp.write("".join("%d\t%d\t%d\n" % (r + 1, c + 1, M[r, c]) for r, c in zip(rr, cc)))
+    # a pileup with one SNP MORE than the phased list inside region long_c - behind the region's last phased SNP and without any
+    # depth: the reference computes its column mask over all columns, pairs it with the (shorter) SNP list by zip() and only
+    # fails when the two filtered lengths differ (baf/fc/phasing.py:43-52) - here they do not
+    os.makedirs(os.path.join(d, "cellsnp_surplus"), exist_ok=True)
+    write_vcf_gz(os.path.join(d, "cellsnp_surplus", "cellSNP.base.vcf.gz"),
+                 ["chr1\t%d\t.\t%s\t%s\t.\tPASS\tAD=%d;DP=%d;OTH=%d\n" % (p, ref[j], alt[j], AD[j].sum(), DP[j].sum(), OTH[j].sum()) for j, p in enumerate(snp_pos)]
+                 + ["chr1\t879000\t.\tA\tC\t.\tPASS\tAD=0;DP=0;OTH=0\n"])
+    with open(os.path.join(d, "cellsnp_surplus", "cellSNP.samples.tsv"), "w") as fp:
+        fp.write("".join(c + "\n" for c in cells))
+    for name, M in (("AD", AD), ("DP", DP), ("OTH", OTH)):
+        rr, cc = np.nonzero(M)
+        with open(os.path.join(d, "cellsnp_surplus", "cellSNP.tag.%s.mtx" % name), "w") as fp:
+            fp.write("%%%%MatrixMarket matrix coordinate integer general\n%%\n%d\t%d\t%d\n" % (n_snp + 1, n_cell, len(rr)))
+            fp.write("".join("%d\t%d\t%d\n" % (r + 1, c + 1, M[r, c]) for r, c in zip(rr, cc)))
     return dict(bams=["possorted.bam"], barcodes="barcodes.tsv")
 
 
@@ -327,6 +341,7 @@ CASES = [
     baf("phasing", "phasing_baf_allreg", cellsnp_dir="$D/cellsnp", output_all_reg=True, no_dup_hap=False, **_baf10x("phasing")),
     baf("phasing", "phasing_baf_off", output_all_reg=True, **_baf10x("phasing")),
     baf("phasing", "phasing_baf_short_pileup", cellsnp_dir="$D/cellsnp_short", output_all_reg=True, **_baf10x("phasing")),
+    baf("phasing", "phasing_baf_surplus_pileup", cellsnp_dir="$D/cellsnp_surplus", output_all_reg=True, **_baf10x("phasing")),
 ]
 
 
@@ -346,7 +361,7 @@ def main():
         if os.path.isdir(d):
             shutil.rmtree(d)
         info = fn(d)
-        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv", "cellsnp", "cellsnp_short", "ref_cells.tsv"}
+        keep = set(info["bams"]) | {b + ".bai" for b in info["bams"]} | {"regions.tsv", "snps.tsv", "snps.vcf", "sample_ids.txt", "barcodes.tsv", "cellsnp", "cellsnp_short", "cellsnp_surplus", "ref_cells.tsv"}
         keep_only(d, keep)
         info["md5"] = {os.path.relpath(os.path.join(dp, f), d): md5(os.path.join(dp, f)) for dp, _, fs in sorted(os.walk(d)) for f in sorted(fs)}
         meta[name] = info

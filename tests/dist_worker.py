@@ -46,7 +46,7 @@ from xcltk_amd.baf.fc.main import afc_wrapper  # noqa: E402
 from xcltk_amd.rdr.fc.main import fc_wrapper  # noqa: E402
 ret = fc_wrapper(**case["kwargs"]) if case["kind"] == "basefc" else afc_wrapper(**case["kwargs"])
 assert ret == 0
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:           # plain single-process run (test_gpu_golden.py's key-overflow case)
+if int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("XCK_DIST_FORCE", "0") in ("", "0"):   # plain single-process run (test_gpu_golden.py's key-overflow case)
     util.assert_dirs_equal(odir, exp)
     print("MULTIRANK_OK", name)
     sys.exit(0)
@@ -54,5 +54,6 @@ import torch.distributed as dist  # noqa: E402
 dist.barrier()
 if dist.get_rank() == 0:
     util.assert_dirs_equal(odir, exp)
+    print("MULTIRANK_BACKEND %s WORLD %d" % (dist.get_backend(), dist.get_world_size()))
     print("MULTIRANK_OK", name)
 dist.destroy_process_group()

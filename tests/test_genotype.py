@@ -106,3 +106,34 @@ def test_output_directory_adapters_read_the_reference_files():
     f, c, mats = bio.load_matrix_data(os.path.join(cdir, "c1_baf_allreg", "expected"))
     assert set(mats) == {"AD", "DP", "OTH"} and all(x.shape == (1000, 200) for x in mats.values())
     assert (mats["AD"] > mats["DP"]).nnz == 0                              # AD is part of DP
+
+
+@pytest.mark.parametrize("exc", [MemoryError, IndexError, OSError])
+def test_pileup_writer_failure_reaches_the_status_collective(exc, monkeypatch, tmp_path):
+    """Multi-rank pileup(): whatever the writer rank's failure is (MemoryError while the .mtx text is built, an index error, a full
+    disk), the rank still takes part in the status all-reduce the other ranks are waiting in, and only then raises."""
+    calls = []
+
+    class FakeDist(object):
+        active = True
+
+        def all_reduce_np(self, x, op="sum"):
+            calls.append((np.asarray(x).tolist(), op))
+            return np.asarray(x)
+
+    class FakeEngine(object):
+        closed = False
+
+        def close(self):
+            self.closed = True
+    eng = FakeEngine()
+    z = np.zeros(0, dtype=np.int32)
+    monkeypatch.setattr(G.fcc, "make_and_count", lambda *a, **k: (eng, {m: (z, z, z) for m in ("ad", "dp", "oth")}, FakeDist()))
+
+    def boom(*a, **k):
+        raise exc("writer failed")
+    monkeypatch.setattr(G, "_write_pileup_dirs", boom)
+    with pytest.raises(exc):
+        G.pileup(sam_fn=os.path.join(DS, "possorted.bam"), barcode_fn=os.path.join(DS, "barcodes.tsv"),
+                 snp_vcf_fn=os.path.join(DS, "cellsnp", "cellSNP.base.vcf.gz"), out_dir=str(tmp_path / "p"))
+    assert calls == [([1], "max")] and eng.closed

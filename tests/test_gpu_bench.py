@@ -61,6 +61,11 @@ def test_bench_line_and_two_rank_outputs(tmp_path):
         assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["end_to_end"]["records_in_bam"] == 3000000
         assert 3000000 <= d2["end_to_end"]["records_decoded"] < 3100000 and d2["end_to_end"]["records_timed"] < 3000000   # (blocks shared by two ranks' contigs are walked twice, counted once)
         assert d2["config"]["nnz"] == d["config"]["nnz"]
+        mg = d2["multi_gpu"]                                          # what a SCALE record shows of the exchange
+        assert mg["exchange"] == ("gather" if "--gather" in extra else "sharded-write") and mg["world_size"] == 2 and mg["ranks_in_collective"] == 2
+        assert mg["backend"].startswith("gloo") and "plan_units" in mg["planner"] and mg["units"] >= 24 and mg["bytes_exchanged"] > 0
+        assert [e["rank"] for e in mg["per_rank"]] == [0, 1] and all(e["decode_threads"] >= 1 and e["ingest_seconds"] > 0 and e["records_decoded"] > 0 for e in mg["per_rank"])
+        assert sum(e["regions"] for e in mg["per_rank"]) == 8000 and sum(e["units"] for e in mg["per_rank"]) == mg["units"]
         two = _read(work, 2)
         for f in FILES:
             assert two[f] == one[f], "%s differs between N=1 and N=2 (%s)" % (f, extra or "sharded write")
@@ -81,6 +86,22 @@ def test_bench_well_workload_line(tmp_path):
     assert d["cpu_baseline"]["gpu_rows_vs_oracle"].startswith("ok") and d["cpu_baseline"]["value_with_decode"] > 0
     hdr = open(os.path.join(work, "well", "out", "basefc", "matrix.mtx")).read().split("\n")[2].split("\t")
     assert hdr[0] == "8000" and hdr[1] == "24"
+    # the same list on two ranks (sharing the test box's GPU, gloo): every rank streams its contigs of every BAM, the ranks write the
+    # files together - byte-identical to the single-rank files; each rank checks the sampled contigs it owns against the oracle
+    from test_gpu_multirank import _free_port
+    env2 = dict(env, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in ([], ["--gather"]):
+        d2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
+                   "bench.py", "--gpus", "2", "--workload", "well", "--well-bams", "24", "--well-reads", "40000", "--genes", "8000", "--snps", "50000", "--cpu-sample", "200000"] + extra, env2)
+        assert d2["n_gpus"] == 2 and d2["config"]["nnz"] == d["config"]["nnz"] and d2["gpu_rows_vs_oracle"].startswith("ok")
+        assert d2["end_to_end"]["records"] == d["end_to_end"]["records"]       # (a BGZF block shared by two ranks' contigs is walked by both, its records are counted once)
+        assert sum(e["records_decoded"] for e in d2["multi_gpu"]["per_rank"]) >= d["end_to_end"]["records"]
+        mg = d2["multi_gpu"]
+        assert mg["exchange"] == ("gather" if extra else "sharded-write") and mg["ranks_in_collective"] == 2 and len(mg["per_rank"]) == 2
+        for f in FILES:
+            a, b = os.path.join(work, "well", "out", f), os.path.join(work, "well", "out_n2", f)
+            assert open(a, "rb").read() == open(b, "rb").read(), "%s differs between N=1 and N=2 (%s)" % (f, extra or "sharded write")
+        os.remove(os.path.join(work, "well", "out_n2", "basefc", "matrix.mtx"))
 
 
 

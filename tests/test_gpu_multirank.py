@@ -64,3 +64,22 @@ def test_pipeline_pileup_then_counting_two_ranks(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     tb = [ln for ln in r.stdout.splitlines() if "Error" in ln or "error" in ln or "File \"/" in ln]
     assert "MULTIRANK_OK pipeline_steps_1_3" in r.stdout, "\n".join(tb[-40:])
+
+
+@pytest.mark.parametrize("exchange", ["sharded", "gather"])
+@pytest.mark.parametrize("name", ["multibam_baf", "c1_basefc_default"])
+def test_rccl_backend_with_a_world_of_one(name, exchange, tmp_path):
+    """The RCCL (`nccl`) backend on the ONE GPU of the test box: XCK_DIST_FORCE=1 sends a single rank down the multi-rank path of the
+    front-ends - fc_common.Dist brings the communicator up with `device_id`, plans the units, and the results meet through the
+    collectives of the sharded writer (all-reduces of device tensors) or through BlockGatherer (all-gather of sizes + gather of the
+    blocks still resident in HBM).  Covers what a world of one can: librccl next to the pre-loaded HIP runtime, communicator
+    init, every collective call of the path, and output files equal to the reference's.  The process is a plain child (no torchrun,
+    no exec after a GPU call)."""
+    env = dict(os.environ, XCK_DIST_BACKEND="nccl", XCK_DIST_FORCE="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0", XCK_DIST_GATHER="1" if exchange == "gather" else "0")
+    env.pop("XCK_DEVICE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), name, str(tmp_path)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    tb = [ln for ln in r.stdout.splitlines() if "Error" in ln or "error" in ln or "File \"/" in ln]
+    assert "MULTIRANK_OK " + name in r.stdout, "\n".join(tb[-40:]) or r.stdout[-2000:]
+    assert "MULTIRANK_BACKEND nccl WORLD 1" in r.stdout

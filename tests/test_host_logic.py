@@ -329,16 +329,6 @@ def test_indexed_contig_subset_decode(ds, mask):
     assert sum(b["n_reads"] for b in want) == int(counts[np.array(mask)].sum())
 
 
-def test_linear_partition_contiguous_and_balanced():
-    from xcltk_amd.shard import linear_partition
-    from xcltk_amd.synth.soa import HG38_LENGTHS
-    for n in (1, 2, 3, 4, 8):
-        bins = linear_partition(HG38_LENGTHS, n)
-        assert sum(bins, []) == list(range(24)) and all(b for b in bins)
-        loads = [sum(HG38_LENGTHS[i] for i in b) for b in bins]
-        assert max(loads) <= 1.25 * sum(loads) / n
-
-
 def test_fast_inflate_matches_zlib_on_every_block():
     """inflate_fast.h vs zlib: every BGZF block of the golden BAMs plus 600 synthetic streams (stored, fixed and
     dynamic blocks, all levels / strategies, corrupted and truncated inputs must not write out of bounds)."""

@@ -3,7 +3,7 @@
 # `bench.py --resident-only`).  usage: tools/fold_variants.sh OUTDIR "VAR=VAL ..." "VAR=VAL ..." ...
 out=$1; shift
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$REPO" || exit 1
 i=0
 for v in "$@"; do
   i=$((i+1))

@@ -2,7 +2,7 @@
 # HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass as the MI355X guide prescribes) of this library's kernels (joins, both folds) on the
 # HBM-resident form of configs[2].  usage: tools/pmc_fold.sh OUTDIR -> OUTDIR/pmc_fold_summary.txt
 out=$1; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$REPO" || exit 1
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $out/$ctr -- python3 bench.py --resident-only --resident-passes 1 > $out/$ctr.json 2> $out/$ctr.err
 done

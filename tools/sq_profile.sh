@@ -2,7 +2,7 @@
 # SQ counters of the hand-written kernels on the HBM-resident form of configs[2] (bench.py --resident-only, one timed pass per counter
 # set; 8 SQ counters per rocprofv3 pass).  usage: tools/sq_profile.sh OUTDIR   -> OUTDIR/sq_summary.txt (+ the raw CSVs)
 out=$1; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$REPO" || exit 1
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU"; do

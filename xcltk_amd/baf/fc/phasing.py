@@ -73,9 +73,14 @@ def local_phasing(regions, snps, csp, ref_cells=None, debug_level=0):
         cols = np.flatnonzero((c_chrom == ch) & (csp.pos >= start) & (csp.pos < end + 1))
         AD, DP = AD_all[:, cols].toarray(), DP_all[:, cols].toarray()
         if AD.shape[1] > len(lst):
-            # more pileup columns than phased SNPs in the region: the reference pairs columns and SNPs by position in the list
-            # (baf/fc/phasing.py:47) and then fails on the mismatched shapes (:51-52)
-            raise ValueError("region '%s': %d SNPs in the phased list but %d in the cellsnp pileup" % (name, len(lst), AD.shape[1]))
+            # more pileup columns than phased SNPs in the region: the reference takes its column mask (depth > 0) over ALL columns,
+            # pairs it with the SNP list by zip() - the list's length - and multiplies the filtered matrices with a vector as long
+            # as the filtered list (baf/fc/phasing.py:43-52): that only works when both filters keep the same number, i.e. when
+            # the columns beyond the list's length are empty (golden case phasing_baf_surplus_pileup); otherwise numpy stops it
+            covered = np.asarray(DP.sum(axis=0) > 0).reshape(-1)
+            if int(covered.sum()) != int(covered[:len(lst)].sum()):
+                raise ValueError("region '%s': %d SNPs in the phased list but %d in the cellsnp pileup, %d of them covered beyond the list's length"
+                                 % (name, len(lst), AD.shape[1], int(covered[len(lst):].sum())))
         if AD.shape[1] < len(lst):
             # fewer columns: zip() pairs them with the FIRST SNPs of the list and the rest of the list leaves this region
             # (baf/fc/phasing.py:47; golden case phasing_baf_short_pileup)
@@ -83,6 +88,7 @@ def local_phasing(regions, snps, csp, ref_cells=None, debug_level=0):
                 excl_region.append(g); excl_snp.append(j)
             lst = lst[:AD.shape[1]]
         kept, flip = reg_local_phasing(ref_hap[lst], AD, DP, s_pos[lst])
+        kept = kept[:len(lst)]                                          # (a column mask longer than the list: zip() stops at the list's end)
         for j in lst[~kept].tolist():                                   # dropped from THIS region's list, whatever the phasing says
             excl_region.append(g); excl_snp.append(j)
         lst_kept = lst[kept]

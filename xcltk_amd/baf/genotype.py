@@ -123,19 +123,22 @@ def pileup(sam_fn=None, sam_list_fn=None, barcode_fn=None, sample_id_fn=None, sa
     snps = [(format_chrom(c), p, r, a, 0, 1) for c, p, r, a in cand]
     conf.reg_list = regions
     eng, coo, dist = fcc.make_and_count(conf, XCK_MODE_BAF, regions, snps, log_prefix="[pileup]", gather=True)   # rank 0 writes the directory
-    try:
-        if coo is not None:                                       # the matrices are views of the engine's pinned buffers: keep copies past close()
-            coo = {k: tuple(np.array(a) for a in v) for k, v in coo.items()}
-    finally:
-        eng.close()
     # Multi-GPU: only rank 0 holds the gathered matrices and writes the directory; every other rank WAITS for it (step 3 of
     # the pipeline reads this directory on every rank) and learns whether the writer failed, so that all ranks leave together.
+    # Whatever goes wrong between here and the status all-reduce - MemoryError while the .mtx text is built, an index error, a
+    # full disk - is held back until the all-reduce has run on this rank too: a rank that skips it leaves the others waiting
+    # for the backend's timeout.
     result, failure = (None, 0, 0), None
-    if coo is not None:
+    try:
         try:
+            if coo is not None:                                   # the matrices are views of the engine's pinned buffers: keep copies past close()
+                coo = {k: tuple(np.array(a) for a in v) for k, v in coo.items()}
+        finally:
+            eng.close()
+        if coo is not None:
             result = _write_pileup_dirs(out_dir, cand, conf.samples, coo, min_count, min_maf)
-        except (ValueError, IOError, OSError) as e:
-            failure = e
+    except Exception as e:                                        # noqa: BLE001 - re-raised below, after the collective
+        failure = e
     if dist.active:
         failed = int(dist.all_reduce_np(np.array([int(failure is not None)], dtype=np.int64), op="max")[0])   # also the barrier
         if failed and failure is None:

@@ -127,8 +127,8 @@ def pipeline_wrapper(label, sam_fn=None, sam_list_fn=None, barcode_fn=None, samp
             vcf, p_raw, p_new = pileup(sam_fn=sam_fn, sam_list_fn=sam_list_fn, barcode_fn=barcode_fn, sample_id_fn=sample_id_fn,
                                        sample_id=sample_id, snp_vcf_fn=snp_vcf_fn, out_dir=pileup_dir, mode=mode,
                                        cell_tag=cell_tag, umi_tag=umi_tag, ncores=ncores, min_count=min_count, min_maf=min_maf)
-        except (ValueError, IOError, OSError) as e:
-            error("pileup failed: %s" % e)
+        except Exception as e:                 # noqa: BLE001 - every rank of a multi-GPU run leaves step 1 the same way (pileup() spreads a failure to all ranks)
+            error("pileup failed: %s%s" % (type(e).__name__ + ": " if not isinstance(e, (ValueError, IOError, OSError)) else "", e))
             return -1
         if vcf is not None:
             info("pileup #SNP raw=%d; post-filtering=%d." % (p_raw, p_new))

@@ -31,6 +31,31 @@ int xck_device_count(void) {
 
 const char* xck_last_error(const xck_engine* e) { return e ? e->err.c_str() : get_thread_error(); }
 
+// the environment knobs of a handle (include/xck.h "Environment"), read here and nowhere on the push / finish path
+Knobs xck::Knobs::from_env() {
+    Knobs k;
+    auto str = [](const char* n) { const char* e = getenv(n); return e ? e : ""; };
+    auto num = [](const char* n, long long d) { const char* e = getenv(n); return e && *e ? atoll(e) : d; };
+    k.debug_timing = getenv("XCK_DEBUG_TIMING") != nullptr;
+    k.fold_sort = !strcmp(str("XCK_FOLD"), "sort");
+    k.fold_c = (int)num("XCK_FOLD_C", 0);
+    k.fold_lgg = (int)num("XCK_FOLD_LGG", -1);
+    k.fold_copies_lg = (int)num("XCK_FOLD_COPIES_LG", 4);
+    k.fold_bucket_blocks = (int)num("XCK_FOLD_BUCKET_BLOCKS", 256 * 4 * 2);
+    k.fold_overlap = (int)num("XCK_FOLD_OVERLAP", 1);
+    k.fold_overlap_blocks = (int)num("XCK_FOLD_OVERLAP_BLOCKS", 512);
+    k.full_sort = num("XCK_FULL_SORT", 0) != 0;
+    k.pileup_radix = !strcmp(str("XCK_PILEUP_SORT"), "radix");
+    k.pileup_hap = !strcmp(str("XCK_PILEUP_HAP"), "sorted") ? 1 : !strcmp(str("XCK_PILEUP_HAP"), "values") ? 2 : 0;
+    k.pileup_bitonic = !strcmp(str("XCK_PILEUP_ITEM_SORT"), "bitonic");
+    k.pileup_lgg = (int)num("XCK_PILEUP_LGG", 10);
+    k.hit_slack = std::max(0ll, num("XCK_HIT_SLACK", 65536));
+    k.hit_cap0 = std::max(64ll, num("XCK_HIT_CAP0", 1ll << 20));
+    k.push_stage = (int)num("XCK_PUSH_STAGE", -1);
+    k.push_stage_bytes = num("XCK_PUSH_STAGE_BYTES", 2ll << 20);
+    return k;
+}
+
 int xck_create(const xck_config* cfg_in, xck_engine** out) {
     if (!cfg_in || !out) { set_thread_error("null argument"); return XCK_E_ARG; }
     *out = nullptr;
@@ -43,6 +68,7 @@ int xck_create(const xck_config* cfg_in, xck_engine** out) {
     if (cfg->n_cells <= 0 || cfg->n_contigs < 0 || cfg->n_regions < 0 || cfg->n_snps < 0) { set_thread_error("invalid table sizes"); return XCK_E_ARG; }
     if ((cfg->n_regions > 0 && !cfg->regions) || (cfg->n_snps > 0 && !cfg->snps)) { set_thread_error("null table pointer"); return XCK_E_ARG; }
     xck_engine* e = new xck_engine();
+    e->knobs = Knobs::from_env();
     e->umi_bits = key_layout(cfg).ubits;
     e->mode = cfg->mode;
     e->n_cells = cfg->n_cells; e->n_contigs = cfg->n_contigs;
@@ -171,8 +197,8 @@ int xck_push_batch(xck_engine* e, const xck_batch* b) {
     if (!e || !b) return XCK_E_ARG;
     if (int rc = check_host_batch(e, b)) return rc;
     if (b->n_reads <= 0 || b->contig < 0 || e->n_impl <= 0) return push_trusted(e, b);     // nothing to copy / decode-only: engine_push reports
-    static const int force = getenv("XCK_PUSH_STAGE") ? atoi(getenv("XCK_PUSH_STAGE")) : -1;
-    static const long long small = getenv("XCK_PUSH_STAGE_BYTES") ? atoll(getenv("XCK_PUSH_STAGE_BYTES")) : (2ll << 20);
+    const int force = e->knobs.push_stage;
+    const long long small = e->knobs.push_stage_bytes;
     const size_t n = (size_t)b->n_reads;
     const size_t bytes = n * 27 + (size_t)(b->cig_off[n] - b->cig_off[0]) * 4 + ((e->mode & XCK_MODE_BAF) ? n * 4 + (b->seq_off[n] - b->seq_off[0]) : 0);
     const bool stage = force >= 0 ? force != 0 : (long long)bytes < small;

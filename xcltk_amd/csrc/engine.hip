@@ -47,9 +47,9 @@ constexpr int JOIN_BLOCK = 256;
 
 // hipGetLastError() after a launch also returns (and clears) an error that some EARLIER, unchecked runtime call of this thread
 // left behind; the launch sites clear it first, and XCK_DEBUG_TIMING reports what was there.
-static inline void clear_stale_error(const char* where) {
+static inline void clear_stale_error(const char* where, bool report = false) {
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess && getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] %s: cleared a stale HIP error left by an earlier call: %s [%d]\n", where, hipGetErrorString(e), (int)e);
+    if (e != hipSuccess && report) fprintf(stderr, "[xck] %s: cleared a stale HIP error left by an earlier call: %s [%d]\n", where, hipGetErrorString(e), (int)e);
 }
 #define HIP_TRY(expr)                                                                      \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                   \
@@ -342,7 +342,11 @@ __device__ __forceinline__ uint32_t set_slot(unsigned long long kk) {
     const uint32_t lo = (uint32_t)kk, hi = (uint32_t)(kk >> 32);
     uint32_t x = lo ^ ((hi << 9) | (hi >> 23));
     x ^= x >> 15;
-    return (__umul24(x, 0x9E3779u) >> 12) & (SLOTS - 1);
+    // (written as asm: only bits 12.. of the product are used, so the compiler narrows __umul24 to a plain 32-bit multiply -
+    // v_mul_lo_u32, a quarter-rate instruction on gfx9 - where the 24-bit form issues at full rate)
+    uint32_t p;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(p) : "v"(x), "v"(0x9E3779u));
+    return (p >> 12) & (SLOTS - 1);
 }
 
 template <class K, int MODE>
@@ -377,9 +381,20 @@ __device__ __forceinline__ void emit_nobase(const JoinArgs<K>& a, JoinSmem<K, MO
         else atomicExch(&a.ctl[CTL_OVERFLOW], 1ull);
     }
 }
+// phase stamps of the join kernel (build with -DXCK_STAMPS=1): cycles of wave 0 of every block between two stamps, kept in
+// registers and stored over the block's own TileMeta record (12 words, read in the prologue and dead since) - no atomics, no
+// extra traffic worth the name (the first version added 12 global atomics per block: 48 ms instead of 7.5).  The host sums
+// the records after the launch; finish_t() prints the table.  Slots: 0 tile record, 1 prologue loads + staging, 2 staging barrier,
+// 3-6 the four sweeps, 7 barrier before the flush, 8 flush: count, 9 flush: cursor atomic, 10 flush: stores, 11 tail.
+struct StampRec { long long t; uint32_t d[12]; };
+#if XCK_STAMPS
+#define XCK_STAMP(sr, slot) do { const long long t_ = clock64(); (sr)->d[slot] += (uint32_t)(t_ - (sr)->t); (sr)->t = t_; } while (0)
+#else
+#define XCK_STAMP(sr, slot) do {} while (0)
+#endif
 // split mode: both queues leave in ONE round (two cursor atomics in flight together, one set of barriers)
 template <class K, int MODE>
-__device__ __forceinline__ void flush_split(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm) {   // block-wide; all inserts are complete (barrier before)
+__device__ __forceinline__ void flush_split(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, StampRec* ts = nullptr) {   // block-wide; all inserts are complete (barrier before)
     const uint32_t tb = min(sm.count, (uint32_t)JoinSmem<K, MODE>::QCAP), tn = min(sm.ncount, (uint32_t)JoinSmem<K, MODE>::NQCAP);
     if (threadIdx.x < 2) {
         const uint32_t total = threadIdx.x ? tn : tb;
@@ -393,17 +408,19 @@ __device__ __forceinline__ void flush_split(const JoinArgs<K>& a, JoinSmem<K, MO
         if (threadIdx.x) sm.nbase = b; else sm.base = b;
     }
     __syncthreads();
+    XCK_STAMP(ts, 9);
     const unsigned long long db = sm.base, dn = sm.nbase;
     if (db != ~0ull) for (uint32_t t = threadIdx.x; t < tb; t += JOIN_BLOCK) { a.keys[db + t] = sm.keys()[t]; a.vals[db + t] = sm.vals()[t]; }
     if (dn != ~0ull) for (uint32_t t = threadIdx.x; t < tn; t += JOIN_BLOCK) { a.nkeys[dn + t] = (K)sm.nq_key[t]; a.nvals[dn + t] = sm.nq_val[t]; }
     __syncthreads();
     if (threadIdx.x == 0) { sm.count = 0; sm.ncount = 0; }
     __syncthreads();
+    XCK_STAMP(ts, 10);
 }
 
 // write the LDS set / queue to HBM as one contiguous fragment; block-wide call
 template <class K, int MODE>
-__device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm) {
+__device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm, StampRec* ts = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = sm.hkeys();
@@ -414,6 +431,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
         for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
         if (lane == 0) sm.wcnt[wave] = c;
         __syncthreads();
+        XCK_STAMP(ts, 8);
         if (threadIdx.x == 0) {
             uint32_t total = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
             unsigned long long b = 0;
@@ -426,6 +444,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
             sm.base = b; sm.count = 0;
         }
         __syncthreads();
+        XCK_STAMP(ts, 9);
         unsigned long long dst = sm.base;
         const bool fits = dst != ~0ull;
         for (int w = 0; w < wave; w++) dst += sm.wcnt[w];
@@ -441,6 +460,7 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
             dst += __popcll(m);
         }
         __syncthreads();
+        XCK_STAMP(ts, 10);
     } else {
         __syncthreads();
         const uint32_t total = min(sm.count, (uint32_t)JoinSmem<K, MODE>::QCAP);
@@ -474,6 +494,83 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
 // broadcast reads of the staged slice); each lane only compares its own read against them - no per-lane index lookups,
 // no divergent loop counts.  A wave that holds a read left of the tile's first read (unsorted input) scans from the
 // contig's first region, so sortedness is a speed assumption, never a correctness one.
+// minimum / maximum of one int32 per lane over the 64 lanes of a wave (all lanes active): four row_shr steps inside the rows
+// of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 - lane 63 then holds the result.  Six DPP
+// VALU ops and one v_readlane; no LDS traffic (a __shfl_xor butterfly is six ds_bpermute round trips).
+template <bool MAX>
+__device__ __forceinline__ int32_t wave_minmax(int32_t v) {
+    constexpr int32_t ID = MAX ? std::numeric_limits<int32_t>::min() : std::numeric_limits<int32_t>::max();
+#define XCK_DPP_STEP(ctrl, rows) { const int32_t t_ = __builtin_amdgcn_update_dpp(ID, v, ctrl, rows, 0xf, false); v = MAX ? max(v, t_) : min(v, t_); }
+    XCK_DPP_STEP(0x111, 0xf) XCK_DPP_STEP(0x112, 0xf) XCK_DPP_STEP(0x114, 0xf) XCK_DPP_STEP(0x118, 0xf)   // row_shr:1,2,4,8
+    XCK_DPP_STEP(0x142, 0xa) XCK_DPP_STEP(0x143, 0xc)                                                       // row_bcast:15, row_bcast:31
+#undef XCK_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#ifndef XCK_JOIN_WALK
+#define XCK_JOIN_WALK 1
+#endif
+#if XCK_JOIN_WALK == 1
+// The walk is done 64 regions at a time with the REGIONS in the lanes: lane l loads start / end of region kb + l (one
+// conflict-free LDS read per array) and asks whether the region can meet any read of the wave at all - start below the
+// largest read end, end beyond the smallest read position (two DPP reductions per sweep).  One ballot gives the candidate
+// regions of the chunk; only those are visited, their start / end / row taken from the lanes by v_readlane (no memory
+// round trip, scalar operands for the per-read compare).  The first version visited every region from the tile's first
+// candidate on, each visit two dependent LDS reads + readfirstlane: with a long gene holding the running maximum of the
+// ends, dozens of regions that no read of the wave touches were walked by every wave - ~300 cycles of latency each.
+template <class K, int MODE>
+__device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r,
+                                                 const int32_t lb, const int32_t n_st, const int32_t p_first, StampRec* ts = nullptr, int sweep = 0) {   // staged slice: regions [lb, lb + n_st); scalars
+    uint32_t n_acc = 0;
+    if (!__ballot(r.ok)) return 0;                                   // no read of this wave passed the filter (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    const int32_t reg_lo = __builtin_amdgcn_readfirstlane(d.reg_lo), reg_hi = __builtin_amdgcn_readfirstlane(d.reg_hi);
+    const int32_t wmin = wave_minmax<false>(r.ok ? r.pos : std::numeric_limits<int32_t>::max());
+    const int32_t wmax = wave_minmax<true>(r.ok ? r.endpos : std::numeric_limits<int32_t>::min());
+    // A region that CONTAINS the whole wave (start <= smallest position, end >= largest read end - two scalar compares; genes are
+    // kilobases long, the 64 reads of a wave span a few hundred bases at most, so this is the usual case) takes every read of the
+    // wave that passed the filter: all its aligned bases are inside (included_len's first shortcut), m == n, the fraction is 1.
+    // What is left per read is the key and the set insert; the overlap / include arithmetic runs only for regions whose
+    // boundary falls inside the wave.  (A read whose fetch span is not its CIGAR's - unmapped flag - rules the shortcut out.)
+    const bool all_span = !__ballot(r.ok && !r.span_is_cigar);
+    const bool full_ok = r.ok && (a.f.frac_mode ? r.n_al > 0 : r.n_al >= a.f.min_inc_len);
+    const K kbase = a.kl.make(0u, (uint32_t)r.cell, r.umi);
+    // p_first = position of the tile's first read: a read left of it means unsorted input, the list is then walked from its start
+    for (int32_t kb = __ballot(r.ok && r.pos < p_first) ? reg_lo : lb; kb < reg_hi; kb += 64) {
+        const int32_t k = kb + lane;
+        const uint32_t rel = (uint32_t)(k - lb);
+        const bool in = k < reg_hi, staged = rel < (uint32_t)n_st;
+        int32_t s0 = std::numeric_limits<int32_t>::max(), e0 = std::numeric_limits<int32_t>::min(), row = 0;
+        if (in) { s0 = staged ? sm.st_a[rel] : as_global(a.reg_s0)[k]; e0 = staged ? sm.st_b[rel] : as_global(a.reg_e0)[k]; }
+        const bool last = __ballot(!in || s0 >= wmax) != 0;          // sorted by start: no read of the wave reaches a region after this chunk
+        unsigned long long cand = __ballot(in && s0 < wmax && e0 > wmin);
+        if (cand && in) row = staged ? sm.st_c[rel] : as_global(a.reg_row)[k];
+#if XCK_STAMPS == 2
+        if (sweep == 0) { XCK_STAMP(ts, 4); ts->d[11] += (uint32_t)__popcll(cand); }      // (slot 11: candidate regions of sweep 0)
+#endif
+        while (cand) {
+            const int b = (int)__builtin_ctzll(cand); cand &= cand - 1;
+            const int32_t rs0 = __builtin_amdgcn_readlane(s0, b), re0 = __builtin_amdgcn_readlane(e0, b), rrow = __builtin_amdgcn_readlane(row, b);
+            const K krow = K((uint32_t)rrow) << (a.kl.cbits + a.kl.ubits);      // wave-uniform: scalar shift
+            if (all_span && wmin >= rs0 && wmax <= re0) {             // the region contains every read of the wave
+                if (full_ok) { emit<K, MODE>(a, sm, kbase | krow, 0); n_acc++; }
+                continue;
+            }
+            if (!(r.ok && r.pos < re0 && r.endpos > rs0)) continue;  // htslib fetch overlap
+            const int32_t m = included_len(a, d, sm, r, rs0, re0);
+            if (a.f.frac_mode) {
+                if (r.n_al <= 0) continue;
+                // m == n gives exactly 1.0, never below a threshold in (0,1): skip the fp64 divide
+                if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue;   // IEEE double, as m / float(n)
+            } else if (m < a.f.min_inc_len) continue;
+            emit<K, MODE>(a, sm, kbase | krow, 0);
+            n_acc++;
+        }
+        if (last) break;
+    }
+    return n_acc;
+}
+#else
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r,
                                                  const int32_t lb, const int32_t n_st, const int32_t p_first) {   // staged slice: regions [lb, lb + n_st); scalars
@@ -500,6 +597,7 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
     }
     return n_acc;
 }
+#endif
 
 
 // position of SNP k (staged slice first)
@@ -613,12 +711,12 @@ template <class K, int MODE>
 __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     __shared__ JoinSmem<K, MODE> sm;
     const int tid = threadIdx.x, lane = tid & 63;
+    StampRec t_s0;
 #if XCK_STAMPS
-    long long t_s0 = clock64();
-#define STAMP(slot) do { long long t_ = clock64(); if (tid == 0) atomicAdd(&a.ctl[4 + (slot)], (unsigned long long)(t_ - t_s0)); t_s0 = t_; } while (0)
-#else
-#define STAMP(slot) do {} while (0)
+    for (int q = 0; q < 12; q++) t_s0.d[q] = 0;
+    t_s0.t = clock64();
 #endif
+#define STAMP(slot) XCK_STAMP(&t_s0, slot)
     // ---- prologue: one record from k_tile_meta, then ONE round of independent loads ----
     const XCK_GLOBAL TileMeta* mp = as_global(a.meta) + blockIdx.x;
     const uint32_t c_lo = mp->c_lo, cg_n = mp->cg_n;
@@ -680,6 +778,9 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
         const int i = tile0 + j * JOIN_BLOCK + tid;
         const RawRead cur = W[j];
         ReadInfo r = load_read<K, MODE>(a, d, sm, cur);
+#if XCK_STAMPS == 2
+        if (j == 0) { uint32_t x_ = (uint32_t)r.endpos ^ (uint32_t)r.n_al; asm volatile("" :: "v"(x_)); STAMP(3); }   // (the summary is complete)
+#endif
         if constexpr (MODE == XCK_MODE_BAF) {
             // read x SNP join, SNP-major: the 64 reads of a wave are (in a sorted BAM) a narrow position range, so the wave
             // walks the few SNPs of that range TOGETHER - position of SNP k is wave-uniform, every lane only asks "inside my
@@ -769,18 +870,21 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
             acc += c + n_gap;
         } else {
             if (r.ok) uor |= r.umi;
-            acc += join_regions<K, MODE>(a, d, sm, r, u_lb, u_nst, u_p0);   // wave-uniform call: the sweep over the regions is shared by all 64 lanes
+            acc += join_regions<K, MODE>(a, d, sm, r, u_lb, u_nst, u_p0, &t_s0, j);   // wave-uniform call: the sweep over the regions is shared by all 64 lanes
         }
         // Flush points are fixed at compile time, never decided from sm.count: a count-based decision read
         // after the barrier races with the next sweep's inserts (threads could disagree and split at the
         // barriers inside flush()).  A set / queue that saturates between two flush points spills through
         // emit_global(), which is always correct.
+#if XCK_STAMPS == 2
+        if (j == 0) STAMP(5); else STAMP(6);                          // sweep 0 in three parts (3 read summary, 4 chunk scan, 5 candidates), 6 = sweeps 1-3
+#else
+        STAMP(3 + j);
+#endif
         if ((j + 1) % FLUSH_EVERY == 0 || j + 1 == TILE_ITEMS) {
-            STAMP(3);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: global prefetches stay in flight
-            STAMP(4);
-            if constexpr (JoinSmem<K, MODE>::SPLIT) flush_split<K, MODE>(a, sm); else flush<K, MODE>(a, sm);
-            STAMP(5);
+            STAMP(7);
+            if constexpr (JoinSmem<K, MODE>::SPLIT) flush_split<K, MODE>(a, sm, &t_s0); else flush<K, MODE>(a, sm, &t_s0);
         }
     }
     // accepted (read, region|SNP) pairs before the LDS de-duplication: the algorithmic unit of the join
@@ -804,7 +908,13 @@ __global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
     }
     if (tid == 0) { acc = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
                     if (acc) atomicAdd(&a.ctl[ctl_accepted(JOIN_SHARD)], (unsigned long long)acc); }
-    STAMP(6);
+#if XCK_STAMPS != 2
+    STAMP(11);
+#endif
+#if XCK_STAMPS
+    if (tid == 0) { uint32_t* o = (uint32_t*)(a.meta + blockIdx.x); for (int q = 0; q < 12; q++) o[q] = t_s0.d[q]; }
+    static_assert(sizeof(TileMeta) == 48, "the stamp record reuses the tile record");
+#endif
 }
 
 // exclusive scan of one uint32 per thread over a 256-thread block; returns block total in `total`
@@ -1671,6 +1781,8 @@ struct EngineImpl {
     bool copy_timed = false, copy_pending = false;
     xck_stats st{};
     int64_t n_join_launches = 0;
+    bool fold_failed = false;             // xck_finish returned an error from inside a fold: only xck_reset makes the handle usable again
+    unsigned long long stamp_sum[12] = {0}; int stamp_tiles = 0; float stamp_ms = 0;   // XCK_STAMPS builds: phase cycles of the last join launch
     // workspace + results
     Arena ws1, ws2;
     int32_t* h_res[4] = {nullptr, nullptr, nullptr, nullptr}; size_t h_res_cap[4] = {0, 0, 0, 0}; size_t res_nnz[4] = {0, 0, 0, 0};
@@ -1811,7 +1923,7 @@ static int res_reserve(EngineImpl* im, int m, size_t nnz) {
 }
 
 // per-shard head room added to every capacity guess (XCK_HIT_SLACK: test knob that makes the overflow / replay path easy to reach)
-static inline size_t hit_slack() { const char* e = getenv("XCK_HIT_SLACK"); return e ? (size_t)std::max(0ll, atoll(e)) : 65536; }
+static inline size_t hit_slack(const EngineImpl* im) { return (size_t)im->eng->knobs.hit_slack; }
 static inline bool split_mode(const EngineImpl* im) { return XCK_BAF_SPLIT && im->mode == XCK_MODE_BAF && im->key_bits == 64; }
 
 static int ensure_hits(EngineImpl* im, size_t need) {           // need = elements per shard
@@ -1878,7 +1990,7 @@ static int launch_join_t(EngineImpl* im) {
     a.keys = (K*)im->d_keys; a.vals = im->d_vals; a.cap = im->hit_cap; a.ctl = im->d_ctl;
     a.nkeys = (K*)im->d_nkeys; a.nvals = im->d_nvals;
     dim3 grid(tiles), block(JOIN_BLOCK);
-    clear_stale_error("launch_join");
+    clear_stale_error("launch_join", im->eng->knobs.debug_timing);
     HIP_TRY(hipEventRecord(im->ev0, im->s_comp));
     const dim3 mgrid((tiles + 255) / 256), mblock(256);
     if (im->mode == XCK_MODE_BASEFC) {
@@ -1902,6 +2014,14 @@ static int complete_pending(EngineImpl* im) {
         HIP_TRY(hipStreamSynchronize(im->s_comp));
         float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, im->ev0, im->ev1));
         im->st.ms_join += ms; im->st.ms_device += ms; im->n_join_launches++;
+#if XCK_STAMPS
+        { int32_t tiles = 0; for (auto& b : im->inflight) tiles += (b.n + TILE - 1) / TILE;
+          std::vector<uint32_t> h((size_t)tiles * 12);
+          HIP_TRY(hipMemcpy(h.data(), im->d_meta, h.size() * 4, hipMemcpyDeviceToHost));
+          for (int q = 0; q < 12; q++) im->stamp_sum[q] = 0;
+          for (size_t t = 0; t < (size_t)tiles; t++) for (int q = 0; q < 12; q++) im->stamp_sum[q] += h[t * 12 + q];
+          im->stamp_tiles = tiles; im->stamp_ms = ms; }
+#endif
         if (im->h_ctl[CTL_OVERFLOW]) {                       // some fragment did not fit: grow, rewind, replay
             unsigned long long mx = 0;
             for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, std::max(im->h_ctl[ctl_cursor(sh)], im->h_ctl[ctl_ncursor(sh)]));
@@ -1932,7 +2052,7 @@ static int launch_queue(EngineImpl* im, int slot_idx, int shared_slot = -1) {
       for (int sh = 0; sh < NSHARD; sh++) mx = std::max(mx, std::max(im->cur[sh], im->ncur[sh]));
       // first guess: 1.25 keys per queued read (after the LDS de-duplication a 10x run leaves ~0.8); a launch that needs
       // more sets the overflow flag and is replayed into grown buffers, and the capacity is kept for the next pass
-      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / 4 / NSHARD + hit_slack()); if (rc) return rc; }
+      rc = ensure_hits(im, mx + (size_t)im->queued_reads * 5 / 4 / NSHARD + hit_slack(im)); if (rc) return rc; }
     im->inflight.swap(im->queue); im->queue.clear();
     im->inflight_reads = im->queued_reads; im->queued_reads = 0;
     im->inflight_slot = slot_idx;
@@ -1950,8 +2070,11 @@ int engine_push(xck_engine* e, const xck_batch* b, bool device_resident) {
     im->st.n_batches++; im->st.n_reads += b->n_reads;
     if (b->n_reads <= 0 || b->contig < 0) return 0;
     if (b->contig >= (int)im->ctab.size()) { e->err = "batch contig out of range"; return XCK_E_ARG; }
-    if (!b->pos || !b->flag || !b->mapq || !b->cell || !b->umi || !b->cig_off || (!b->cigar)) { e->err = "null batch array"; return XCK_E_ARG; }
-    if (im->mode == XCK_MODE_BAF && (!b->seq_off || !b->seq)) { e->err = "BAF mode needs seq arrays"; return XCK_E_ARG; }
+    // (host batches: a null cigar / seq pointer is fine when its offset range is empty - the same rule as xck_push_batch's check and
+    // its packed form; device-resident batches: the offsets live in HBM, so the pointers must be there)
+    if (!b->pos || !b->flag || !b->mapq || !b->cell || !b->umi || !b->cig_off) { e->err = "null batch array"; return XCK_E_ARG; }
+    if (!b->cigar && (device_resident || b->cig_off[b->n_reads] != b->cig_off[0])) { e->err = "null batch array"; return XCK_E_ARG; }
+    if (im->mode == XCK_MODE_BAF && (!b->seq_off || (!b->seq && (device_resident || b->seq_off[b->n_reads] != b->seq_off[0])))) { e->err = "BAF mode needs seq arrays"; return XCK_E_ARG; }
     HIP_TRY(hipSetDevice(im->device));
     const ContigTab& t = im->ctab[b->contig];
     bool has_targets = im->mode == XCK_MODE_BASEFC ? t.n_reg > 0 : t.n_snp > 0;
@@ -2236,7 +2359,7 @@ static int fold_coo(EngineImpl* im, Arena& ws, const K* keys, size_t n, KeyLayou
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, im->s_comp, (const unsigned long long*)(im->d_ctl + CTL_GIANT), im->d_hctl + CTL_GIANT, 1);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(im->s_comp));
-            if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] hash fold: n=%zu nnz=%zu ubits=%d cbits=%d giant=%llu\n", n, total, kl.ubits, kl.cbits, im->h_ctl[CTL_GIANT]);
+            if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] hash fold: n=%zu nnz=%zu ubits=%d cbits=%d giant=%llu\n", n, total, kl.ubits, kl.cbits, im->h_ctl[CTL_GIANT]);
             if (im->h_ctl[CTL_GIANT]) return FOLD_GIANT;
             return copy_out(im, m, d_o, total);
         }
@@ -2279,7 +2402,7 @@ static int pack_shards(EngineImpl* im, K* dst_keys, uint64_t* dst_vals) {
 
 template <class K>
 static int finish_t(EngineImpl* im) {
-    clear_stale_error("finish");
+    clear_stale_error("finish", im->eng->knobs.debug_timing);
     KeyLayout<K> kl; kl.ubits = im->ubits; kl.cbits = im->cbits;
     const size_t n = im->cursor;
     for (int m = 0; m < 4; m++) { im->res_nnz[m] = 0; im->d_res[m] = nullptr; }
@@ -2287,8 +2410,11 @@ static int finish_t(EngineImpl* im) {
       im->st.n_hits = acc; }                          // accepted pairs (before the LDS de-duplication)
     im->st.n_hits_unique = (int64_t)(n + im->ncursor);   // keys that reached HBM
 #if XCK_STAMPS
-    fprintf(stderr, "[stamps mode=%d] desc=%llu extent=%llu stage=%llu sweeps=%llu barrier=%llu flush=%llu tail=%llu (cycles summed over blocks)\n", im->mode,
-            im->h_ctl[4], im->h_ctl[5], im->h_ctl[6], im->h_ctl[7], im->h_ctl[8], im->h_ctl[9], im->h_ctl[10]);
+    { static const char* nm[12] = {"record", "prologue", "stage_barrier", "sweep0", "sweep1", "sweep2", "sweep3", "flush_barrier", "flush_count", "flush_cursor", "flush_stores", "tail"};
+      unsigned long long tot = 0; for (int q = 0; q < 12; q++) tot += im->stamp_sum[q];
+      fprintf(stderr, "[stamps mode=%d] last join launch: %d tiles, %.3f ms; cycles of wave 0 per tile (share of the block's life):", im->mode, im->stamp_tiles, im->stamp_ms);
+      for (int q = 0; q < 12; q++) fprintf(stderr, " %s=%.0f (%.1f%%)", nm[q], (double)im->stamp_sum[q] / std::max(1, im->stamp_tiles), 100.0 * im->stamp_sum[q] / std::max(1ull, tot));
+      fprintf(stderr, " | total=%.0f\n", (double)tot / std::max(1, im->stamp_tiles)); }
 #endif
     if (n == 0) return 0;
     Timer tm{im, im->ev0, im->ev1};
@@ -2301,7 +2427,7 @@ static int finish_t(EngineImpl* im) {
         // 64-bit keys: the partition fold (fold_partition.h - no sort); it hands back PF_FALLBACK for the inputs it cannot place
         // (one (row, cell) with more keys than a work item holds, ...), and the radix-sort fold below then takes over
         if constexpr (sizeof(K) == 8) {
-            const bool want_sort = getenv("XCK_FOLD") && !strcmp(getenv("XCK_FOLD"), "sort");   // (read per finish: the tests switch it)
+            const bool want_sort = im->eng->knobs.fold_sort;
             if (!want_sort) {
                 if ((rc = tm.start())) return rc;
                 KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
@@ -2314,7 +2440,7 @@ static int finish_t(EngineImpl* im) {
                 }
                 if (rc != PF_FALLBACK) return rc;
                 im->fold_fallbacks++;
-                if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: handing over to the radix-sort fold\n");
+                if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] partition fold: handing over to the radix-sort fold\n");
             }
         }
         im->fold_path = 2;
@@ -2335,7 +2461,7 @@ static int finish_t(EngineImpl* im) {
         const int top_fc = kl.ubits + im->cbits + im->rbits;
         // 64-bit keys: the radix sort only orders (row, cell) - 4 passes instead of 7 - and the fold tells the UMIs of a run
         // apart with an LDS hash set; a run too long for that (FOLD_GIANT) is redone on fully sorted keys
-        static const bool full_sort = getenv("XCK_FULL_SORT") && atoi(getenv("XCK_FULL_SORT"));
+        const bool full_sort = im->eng->knobs.full_sort;
         // (rocPRIM 4.2 returns garbage for begin_bit > 0 with end_bit = 64 - profiles/experiments/sortpart.hip - so keys that could not be
         // squeezed below 63 bits take the classic path)
         const bool partial = sizeof(K) == 8 && !full_sort && top_fc <= 62;
@@ -2370,7 +2496,7 @@ static int finish_t(EngineImpl* im) {
         if constexpr (sizeof(K) == 8) {
             // (default since the items are sorted by an LDS radix sort: 1.7 ms at configs[2] against 2.3 ms for pack + rocPRIM's eight passes;
             // XCK_PILEUP_SORT=radix forces the library sort)
-            const bool want_part = !(getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "radix"));
+            const bool want_part = !im->eng->knobs.pileup_radix;
             if (want_part) {
                 KeyLayout<unsigned long long> kl8; kl8.ubits = im->ubits; kl8.cbits = im->cbits;
                 rc = pileup_partition_sort(im, im->ws2, true, kl8, (const unsigned long long*)im->d_keys, (const uint64_t*)im->d_vals, im->hit_cap, im->cur,
@@ -2452,11 +2578,11 @@ static int finish_t(EngineImpl* im) {
             // 64-bit keys: k_expand writes its 16 slices at a fixed stride and the partition sort (fold_partition.h) orders them; when it hands
             // back PF_FALLBACK (a (region, cell group) deeper than an item), or with 128-bit keys, k_expand writes the slices back to back and
             // the library radix sort orders them.  XCK_PILEUP_SORT=radix forces the latter.
-            const bool try_part = sizeof(K) == 8 && !(getenv("XCK_PILEUP_SORT") && !strcmp(getenv("XCK_PILEUP_SORT"), "radix"));
+            const bool try_part = sizeof(K) == 8 && !im->eng->knobs.pileup_radix;
             const size_t n2s = try_part ? std::max<size_t>((size_t)XSHARD * cap2, n2) : n2;      // entries of the unsorted buffers
             const size_t tmpb2 = sort_tmp_bytes<K, V2>(n2, top);
             const size_t nb2 = (n2 + CP_TILE - 1) / CP_TILE;
-            const size_t part_bytes = try_part ? partition_sort_scratch(n2, (size_t)std::max(im->n_regions, 1)) : 0;
+            const size_t part_bytes = try_part ? partition_sort_scratch(im, n2, (size_t)std::max(im->n_regions, 1)) : 0;
             if ((rc = arena_begin(im, im->ws2, (n2s + n2 + 8) * (sizeof(K) + sizeof(V2)) + n2 + 4 * (n2 + 8) * 4 + std::max(tmpb2, part_bytes) + 3 * (nb2 * 12 + n2 * 12) + ((n2 + FD_TILE - 1) / FD_TILE) * 12 + (n2 / RUN_WALK + 2) * 8 + (1 << 16)))) return rc;
             K* k2 = im->ws2.get<K>(n2s + 8); K* k2b = im->ws2.get<K>(n2); V2* v2 = im->ws2.get<V2>(n2s); V2* v2b = im->ws2.get<V2>(n2);
             uint8_t* cls = im->ws2.get<uint8_t>(n2);
@@ -2472,9 +2598,8 @@ static int finish_t(EngineImpl* im) {
                     for (int sh = 0; sh < XSHARD; sh++) xb.base[sh] = (unsigned long long)sh * cap2;
                     // (XCK_PILEUP_HAP=sorted: sort the items completely and run k_hap_class / k_hap_sum on them, as after the radix sort;
                     //  XCK_PILEUP_HAP=values: keep the haplotype class in a value word beside the key, as when the UMI field has no two free bits)
-                    const char* hap_env = getenv("XCK_PILEUP_HAP");
-                    const bool hap_items = !(hap_env && !strcmp(hap_env, "sorted"));
-                    const int pack_shift = hap_items && !(hap_env && !strcmp(hap_env, "values")) && used2 + 2 <= im->ubits ? used2 : -1;
+                    const bool hap_items = im->eng->knobs.pileup_hap != 1;
+                    const int pack_shift = hap_items && im->eng->knobs.pileup_hap != 2 && used2 + 2 <= im->ubits ? used2 : -1;
                     hipLaunchKernelGGL((k_expand<K, true, V2>), dim3(gs), dim3(JOIN_BLOCK), 0, im->s_comp, alt, al, (long long)n, kl, im->d_tally, im->d_snp_info,
                                        im->sf, im->d_csr_off, im->d_csr_reg, k2, v2, im->d_ctl, xb, pack_shift);
                     HIP_TRY(hipGetLastError());
@@ -2533,9 +2658,12 @@ int engine_finish_async(xck_engine* e) {
     int rc = launch_queue(im, -1); if (rc) return rc;
     rc = complete_pending(im); if (rc) return rc;
     if (!im->finished) {
+        // a finish that failed half-way may have overwritten the accumulated keys (the folds reuse the shard slices as scratch): it
+        // cannot be tried again on them
+        if (im->fold_failed) { e->err = "an earlier xck_finish failed inside the fold: the accumulated hits are gone (call xck_reset)"; return XCK_E_STATE; }
         im->copy_timed = false;
         rc = im->key_bits == 64 ? finish_t<uint64_t>(im) : finish_t<u128>(im);
-        if (rc) return rc;
+        if (rc) { im->fold_failed = true; hipStreamSynchronize(im->s_comp); hipStreamSynchronize(im->s_copy); return rc; }   // (nothing of the failed fold is still running when the arenas are reused)
         im->finished = true; im->copy_pending = true;
     }
     return 0;
@@ -2546,7 +2674,7 @@ int engine_finish(xck_engine* e, xck_result* out) {
     if (!im) { e->err = "decode-only handle: no GPU engine behind it"; return XCK_E_STATE; }
     int rc = engine_finish_async(e); if (rc) return rc;
     if (im->copy_pending) {
-        static const bool dbg = getenv("XCK_DEBUG_TIMING") != nullptr;
+        const bool dbg = im->eng->knobs.debug_timing;
         const auto t0_ = std::chrono::steady_clock::now();
         const hipError_t q_ = dbg ? hipStreamQuery(im->s_copy) : hipSuccess;
         HIP_TRY(hipStreamSynchronize(im->s_copy));
@@ -2589,7 +2717,7 @@ int engine_reset(xck_engine* e) {
     if (im->copy_pending) { HIP_TRY(hipStreamSynchronize(im->s_copy)); im->copy_pending = false; }
     HIP_TRY(hipMemsetAsync(im->d_ctl, 0, CTL_WORDS * sizeof(unsigned long long), im->s_comp));
     HIP_TRY(hipStreamSynchronize(im->s_comp));
-    im->cursor = 0; im->ncursor = 0; im->finished = false;
+    im->cursor = 0; im->ncursor = 0; im->finished = false; im->fold_failed = false;
     for (int i = 0; i < CTL_WORDS; i++) im->h_ctl[i] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { im->cur[sh] = 0; im->ncur[sh] = 0; }
     int kb = im->key_bits, ub = im->ubits;
@@ -2659,7 +2787,7 @@ int engine_create(const xck_config* cfg, xck_engine* e) {
     HIP_TRY(hipHostMalloc((void**)&im->h_ctl, CTL_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
     memset(im->h_ctl, 0, CTL_WORDS * sizeof(unsigned long long));
     HIP_TRY(hipHostGetDevicePointer((void**)&im->d_hctl, im->h_ctl, 0));
-    rc = ensure_hits(im, getenv("XCK_HIT_CAP0") ? (size_t)std::max(64ll, atoll(getenv("XCK_HIT_CAP0"))) : (size_t)1 << 20); if (rc) return rc;   // (test knob)
+    rc = ensure_hits(im, (size_t)e->knobs.hit_cap0); if (rc) return rc;   // (XCK_HIT_CAP0: test knob)
     return 0;
 }
 

@@ -730,7 +730,6 @@ static int pf_scan(EngineImpl* im, uint32_t* data, size_t n, uint32_t* bsum, uin
     HIP_TRY(hipGetLastError());
     return 0;
 }
-static inline int pf_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static inline int pf_bucket_lds(int sb) { return PF_SLOTS * 8 + (1 << sb) / 8; }
 
 // basefc fold of the n keys in the shard slices of im->d_keys -> result matrix 0.  0 = done, PF_FALLBACK = take the radix path
@@ -739,7 +738,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     typedef unsigned long long K;
     if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;                   // 32-bit offsets
     int lgC = 0;
-    { const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }   // (test knob: small pages reach every path with small inputs)
+    { const int c = im->eng->knobs.fold_c > 0 ? im->eng->knobs.fold_c : PF_C_MAX; while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; }   // (test knob: small pages reach every path with small inputs)
     PartGeom g; g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.n_cells = (uint32_t)im->n_cells;
     g.sb = std::min(PF_SB_MAX, std::max(kl.cbits, 11));                                    // 14 cell bits: one row per span, a 2 KB bitmap
     const int lg_min = std::max(0, kl.cbits - g.sb);                                      // a level-1 cell never straddles two spans
@@ -747,7 +746,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     // atomics, short runs (A/B on one box at configs[2]: 8 -> 9.6 ms, 7 -> 8.9, 6 -> 8.7, 5 -> 8.9; profiles/r03_x_fold_variants_ab.log)
     // with at most 512 cells (well-based data: one BAM per cell) a row may get one group per cell: the cells of such data are far from
     // even (every cell has its own hot genes), and a level-1 cell that IS one (row, cell) knows its depth exactly
-    const int lg_max = std::max(lg_min, std::min(pf_env_int("XCK_FOLD_LGG", kl.cbits <= 9 ? kl.cbits : 6), kl.cbits));
+    const int lg_max = std::max(lg_min, std::min((im->eng->knobs.fold_lgg >= 0 ? im->eng->knobs.fold_lgg : kl.cbits <= 9 ? kl.cbits : 6), kl.cbits));
     const uint32_t n_rows = (uint32_t)im->n_regions;
     ShardChunks sc; sc.cap = im->hit_cap; sc.chunk0[0] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)im->cur[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((im->cur[sh] + PT_CHUNK - 1) / PT_CHUNK); }
@@ -759,12 +758,12 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     for (int sh = 0; sh < NSHARD; sh++) scs.chunk0[sh + 1] = scs.chunk0[sh] + (uint32_t)((im->cur[sh] + (size_t)PT_CHUNK * stride - 1) / ((size_t)PT_CHUNK * stride));
     const unsigned n_sample = scs.chunk0[NSHARD];
     const size_t z_cap = ((size_t)n_rows << lg_min) + 4 * ((n + (size_t)NSHARD * stride * PT_CHUNK) >> lgC) + 64;   // sum of 2^l over the rows (k_pf_rowplan)
-    if (z_cap > (size_t(1) << 24)) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: level-1 cell bound %zu\n", z_cap); return PF_FALLBACK; }
+    if (z_cap > (size_t(1) << 24)) { if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] partition fold: level-1 cell bound %zu\n", z_cap); return PF_FALLBACK; }
     const size_t zs_cap = z_cap + 1, rs = (size_t)n_rows + 1;
     const size_t sb1 = (std::max(zs_cap, rs) + SC_TILE - 1) / SC_TILE + 8;
     int rc;
     // ---- workspace 1: level-1 output, row geometry, histogram / flags over the cells
-    const int pl = std::max(0, std::min(pf_env_int("XCK_FOLD_COPIES_LG", 4), 6));            // 2^pl copies of the level-1 counters / cursors
+    const int pl = std::max(0, std::min(im->eng->knobs.fold_copies_lg, 6));            // 2^pl copies of the level-1 counters / cursors
     const size_t ss_cap = (z_cap << pl) + 1;
     const size_t sbs = (ss_cap + SC_TILE - 1) / SC_TILE + 8;
     if ((rc = arena_begin(im, im->ws1, n * sizeof(K) + 3 * (rs * 4 + 256) + 5 * (zs_cap * 4 + 256) + ss_cap * 4 + (sb1 + sbs) * 4 + 64 * 4 + (1 << 16)))) return rc;
@@ -837,19 +836,19 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
       memset(st, 0, sizeof st); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pf_stamps), st, sizeof st)); }
 #endif
     const int lds = pf_bucket_lds(g.sb);
-    const size_t bucket_grid = (size_t)std::max(1, pf_env_int("XCK_FOLD_BUCKET_BLOCKS", 256 * 4 * 2));     // resident blocks (4 per CU by LDS) x 2: the tail evens out
+    const size_t bucket_grid = (size_t)std::max(1, im->eng->knobs.fold_bucket_blocks);     // resident blocks (4 per CU by LDS) x 2: the tail evens out
     size_t n_wi2 = 0;
     K* B = (K*)im->d_keys;                                                                 // level-2 output: the shard slices are dead once level 1 has moved the keys
     // The level-1 items do not depend on level 2: their bucket pass runs on the copy stream (idle until the copy-out) beside the
     // level-2 histogram / partition - two latency-bound kernels share the CUs better than either fills them (XCK_FOLD_OVERLAP=0: serial).
-    const bool overlap = n_big && pf_env_int("XCK_FOLD_OVERLAP", 1) != 0;
+    const bool overlap = n_big && im->eng->knobs.fold_overlap != 0;
     if (overlap) {
         if (!im->ev_f1) { HIP_TRY(hipEventCreateWithFlags(&im->ev_f1, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&im->ev_f2, hipEventDisableTiming)); }
         HIP_TRY(hipEventRecord(im->ev_f1, im->s_comp));
         HIP_TRY(hipStreamWaitEvent(im->s_copy, im->ev_f1, 0));
         // (half of the CUs' wave slots - 2 blocks of 8 waves per CU: a persistent grid that fills the device would leave the level-2
         // kernels waiting for a slot until it retires)
-        const size_t side_grid = (size_t)std::max(1, pf_env_int("XCK_FOLD_OVERLAP_BLOCKS", 512));
+        const size_t side_grid = (size_t)std::max(1, im->eng->knobs.fold_overlap_blocks);
         hipLaunchKernelGGL(k_pf_bucket, dim3((unsigned)std::min<size_t>(n_wi1, side_grid)), dim3(PF_THREADS), lds, im->s_copy, (const K*)A, (const WorkItem*)wi1, (uint32_t)n_wi1, kl.ubits, g.sb, res1, nnz1, (uint32_t*)nullptr, ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(im->ev_f2, im->s_copy));
@@ -867,7 +866,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(im->s_comp));
             Z2 = h_ctr[9];
-            if (Z2 > z2_cap) { if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: %zu level-2 cells (room for %zu)\n", Z2, z2_cap);
+            if (Z2 > z2_cap) { if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] partition fold: %zu level-2 cells (room for %zu)\n", Z2, z2_cap);
                                if (overlap) HIP_TRY(hipStreamSynchronize(im->s_copy));      // (the level-1 bucket pass still reads this workspace)
                                return PF_FALLBACK; }
             const size_t zs2n = Z2 + 1;
@@ -885,7 +884,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
             HIP_TRY(hipStreamSynchronize(im->s_comp));
             if (!h_ctr[5]) break;
             // (the shard slices still hold the keys: level 2 has not written yet)
-            if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: a level-2 sub-cell holds %llu keys (more than %d) - %s (n=%zu cells=%u big=%zu, %zu keys, %zu sub-cells)\n",
+            if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] partition fold: a level-2 sub-cell holds %llu keys (more than %d) - %s (n=%zu cells=%u big=%zu, %zu keys, %zu sub-cells)\n",
                                                     h_ctr[10], 2 << lgC, h_ctr[11] || attempt >= 3 ? "radix fold" : "finer geometry for its big cell", n, Z, n_big, n_bigkeys, Z2);
             if (h_ctr[11] || attempt >= 3) { if (overlap) HIP_TRY(hipStreamSynchronize(im->s_copy)); return PF_FALLBACK; }
             im->fold_refinements++;
@@ -917,7 +916,7 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     if (h_ctr[7]) { im->eng->err = "internal: a work item of the partition fold exceeds its capacity"; return XCK_E_STATE; }
     const size_t total = h_ctr[6];
-    if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] partition fold: n=%zu rows=%u cells=%u (sample stride %u) items=%zu big=%zu (%zu keys, %zu sub-cells, %zu items) nnz=%zu C=%d sb=%d\n",
+    if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] partition fold: n=%zu rows=%u cells=%u (sample stride %u) items=%zu big=%zu (%zu keys, %zu sub-cells, %zu items) nnz=%zu C=%d sb=%d\n",
                                             n, n_rows, Z, stride, n_wi1, n_big, n_bigkeys, Z2, n_wi2, total, 1 << lgC, g.sb);
     im->res_nnz[0] = total; im->d_res[0] = nullptr;
     if (!total) return 0;
@@ -1226,17 +1225,17 @@ static PartSortSizes partition_sort_sizes(size_t n, size_t n_rows, int lgC) {
     q.bytes = 3 * (q.rs * 4 + 256) + 2 * (q.zs_cap * 4 + 256) + (q.wi_cap + 1) * 4 + q.sb * 4 + 64 * 4 + (1 << 16);
     return q;
 }
-static int partition_sort_lgC() { int lgC = 0; const int c = pf_env_int("XCK_FOLD_C", PF_C_MAX); while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; return lgC; }
-static size_t partition_sort_scratch(size_t n, size_t n_rows) { return partition_sort_sizes(n, n_rows, partition_sort_lgC()).bytes; }
+static int partition_sort_lgC(const EngineImpl* im) { int lgC = 0; const int c = im->eng->knobs.fold_c > 0 ? im->eng->knobs.fold_c : PF_C_MAX; while ((2 << lgC) <= c && (2 << lgC) <= PF_C_MAX) lgC++; return lgC; }
+static size_t partition_sort_scratch(const EngineImpl* im, size_t n, size_t n_rows) { return partition_sort_sizes(n, n_rows, partition_sort_lgC(im)).bytes; }
 static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyLayout<unsigned long long> kl, const unsigned long long* src_keys, const uint64_t* src_vals,
                                  size_t src_cap, const unsigned long long* src_cnt, uint32_t n_rows, size_t n, unsigned long long* out_keys, uint64_t* out_vals,
                                  const HapItemsOut* hap = nullptr, PartIndex* index = nullptr) {
     typedef unsigned long long K;
     if (n >= (size_t(1) << 32) - (size_t(1) << 20)) return PF_FALLBACK;
-    const int lgC = partition_sort_lgC();
+    const int lgC = partition_sort_lgC(im);
     PartGeom g; memset(&g, 0, sizeof g); g.ubits = kl.ubits; g.cbits = kl.cbits; g.lgC = lgC; g.sb = PF_SB_MAX; g.n_cells = (uint32_t)im->n_cells;
     // (there is no second level here: a SNP of a hot gene - 100 k hits at configs[2] - must come apart in the first one, so up to 2^10 groups per SNP)
-    const int lg_max = std::max(0, std::min(pf_env_int("XCK_PILEUP_LGG", 10), kl.cbits));
+    const int lg_max = std::max(0, std::min(im->eng->knobs.pileup_lgg, kl.cbits));
     ShardChunks sc; sc.cap = src_cap; sc.chunk0[0] = 0;
     for (int sh = 0; sh < NSHARD; sh++) { sc.cnt[sh] = (uint32_t)src_cnt[sh]; sc.chunk0[sh + 1] = sc.chunk0[sh] + (uint32_t)((src_cnt[sh] + PT_CHUNK - 1) / PT_CHUNK); }
     const unsigned n_chunks = sc.chunk0[NSHARD];
@@ -1283,14 +1282,14 @@ static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyL
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     if (h_ctr[5]) {                                                                       // a (SNP, cell group) with more hits than an item holds
-        if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] pileup partition sort: a cell group exceeds an item (n=%zu cells=%u): radix sort\n", n, Z);
+        if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] pileup partition sort: a cell group exceeds an item (n=%zu cells=%u): radix sort\n", n, Z);
         return PF_FALLBACK;
     }
     const size_t n_items = h_ctr[0];
     if (n_items > wi_cap) { im->eng->err = "internal: pileup items exceed their bound"; return XCK_E_STATE; }
     hipLaunchKernelGGL(k_pf_emit0, dim3(gz), dim3(256), 0, im->s_comp, (const uint32_t*)S, Z, (const uint32_t*)fs, item_off);
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)src_keys, sc, bc0, g, 0, S, out_keys, src_vals, out_vals);
-    const bool bitonic = getenv("XCK_PILEUP_ITEM_SORT") && !strcmp(getenv("XCK_PILEUP_ITEM_SORT"), "bitonic");
+    const bool bitonic = im->eng->knobs.pileup_bitonic;
     if (hap && hap->pack_shift >= 0) hipLaunchKernelGGL((k_hap_items<true>), dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, (const unsigned long long*)out_keys, (const uint64_t*)nullptr, (const uint32_t*)item_off, kl.ubits, *hap, ctr);
     else if (hap) hipLaunchKernelGGL((k_hap_items<false>), dim3((unsigned)n_items), dim3(RS_THREADS), 0, im->s_comp, (const unsigned long long*)out_keys, (const uint64_t*)out_vals, (const uint32_t*)item_off, kl.ubits, *hap, ctr);
     else if (bitonic) hipLaunchKernelGGL(k_pf_sort_items, dim3((unsigned)n_items), dim3(PS_THREADS), 0, im->s_comp, out_keys, out_vals, (const uint32_t*)item_off, ctr);
@@ -1301,6 +1300,6 @@ static int pileup_partition_sort(EngineImpl* im, Arena& ar, bool own_arena, KeyL
     HIP_TRY(hipStreamSynchronize(im->s_comp));
     if (h_ctr[7]) { im->eng->err = "internal: a pileup item exceeds its capacity"; return XCK_E_STATE; }
     if (index) { index->rowtab = rowtab; index->end = S; }
-    if (getenv("XCK_DEBUG_TIMING")) fprintf(stderr, "[xck] pileup partition sort: n=%zu snps=%u cells=%u items=%zu C=%d\n", n, n_rows, Z, n_items, 1 << lgC);
+    if (im->eng->knobs.debug_timing) fprintf(stderr, "[xck] pileup partition sort: n=%zu snps=%u cells=%u items=%zu C=%d\n", n, n_rows, Z, n_items, 1 << lgC);
     return 0;
 }

@@ -85,6 +85,29 @@ inline KeyBits key_layout(const xck_config* cfg) {
     return k;
 }
 
+// Tuning / test knobs of a handle, read from the environment ONCE, at xck_create (include/xck.h lists them with their meaning):
+// the host path of push / finish never calls getenv().
+struct Knobs {
+    bool debug_timing = false;           // XCK_DEBUG_TIMING
+    bool fold_sort = false;              // XCK_FOLD=sort
+    int  fold_c = 0;                     // XCK_FOLD_C (0 = the built-in page size)
+    int  fold_lgg = -1;                  // XCK_FOLD_LGG (-1 = by the number of cells)
+    int  fold_copies_lg = 4;             // XCK_FOLD_COPIES_LG
+    int  fold_bucket_blocks = 2048;      // XCK_FOLD_BUCKET_BLOCKS
+    int  fold_overlap = 1;               // XCK_FOLD_OVERLAP
+    int  fold_overlap_blocks = 512;      // XCK_FOLD_OVERLAP_BLOCKS
+    bool full_sort = false;              // XCK_FULL_SORT
+    bool pileup_radix = false;           // XCK_PILEUP_SORT=radix
+    int  pileup_hap = 0;                 // XCK_PILEUP_HAP: 0 = packed class bits, 1 = sorted, 2 = values
+    bool pileup_bitonic = false;         // XCK_PILEUP_ITEM_SORT=bitonic
+    int  pileup_lgg = 10;                // XCK_PILEUP_LGG
+    long long hit_slack = 65536;         // XCK_HIT_SLACK
+    long long hit_cap0 = 1 << 20;        // XCK_HIT_CAP0
+    int  push_stage = -1;                // XCK_PUSH_STAGE (-1 = by size)
+    long long push_stage_bytes = 2 << 20;   // XCK_PUSH_STAGE_BYTES
+    static Knobs from_env();             // api.cpp
+};
+
 // the decoder's own batches are valid by construction and skip the O(n) check of xck_push_batch()
 int push_trusted(xck_engine* e, const xck_batch* b);
 // host threads this process may really use: min(hardware threads, CPU affinity, cgroup CPU quota) - a container with a
@@ -105,6 +128,7 @@ struct xck_engine {
     int n_impl = 0;
     void* stager = nullptr;              // xck::Stager (engine.hip): device staging slots of engine_push_block
     struct PushRing { void* blk[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}; void* fence[3] = {nullptr, nullptr, nullptr}; int next = 0; } push_ring;   // pinned blocks of xck_push_batch's one-copy form (api.cpp)
+    xck::Knobs knobs;                    // the environment, read once at xck_create
     int mode = 0;
     int umi_bits = 64;
     int32_t n_cells = 0, n_contigs = 0;  // bounds that caller-supplied batches are checked against (xck_push_batch)

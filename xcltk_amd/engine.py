@@ -252,10 +252,10 @@ class Engine(object):
         finally:
             self.lib.xck_bam_close(b)
 
-    def open_stream(self, path, sample=0, n_threads=0, contig_mask=None, use_index=False):
+    def open_stream(self, path, sample=0, n_threads=0, contig_mask=None, use_index=False, windows=None):
         """Resumable ingest of one BAM: -> BamStream whose advance(n) decodes and joins about n further
         records (whole decode chunks) and returns (records so far, done)."""
-        return BamStream(self, path, sample, n_threads, contig_mask, use_index)
+        return BamStream(self, path, sample, n_threads, contig_mask, use_index, windows)
 
     def decode_bam(self, path, sample=0, n_threads=0, max_records=0, contig_mask=None, use_index=False, windows=None):
         """Pull-style decode (tests / inspection): yields dicts of numpy copies per batch."""
@@ -346,10 +346,10 @@ class Engine(object):
 class BamStream(object):
     """One open BAM being streamed through an Engine in slices (xck_ingest_opts.pause_records)."""
 
-    def __init__(self, eng, path, sample=0, n_threads=0, contig_mask=None, use_index=False):
+    def __init__(self, eng, path, sample=0, n_threads=0, contig_mask=None, use_index=False, windows=None):
         self.eng = eng
         self.b, refs = eng._open(path, n_threads or eng.cfg.n_threads)
-        self.opts, self._keep = eng._opts(refs, sample, 0, contig_mask, use_index)
+        self.opts, self._keep = eng._opts(refs, sample, 0, contig_mask, use_index, windows)
         self.n_records = 0
         self.done = False
 

@@ -356,34 +356,42 @@ class Dist(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = None
         self.device = "cpu"
+        # XCK_DIST_FORCE=1: take the multi-rank code path with ONE rank as well (communicator, collectives, gather and the sharded
+        # writer all run, over a world of one) - how the one-GPU test box exercises the RCCL backend
+        self.forced = self.world == 1 and os.environ.get("XCK_DIST_FORCE", "0") not in ("", "0")
         # how the ranks' results meet: every rank writes the lines of its own rows into the shared output files (default; the
         # ranks of one node see the same directory), or XCK_DIST_GATHER=1: the sparse blocks are gathered on rank 0, which writes
         self.sharded_output = False
-        if self.world > 1:
+        if self.world > 1 or self.forced:
             import torch
             import torch.distributed as dist
             self.backend = os.environ.get("XCK_DIST_BACKEND", "nccl")
             if not dist.is_initialized():
+                if self.forced:
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29533")
+                kw = dict(rank=self.rank, world_size=self.world) if self.forced else {}
                 if self.backend == "nccl":
                     torch.cuda.set_device(self.local_rank)
-                    dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), **kw)
                 else:
-                    dist.init_process_group(self.backend)
+                    dist.init_process_group(self.backend, **kw)
             if self.backend == "nccl":
                 self.device = "cuda:%d" % self.local_rank
             self.sharded_output = os.environ.get("XCK_DIST_GATHER", "0") in ("", "0")
 
     @property
     def active(self):
-        return self.world > 1
+        return self.world > 1 or self.forced
 
-    def plan(self, conf, regions, snps=()):
+    def plan(self, conf, regions, snps=(), names=None):
         """Who counts what (identical on every rank): contigs by longest-processing-time on the .bai record counts; a contig
         that outweighs 1 / world of the reads is cut at region boundaries (shard.plan_units).  Sets contig_mask (contigs this
         rank streams), windows ({contig: (beg0, end0)} for the cut ones), region_mask (regions this rank counts) and
         row_owner (rank per region, for stitching the gathered blocks)."""
         from .shard import plan_units
-        names = contig_table(regions, snps)
+        if names is None:
+            names = contig_table(regions, snps)
         probe = Engine(XCK_MODE_BASEFC, names, [], 1, decode_only=True)
         try:
             weights = np.zeros(len(names), dtype=np.float64)
@@ -405,6 +413,7 @@ class Dist(object):
             probe.close()
         cidx = {n: i for i, n in enumerate(names)}
         units, owner = plan_units(weights + 1e-9, self.world, regions, cidx, profiles)
+        self.units, self.unit_owner, self.contig_weights = units, owner, weights
         self.contig_mask = np.zeros(len(names), dtype=bool)
         self.region_mask = np.zeros(len(regions), dtype=bool)
         self.row_owner = np.full(len(regions), -1, dtype=np.int32)

@@ -126,35 +126,6 @@ def merge_row_blocks(blocks, row_owner):
     return out
 
 
-def linear_partition(weights, n_bins):
-    """Contiguous partition of items (in order) into n_bins minimising the largest bin
-    (used when per-rank row ranges must stay contiguous so that concatenating the per-rank
-    blocks in rank order is already the (row, col) order).  Returns list of index lists."""
-    w = list(weights)
-    n = len(w)
-    pre = [0.0]
-    for x in w:
-        pre.append(pre[-1] + x)
-    INF = float("inf")
-    best = [[INF] * (n + 1) for _ in range(n_bins + 1)]
-    cut = [[0] * (n + 1) for _ in range(n_bins + 1)]
-    best[0][0] = 0.0
-    for k in range(1, n_bins + 1):
-        for i in range(0, n + 1):
-            for j in range(0, i + 1):
-                v = max(best[k - 1][j], pre[i] - pre[j])
-                if v < best[k][i]:
-                    best[k][i] = v
-                    cut[k][i] = j
-    bins = []
-    i = n
-    for k in range(n_bins, 0, -1):
-        j = cut[k][i]
-        bins.append(list(range(j, i)))
-        i = j
-    return bins[::-1]
-
-
 class _DevArray(object):
     """Minimal __cuda_array_interface__ holder so torch can wrap an engine-owned device buffer."""
 
@@ -277,29 +248,3 @@ class BlockGatherer(object):
             res[k] = [outs[r][off:off + 3 * sizes[r][j]] for r in range(self.world)]
             off += pad[j]
         return res
-
-
-def gather_device_blocks(block, world, rank, device, backend_is_nccl=True):
-    """all-gatherv for the writer rank: every rank contributes its [row|col|val] int32 block that is
-    already resident in HBM; sizes are all-gathered first, then the padded blocks are gathered to
-    rank 0 GPU-to-GPU (RCCL over xGMI).  block = (device_ptr, nnz).  Returns on rank 0 a list of
-    per-rank int32 tensors (3*nnz_r elements each, rank order) and the sizes; None elsewhere."""
-    import torch
-    import torch.distributed as dist
-    ptr, nnz = block
-    dev = device if backend_is_nccl else "cpu"
-    n = torch.tensor([nnz], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(x.item()) for x in sizes]
-    mx = max(max(sizes), 1) * 3
-    buf = torch.zeros(mx, dtype=torch.int32, device=device)
-    if nnz:
-        buf[:3 * nnz] = torch.as_tensor(_DevArray(ptr, 3 * nnz), device=device)
-    if not backend_is_nccl:
-        buf = buf.cpu()
-    outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, outs, dst=0)
-    if rank != 0:
-        return None, sizes
-    return [o[:3 * s] for o, s in zip(outs, sizes)], sizes

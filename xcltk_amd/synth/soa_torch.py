@@ -1,6 +1,9 @@
 """soa_torch.py - the synthetic record generator of soa.py, on the GPU (torch), for benchmark
 sized inputs (tens of millions of reads are produced in seconds and are already resident
-in HBM, which is what bench.py times).  Same distributions as soa.gen_reads; seeded."""
+in HBM, which is what bench.py times).  Same distributions as soa.gen_reads; seeded, and the
+same arrays for the same seed in every process and on every box (tests/test_gpu_configs.py
+checks the checksums of a 2 M-read draw against committed values): every draw is a
+torch.rand / torch.randint of the seeded generator, every scatter has unique indices, the sort is stable."""
 
 import numpy as np
 import torch
@@ -21,12 +24,15 @@ def gen_reads_device(regions, names, n_reads, n_cells, seed, device, umi_len=12,
     rng = np.random.default_rng(seed)
     w = 1.0 / np.arange(1, len(regions) + 1) ** 0.8
     rng.shuffle(w)
-    w = torch.tensor(w, dtype=torch.float64, device=device)
     if contig_subset is not None:
-        mask = torch.zeros(len(names), dtype=torch.bool, device=device)
-        mask[torch.tensor(sorted(contig_subset), dtype=torch.int64, device=device)] = True
-        w = w * mask[g_c].to(w.dtype)
-    w = (w / w.sum()).to(torch.float32)
+        keep = np.zeros(len(names), dtype=bool)
+        keep[sorted(contig_subset)] = True
+        w = w * keep[np.array([cidx[r[0]] for r in regions])]
+    # gene of a molecule by inverse CDF (float64, the table summed on the host): torch.multinomial gave a different draw on the
+    # first call of a process than on later ones (same seed, same generator offset), so that no two boxes agreed on the workload
+    cdf = np.cumsum(w / w.sum())
+    cdf[-1] = 1.0
+    cdf = torch.tensor(cdf, dtype=torch.float64, device=device)
 
     def rint(lo, hi, n, dtype=torch.int64):
         return torch.randint(lo, hi, (n,), generator=g, device=device, dtype=dtype)
@@ -43,8 +49,7 @@ def gen_reads_device(regions, names, n_reads, n_cells, seed, device, umi_len=12,
     per = per[:k].clone()
     per[-1] -= int(per.sum().item()) - n_reads
     n_mol = k
-    # torch.multinomial is limited to 2^24 categories per call on some builds; genes are far fewer
-    mg = torch.multinomial(w, n_mol, replacement=True, generator=g)
+    mg = torch.clamp(torch.searchsorted(cdf, torch.rand((n_mol,), generator=g, device=device, dtype=torch.float64), right=True), max=len(regions) - 1)
     m_cell = rint(0, n_cells, n_mol, torch.int32)
     m_cell[rnd(n_mol) < frac_nocell] = -1
     m_umi = rint(0, 1 << (2 * umi_len), n_mol) | (1 << (2 * umi_len))
