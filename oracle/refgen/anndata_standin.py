@@ -13,6 +13,12 @@ class AnnData(object):
         self.obs.index = self.obs.index.astype(str)
         self.var.index = self.var.index.astype(str)
         self.layers, self.uns, self.obsm = {}, {}, {}
+        if X is not None:                                     # (rdr/io.py:20-24 passes the count matrix as X; kept as one more layer)
+            self.layers["X"] = np.asarray(X)
+
+    @property
+    def X(self):
+        return self.layers.get("X")
 
     @property
     def shape(self):

@@ -17,7 +17,7 @@ sys.dont_write_bytecode = True (the tree is read-only) and only its *outputs* ar
 as fixtures under tests/golden/.
 
 usage: run_reference.py <job.json>
-  job = {"kind": "basefc"|"baf"|"convert", "out_dir": ..., "kwargs": {...}}   (kwargs of fc_wrapper /
+  job = {"kind": "basefc"|"baf"|"convert"|"filter_snps"|"csp_load", "out_dir": ..., "kwargs": {...}}   (kwargs of fc_wrapper /
   afc_wrapper, xcltk/rdr/fc/main.py:142 and xcltk/baf/fc/main.py:32); optional "argv" (basefc command line
   instead of kwargs) and "prewarm" (BAMs parsed before the timed call)
 """
@@ -82,6 +82,25 @@ def main():
         from xcltk.tools.convert import convert_main
         convert_main(["xcltk", "convert"] + job["argv"])
         ret = 0
+    elif job["kind"] == "filter_snps":
+        # the reference's own post-filter of a cellsnp-lite style pileup directory (xcltk/baf/genotype.py:200-229), which loads the
+        # directory with utils/csp_io.load_data (:16-63) and writes the kept SNPs with save_data (:66-100)
+        from xcltk.baf.genotype import filter_snps
+        vcf, p_raw, p_new = filter_snps(**job["kwargs"])
+        sys.stdout.write(json.dumps({"ret": 0, "vcf": vcf, "p_raw": int(p_raw), "p_new": int(p_new)}) + "\n")
+        return 0
+    elif job["kind"] == "csp_load":
+        # the reference's loader on a directory written by this repo's writer: shapes and layer sums as the reference sees them
+        from xcltk.utils.csp_io import load_data
+        ad = load_data(job["kwargs"]["data_dir"])
+        n, p = ad.shape
+        out = dict(ret=0, n_cells=int(n), n_snps=int(p), cells=[str(x) for x in ad.obs["cell"]], pos=[int(x) for x in ad.var["pos"]],
+                   chrom=[str(x) for x in ad.var["chrom"]], ref=[str(x) for x in ad.var["ref"]], alt=[str(x) for x in ad.var["alt"]])
+        for k in ("AD", "DP", "OTH"):
+            m = ad.layers[k]
+            out["sum_" + k] = int(m.sum()); out["colsum_" + k] = [int(x) for x in m.sum(axis=0)]
+        sys.stdout.write(json.dumps(out) + "\n")
+        return 0
     elif job["kind"] == "fet1":
         # direct per-region call used for the known-answer tests of SURVEY 8c
         raise SystemExit("fet1 jobs are handled by kat.py")

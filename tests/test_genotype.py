@@ -137,3 +137,54 @@ def test_pileup_writer_failure_reaches_the_status_collective(exc, monkeypatch, t
         G.pileup(sam_fn=os.path.join(DS, "possorted.bam"), barcode_fn=os.path.join(DS, "barcodes.tsv"),
                  snp_vcf_fn=os.path.join(DS, "cellsnp", "cellSNP.base.vcf.gz"), out_dir=str(tmp_path / "p"))
     assert calls == [([1], "max")] and eng.closed
+
+
+# ---- f1 against the reference's own code (oracle/refgen/make_genotype_goldens.py; fixtures under tests/golden/genotype) -------------
+GT = os.path.join(util.GOLDEN, "genotype")
+
+
+def assert_cellsnp_dirs_equal(got, exp):
+    """Same directory content: VCF text after decompression, cell list bytes, the three matrices entry by entry."""
+    assert gzip.open(os.path.join(got, "cellSNP.base.vcf.gz"), "rt").read() == gzip.open(os.path.join(exp, "cellSNP.base.vcf.gz"), "rt").read()
+    assert open(os.path.join(got, "cellSNP.samples.tsv"), "rb").read() == open(os.path.join(exp, "cellSNP.samples.tsv"), "rb").read()
+    for k in ("AD", "DP", "OTH"):
+        a, b = (spio.mmread(os.path.join(d, "cellSNP.tag.%s.mtx" % k)).tocsr() for d in (got, exp))
+        assert a.shape == b.shape and (a != b).nnz == 0, k
+
+
+def test_raw_fixture_is_the_oracle_pileup_through_our_writer(oracle_lib, tmp_path):
+    """The fixture INPUT: the oracle's per-SNP x cell counts of the `phasing` dataset, written by write_cellsnp_dir."""
+    cand = G.load_candidate_snps(os.path.join(DS, "cellsnp", "cellSNP.base.vcf.gz"))
+    regions, snps = snp_feature_tables(cand)
+    rfn, sfn = str(tmp_path / "r.tsv"), str(tmp_path / "s.tsv")
+    open(rfn, "w").write("".join("%s\t%d\t%d\t%s\n" % r for r in regions))
+    open(sfn, "w").write("chrom\tpos\tref\talt\tref_hap\talt_hap\n" + "".join("%s\t%d\t%s\t%s\t%d\t%d\n" % s for s in snps))
+    coo = O.run_files(capi.XCK_MODE_BAF, [os.path.join(DS, "possorted.bam")], rfn, barcode_fn=os.path.join(DS, "barcodes.tsv"), snp_fn=sfn,
+                      output_all_reg=True, min_count=1, min_maf=0, no_dup_hap=True)
+    cells = sorted(x.strip() for x in open(os.path.join(DS, "barcodes.tsv")) if x.strip())
+    G._write_raw_dir(str(tmp_path / "raw"), cand, cells, coo)
+    assert_cellsnp_dirs_equal(str(tmp_path / "raw"), os.path.join(GT, "raw"))
+
+
+def test_reference_loader_reads_our_directory_as_we_do():
+    """utils/csp_io.load_data of the REFERENCE on a directory of our writer (recorded by the generator) == our own loader."""
+    import json
+    seen = json.load(open(os.path.join(GT, "ref_load.json")))
+    d = csp_io.load_data(os.path.join(GT, "raw"))
+    assert seen["n_cells"] == d.shape[0] and seen["n_snps"] == d.shape[1] and seen["cells"] == d.cells
+    assert seen["pos"] == d.pos.tolist() and seen["chrom"] == [str(c) for c in d.chrom] and seen["ref"] == list(d.ref) and seen["alt"] == list(d.alt)
+    for k, m in (("AD", d.AD), ("DP", d.DP), ("OTH", d.OTH)):
+        assert seen["colsum_" + k] == np.asarray(m.sum(axis=0)).reshape(-1).astype(int).tolist() and seen["sum_" + k] == int(m.sum())
+
+
+def _genotype_cases():
+    import json
+    return sorted(json.load(open(os.path.join(GT, "cases.json")))["cases"].items())
+
+
+@pytest.mark.parametrize("name,case", _genotype_cases())
+def test_filter_snps_equals_the_reference_filter(name, case, tmp_path):
+    """filter_snps against the output of the reference's filter_snps (baf/genotype.py:200-229) on the same raw directory."""
+    fn, p_raw, p_new = G.filter_snps(os.path.join(GT, "raw"), str(tmp_path / "flt"), case["min_count"], case["min_maf"])
+    assert (p_raw, p_new) == (case["p_raw"], case["p_new"]) and fn == str(tmp_path / "flt" / "cellSNP.base.vcf.gz")
+    assert_cellsnp_dirs_equal(str(tmp_path / "flt"), os.path.join(GT, name))

@@ -51,6 +51,7 @@ def test_bench_line_and_two_rank_outputs(tmp_path):
     z6, cr = d["end_to_end_zlib6"], d["cellranger_shape"]
     assert z6["records"] == 1000000 and cr["records"] == 1000000 and "zlib level 6" in z6["bgzf_writer"]
     assert cr["inflated_bytes_per_record"] > 1.7 * z6["inflated_bytes_per_record"] and 0 < cr["ratio_to_headline"] and 0 < z6["ratio_to_headline"]
+    assert z6["passes"] == 3 and len(z6["values_all_passes"]) == 3 and z6["value_min"] <= z6["value"] <= z6["value_max"] and "zlib level 6" in cr["bgzf_writer"]
     one = _read(work, 1)
     assert one["basefc/matrix.mtx"].startswith(b"%%MatrixMarket matrix coordinate integer general\n%%\n8000\t2000\t")
     for extra in (["--selfcheck", "--selfcheck-reads", "1500000"], ["--gather"]):

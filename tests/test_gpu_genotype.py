@@ -52,3 +52,19 @@ def test_pipeline_steps_1_and_3_with_engine_pileup(tmp_path):
                 barcode_fn=os.path.join(DS, "barcodes.tsv"), snp_fn=snp_fn, output_all_reg=True, min_count=1, min_maf=0, no_dup_hap=True,
                 phase=util.phase_from_cellsnp(pdir, os.path.join(DS, "ref_cells.tsv"), True))
     util.assert_dirs_equal(os.path.join(out, "3_baf_fc"), exp)
+
+
+@pytest.mark.parametrize("name,case", __import__("test_genotype")._genotype_cases())
+def test_engine_pileup_directories_equal_the_reference_filtered_fixtures(name, case, tmp_path):
+    """pileup() through the engine: raw/ equals the fixture input (oracle counts through the same writer) and the filtered directory
+    equals what the REFERENCE's filter_snps made of that input (tests/golden/genotype, oracle/refgen/make_genotype_goldens.py).
+    The counts themselves stay unpinned against cellsnp-lite (binary absent)."""
+    from test_genotype import GT, assert_cellsnp_dirs_equal
+    from xcltk_amd.baf.genotype import pileup
+    out = str(tmp_path / "pileup")
+    vcf, p_raw, p_new = pileup(sam_fn=os.path.join(DS, "possorted.bam"), barcode_fn=os.path.join(DS, "barcodes.tsv"),
+                               snp_vcf_fn=os.path.join(DS, "cellsnp", "cellSNP.base.vcf.gz"), out_dir=out, mode="droplet", ncores=2,
+                               min_count=case["min_count"], min_maf=case["min_maf"])
+    assert (p_raw, p_new) == (case["p_raw"], case["p_new"])
+    assert_cellsnp_dirs_equal(os.path.join(out, "raw"), os.path.join(GT, "raw"))
+    assert_cellsnp_dirs_equal(out, os.path.join(GT, name))

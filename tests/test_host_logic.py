@@ -716,3 +716,40 @@ def test_position_windows_decode_through_the_linear_index():
         assert prof is not None and len(prof) >= (int(pos.max()) >> 14) and np.all(np.diff(prof[prof > 0]) >= 0)
     finally:
         eng.close()
+
+
+def test_io_adapters_build_the_reference_anndata_objects(tmp_path, monkeypatch):
+    """rdr/io.py / baf/io.py load_data(): the cell x feature AnnData the reference returns (xcltk/rdr/io.py:14-26, baf/io.py:14-33) -
+    built here with the minimal AnnData of oracle/refgen/anndata_standin.py standing in for the `anndata` package (absent from the
+    image), on two reference-generated output directories; save_data() writes directories that load back to the same object."""
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(util.GOLDEN), os.pardir, "oracle", "refgen"))
+    import anndata_standin
+    m = types.ModuleType("anndata")
+    m.AnnData = anndata_standin.AnnData
+    monkeypatch.setitem(sys.modules, "anndata", m)
+    from scipy import io as spio
+    from xcltk_amd.baf import io as bio
+    from xcltk_amd.rdr import io as rio
+    d = os.path.join(util.GOLDEN, "cases", "c1_basefc_default", "expected")
+    a = rio.load_data(d)
+    feats, cells, mtx = rio.load_matrix_data(d)
+    assert a.shape == (len(cells), len(feats)) == mtx.shape and list(a.obs["cell"]) == list(cells["cell"]) and list(a.var["feature"]) == list(feats["feature"])
+    assert np.array_equal(np.asarray(a.X), spio.mmread(os.path.join(d, "matrix.mtx")).toarray().T) and int(np.asarray(a.X).sum()) == int(mtx.sum()) > 0
+    # save_data writes the object as it stands - cell x feature, like the reference's (rdr/io.py:29-37: its files are the transpose of
+    # what load_data reads; kept, it is the reference's contract)
+    rio.save_data(a, str(tmp_path / "rdr"))
+    assert np.array_equal(spio.mmread(str(tmp_path / "rdr" / "matrix.mtx")).toarray(), np.asarray(a.X))
+    assert open(str(tmp_path / "rdr" / "barcodes.tsv")).read() == open(os.path.join(d, "barcodes.tsv")).read()
+    assert open(str(tmp_path / "rdr" / "features.tsv")).read() == open(os.path.join(d, "features.tsv")).read()
+    d = os.path.join(util.GOLDEN, "cases", "c1_baf_allreg", "expected")
+    a = bio.load_data(d)
+    feats, cells, mats = bio.load_matrix_data(d)
+    assert a.shape == (len(cells), len(feats)) and set(a.layers) >= {"AD", "DP", "OTH"}
+    for k in bio.LAYERS:
+        assert np.array_equal(np.asarray(a.layers[k]), mats[k].toarray()) and a.layers[k].shape == a.shape
+    assert int(np.asarray(a.layers["DP"]).sum()) > 0
+    bio.save_data(a, str(tmp_path / "baf"))
+    for k in bio.LAYERS:
+        assert np.array_equal(spio.mmread(str(tmp_path / "baf" / ("xcltk.%s.mtx" % k))).toarray(), np.asarray(a.layers[k]))
+    assert open(str(tmp_path / "baf" / "xcltk.region.tsv")).read() == open(os.path.join(d, "xcltk.region.tsv")).read()

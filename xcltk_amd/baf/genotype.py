@@ -9,9 +9,11 @@ xcltk share (MAPQ >= 20, aligned length >= 30, exclude UNMAP / SECONDARY / QCFAI
 
 PARITY UNPINNED: the binary is absent from the reference tree and from this image, so nothing pins the numbers to
 cellsnp-lite's.  Known difference by construction: a (cell, UMI) takes the base of its FIRST read in fetch order
-(baf/fc/mcount.py:118-119), cellsnp-lite's own choice inside a UMI group is not restated.  What IS pinned: the files are
-read back by the reference's own consumers (utils/csp_io.py:16-63, baf/genotype.py:200-229) - tests/test_gpu_genotype.py
-checks them against the oracle's pileup and hand-made known answers.
+(baf/fc/mcount.py:118-119), cellsnp-lite's own choice inside a UMI group is not restated.  What IS pinned, with the reference's
+own code (oracle/refgen/make_genotype_goldens.py, container-only; fixtures under tests/golden/genotype/): a directory written by
+write_cellsnp_dir is read by the reference's loader (utils/csp_io.load_data, :16-63) to the same cells, sites and per-SNP sums,
+and filter_snps below keeps the same SNPs and matrices as the reference's (baf/genotype.py:200-229) on it, for three
+(minCOUNT, minMAF) pairs - tests/test_genotype.py (CPU) and tests/test_gpu_genotype.py (engine pileup -> same fixtures).
 
 Output (`<out_dir>/raw` = every candidate SNP with at least one counted UMI, `<out_dir>` = after `filter_snps`):
 cellSNP.base.vcf.gz (bgzip; INFO = AD=..;DP=..;OTH=..), cellSNP.samples.tsv, cellSNP.tag.{AD,DP,OTH}.mtx (SNP x cell).
@@ -151,6 +153,12 @@ def pileup(sam_fn=None, sam_list_fn=None, barcode_fn=None, sample_id_fn=None, sa
 def _write_pileup_dirs(out_dir, cand, samples, coo, min_count, min_maf):
     """raw/ (every covered SNP) and the filtered directory, from the gathered AD / DP / OTH matrices (writer rank)."""
     raw_dir = os.path.join(out_dir, "raw")
+    _write_raw_dir(raw_dir, cand, samples, coo)
+    return filter_snps(raw_dir, out_dir, min_count, min_maf)
+
+
+def _write_raw_dir(raw_dir, cand, samples, coo):
+    """The raw pileup directory: every candidate SNP with at least one counted UMI (coo = engine / oracle matrices, rows = candidates)."""
     covered = np.zeros(len(cand), dtype=bool)
     covered[coo["dp"][0]] = True
     covered[coo["oth"][0]] = True
@@ -159,4 +167,3 @@ def _write_pileup_dirs(out_dir, cand, samples, coo, min_count, min_maf):
     remap[idx] = np.arange(len(idx))
     mats = {k: (remap[np.asarray(coo[m][0], dtype=np.int64)], coo[m][1], coo[m][2]) for k, m in (("AD", "ad"), ("DP", "dp"), ("OTH", "oth"))}
     write_cellsnp_dir(raw_dir, [cand[i] for i in idx.tolist()], samples, mats)
-    return filter_snps(raw_dir, out_dir, min_count, min_maf)

@@ -507,17 +507,15 @@ __device__ __forceinline__ int32_t wave_minmax(int32_t v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-#ifndef XCK_JOIN_WALK
-#define XCK_JOIN_WALK 1
-#endif
-#if XCK_JOIN_WALK == 1
 // The walk is done 64 regions at a time with the REGIONS in the lanes: lane l loads start / end of region kb + l (one
 // conflict-free LDS read per array) and asks whether the region can meet any read of the wave at all - start below the
 // largest read end, end beyond the smallest read position (two DPP reductions per sweep).  One ballot gives the candidate
 // regions of the chunk; only those are visited, their start / end / row taken from the lanes by v_readlane (no memory
 // round trip, scalar operands for the per-read compare).  The first version visited every region from the tile's first
-// candidate on, each visit two dependent LDS reads + readfirstlane: with a long gene holding the running maximum of the
-// ends, dozens of regions that no read of the wave touches were walked by every wave - ~300 cycles of latency each.
+// candidate on, each visit two dependent LDS reads + readfirstlane (7.76 -> 7.44 ms at configs[2]; the walk it replaces is in
+// the history: commit 97658ab).  What bounds the kernel now is VALU issue: 1756 VALU instructions per wave x 4 cycles x 6
+// waves per SIMD = 88 % of a wave's 48 k-cycle life; by ablation (profiles/experiments/join_r04/) 676 of them are the read
+// summary + prologue + flush, 583 the walk, ~500 the set inserts.
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r,
                                                  const int32_t lb, const int32_t n_st, const int32_t p_first, StampRec* ts = nullptr, int sweep = 0) {   // staged slice: regions [lb, lb + n_st); scalars
@@ -570,34 +568,6 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
     }
     return n_acc;
 }
-#else
-template <class K, int MODE>
-__device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const BatchDesc& d, JoinSmem<K, MODE>& sm, const ReadInfo& r,
-                                                 const int32_t lb, const int32_t n_st, const int32_t p_first) {   // staged slice: regions [lb, lb + n_st); scalars
-    uint32_t n_acc = 0;
-    if (!__ballot(r.ok)) return 0;                                   // no read of this wave passed the filter (wave-uniform)
-    // p_first = position of the tile's first read: a read left of it means unsorted input, the list is then walked from its start
-    int32_t k = __ballot(r.ok && r.pos < p_first) ? d.reg_lo : lb;
-    for (; k < d.reg_hi; k++) {
-        const uint32_t rel = (uint32_t)(k - lb);
-        const bool staged = rel < (uint32_t)n_st;
-        const int32_t s0 = __builtin_amdgcn_readfirstlane(staged ? sm.st_a[rel] : as_global(a.reg_s0)[k]);
-        if (!__ballot(r.ok && s0 < r.endpos)) break;                // sorted by start: no read of the wave reaches this or any later region
-        const int32_t e0 = __builtin_amdgcn_readfirstlane(staged ? sm.st_b[rel] : as_global(a.reg_e0)[k]);
-        if (!(r.ok && r.pos < e0 && r.endpos > s0)) continue;       // htslib fetch overlap
-        const int32_t m = included_len(a, d, sm, r, s0, e0);
-        if (a.f.frac_mode) {
-            if (r.n_al <= 0) continue;
-            // m == n gives exactly 1.0, never below a threshold in (0,1): skip the fp64 divide
-            if (m != r.n_al && frac_below(m, r, a.f.min_inc_frac)) continue;   // IEEE double, as m / float(n)
-        } else if (m < a.f.min_inc_len) continue;
-        const int32_t row = staged ? sm.st_c[rel] : as_global(a.reg_row)[k];
-        emit<K, MODE>(a, sm, a.kl.make((uint32_t)row, (uint32_t)r.cell, r.umi), 0);
-        n_acc++;
-    }
-    return n_acc;
-}
-#endif
 
 
 // position of SNP k (staged slice first)
