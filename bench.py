@@ -61,6 +61,10 @@ from xcltk_amd.shard import write_mtx_sharded
 from xcltk_amd.synth import soa, soa_torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+# What the HBM-resident sub-record must count at the default sizes (seed 100; the generator is reproducible across processes and boxes,
+# tests/test_gpu_configs.py::test_resident_generator_draws_the_committed_workload): accepted (read, region) / (read, SNP) pairs and the
+# non-zeros of the four matrices.  Printed beside the observed values as device_resident.expected / matches_expected.
+EXPECTED_RESIDENT = {(500_000_000, 10000, 1_000_000, 33472): dict(hits_basefc=809553807, hits_pileup=354637614, nnz_count=97973064, nnz_ad=6583662, nnz_dp=12151202, nnz_oth=11344632)}
 FILT = dict(min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True)
 
 
@@ -816,6 +820,13 @@ def device_resident(args, names, regions, snps, dev_idx, device, log):
                     hits=dict(basefc=int(hits_fc), pileup=int(hits_baf), basefc_after_lds_dedup=int(sfc["n_hits_unique"]), pileup_after_lds_dedup=int(sbaf["n_hits_unique"])),
                     # which fold ran (include/xck.h xck_stats): 1 = the sort-free partition paths, 2 = the radix-sort fallbacks
                     fold_paths=dict(basefc=int(sfc.get("fold_path", 0)), pileup_hits=int(sbaf.get("pileup_sort_path", 0)), pileup_region_level=int(sbaf.get("pileup_sort2_path", 0))))
+    exp = EXPECTED_RESIDENT.get((args.reads, args.cells, args.snps, args.genes))
+    if exp is not None:
+        obs = dict(hits_basefc=int(hits_fc), hits_pileup=int(hits_baf), **{"nnz_" + m: int(len(res[m][0])) for m in ("count", "ad", "dp", "oth")})
+        resident["expected"] = exp
+        resident["matches_expected"] = obs == exp
+        if obs != exp:
+            sys.stderr.write("bench.py: the HBM-resident sub-record counted %s, the committed values for this workload are %s\n" % (obs, exp))
     log("resident: %.2f ms/pass %s" % (dt * 1e3, resident["stage_ms_per_pass"]))
     eng_fc.close(); eng_baf.close()
     return resident, roofline

@@ -6,6 +6,7 @@
               independent BAM reader.
 Reads are synthetic (xcltk_amd/synth), generated on the device for the two large cases."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -142,3 +143,23 @@ def test_deep_molecule_runs_are_not_walked_by_one_lane(flags):
     got, exp, st = util.engine_vs_oracle(capi.XCK_MODE_BAF, names, regions, snps, 2, batches, flags=flags, min_len=10)
     util.assert_coo_equal(got, exp, ["ad", "dp", "oth"])
     assert st["n_hits"] > 200_000
+
+
+def test_resident_generator_draws_the_committed_workload():
+    """The HBM-resident generator (xcltk_amd/synth/soa_torch.py) is reproducible: two draws in this process are identical array by
+    array, and equal to the checksums committed in tests/golden/gen_check.json (drawn on another box by tools/gen_check.py) - so the
+    `device_resident` numbers of bench.py mean the same workload wherever they are measured (they did not)."""
+    import json
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(util.GOLDEN), os.pardir, "tools"))
+    import gen_check
+    from xcltk_amd.synth import soa, soa_torch
+    want = json.load(open(os.path.join(util.GOLDEN, "gen_check.json")))
+    regions, snps, names = soa.make_tables(want["genes"], 100000, soa.HG38_LENGTHS, seed=2)
+    got = []
+    for rep in range(2):
+        arrays, batches = soa_torch.gen_reads_device(regions, names, want["reads"], want["cells"], seed=want["seed"], device=torch.device("cuda", 0))
+        got.append(gen_check.checksums(arrays))
+        del arrays
+    assert got[0] == got[1]
+    assert got[0] == want["checksums"]

@@ -1,5 +1,5 @@
 """Is the HBM-resident generator reproducible?  Three draws in this process: checksums (sum, and a position-weighted sum that sees
-the order) of every array must be equal; run it twice to compare processes.  usage: gen_check.py [reads] [cells]"""
+the order) of every array must be equal; run it twice to compare processes.  usage: gen_check.py [reads] [cells] [json to write]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,3 +30,6 @@ if __name__ == "__main__":
         print(rep, got[-1], len(batches), flush=True)
         del arrays
     print("identical draws:", got[0] == got[1] == got[2])
+    if len(sys.argv) > 3:                                      # write the checksums (tests/golden/gen_check.json: what every box must draw)
+        import json
+        json.dump(dict(reads=n, cells=cells, seed=100, genes=33472, checksums=got[0]), open(sys.argv[3], "w"), indent=1, sort_keys=True)
