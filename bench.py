@@ -800,17 +800,25 @@ def device_resident(args, names, regions, snps, dev_idx, device, log):
     n_launch = max(1, int(dom[3]["n_join_launches"]))
     avg_ms = dom[1] / n_launch
     achieved = (dom[2] / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None                                          # PMC bytes were collected at the default workload only (profiles/pmc_traffic.json)
+    # PMC bytes: collected at the default workload only (tools/profile_round.sh -> profiles/pmc_traffic.json), and only valid for the
+    # kernel sources they were counted on (the file carries their hash): a changed kernel reports null until the counters are re-collected
+    traffic, traffic_note = None, "not collected for this workload size"
     if os.path.isfile(args.pmc_json) and (args.reads, args.cells, args.snps) == (500_000_000, 10000, 1_000_000):
         try:
-            traffic = json.load(open(args.pmc_json)).get(dom[0])
+            pj = json.load(open(args.pmc_json))
+            src = os.path.join(ROOT, "xcltk_amd", "csrc")
+            now = hashlib.sha256(b"".join(open(os.path.join(src, f), "rb").read() for f in ("engine.hip", "fold_partition.h"))).hexdigest()[:16]
+            if pj.get("_kernel_source_sha256_16") == now:
+                traffic, traffic_note = pj.get(dom[0]), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 2 x FETCH + WRITE, of the kernel sources " + now
+            else:
+                traffic_note = "profiles/pmc_traffic.json was counted on other kernel sources (%s, now %s): re-collect" % (pj.get("_kernel_source_sha256_16"), now)
         except Exception:
             traffic = None
     both = {name: dict(avg_launch_ms=round(ms / max(1, int(stt["n_join_launches"])), 4), algorithmic_bytes_per_launch=int(A / max(1, int(stt["n_join_launches"]))),
                        frac=round((A / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0, 4))
             for name, ms, A, stt in (("k_join<basefc>", k["ms_join_fc"], A_fc, sfc), ("k_join<pileup>", k["ms_join_baf"], A_baf, sbaf))}
     roofline = dict(bound="hbm", kernel=dom[0], achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, launches_per_pass=n_launch, avg_launch_ms=round(avg_ms, 4),
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_note=traffic_note, launches_per_pass=n_launch, avg_launch_ms=round(avg_ms, 4),
                     algorithmic_bytes_per_launch=int(dom[2] / n_launch), workload="HBM-resident sub-record (device_resident)",
                     note="dominant = the join kernel with the longer launch; both join kernels are listed under 'kernels'", kernels=both)
     resident = dict(reads=n_reads, passes=args.resident_passes, ms_per_pass=round(dt * 1e3, 3), reads_per_s=round(n_reads / dt, 1),

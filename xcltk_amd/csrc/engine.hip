@@ -196,6 +196,9 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double
 #ifndef XCK_BAF_BQUEUE_BYTES
 #define XCK_BAF_BQUEUE_BYTES 4096   // split mode: queue of the hits with a base (~1 in 10), flushed at the tile end
 #endif
+#ifndef XCK_CX_CAP
+#define XCK_CX_CAP 192            // pileup: spliced / indel reads of a tile set aside for the joint walk (beyond it they are walked in place)
+#endif
 #ifndef XCK_HS_BYTES
 #define XCK_HS_BYTES 16384
 #endif
@@ -246,7 +249,7 @@ template <class K, int MODE> struct JoinSmem {
     static constexpr int PR = MODE == XCK_MODE_BAF ? JOIN_BLOCK : 1;
     uint64_t pk_umi[PR];
     // pileup: reads with N / D gaps (or without a CIGAR span) of the whole tile, set aside for pileup_complex()
-    static constexpr int CXCAP = MODE == XCK_MODE_BAF ? 192 : 1;
+    static constexpr int CXCAP = MODE == XCK_MODE_BAF ? XCK_CX_CAP : 1;
     uint64_t cx_umi[CXCAP]; int32_t cx_pos[CXCAP], cx_end[CXCAP], cx_cell[CXCAP], cx_idx[CXCAP]; uint32_t cx_c0[CXCAP], cx_c1[CXCAP], cx_s0[CXCAP], cx_sl[CXCAP];
     uint32_t cx_n;
     int32_t  pk_k[PR], pk_qi[PR], pk_cell[PR], pk_idx[PR];
@@ -677,8 +680,11 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     out[t] = m;
 }
 
+#ifndef XCK_JOIN_WAVES
+#define XCK_JOIN_WAVES 4
+#endif
 template <class K, int MODE>
-__global__ __launch_bounds__(JOIN_BLOCK) void k_join(JoinArgs<K> a) {
+__global__ __launch_bounds__(JOIN_BLOCK) __attribute__((amdgpu_waves_per_eu(XCK_JOIN_WAVES, 8))) void k_join(JoinArgs<K> a) {
     __shared__ JoinSmem<K, MODE> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     StampRec t_s0;

@@ -66,15 +66,8 @@ constexpr uint32_t PF_CONT = 0x80000000u;              // WorkItem.pad: that (ro
 struct ShardChunks { unsigned long long cap; uint32_t cnt[NSHARD]; uint32_t chunk0[NSHARD + 1]; };   // level 1: the 16 shard slices of the hit buffer
 struct BigChunks { const uint32_t* off; const uint32_t* cnt; const uint32_t* chunk0; const uint32_t* z2base; const uint32_t* sg; const uint32_t* eb; uint32_t n_big; };   // level 2: the big z of the level-1 output
 
-// XCK_EXP_XCC_ATOMICS (experiment): counters / cursors privatised per XCD (copy = the hardware XCC id) and updated with workgroup-scope
-// atomics, which the per-XCD L2 executes locally instead of forwarding them to the memory-side atomic units.
-#ifdef XCK_EXP_XCC_ATOMICS
-#define PF_GADD(p, v) (pl ? __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAdd(p, v))   /* pl == 0: one shared copy */
-__device__ __forceinline__ uint32_t pf_copy_of_block(int pl) { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x & ((1u << pl) - 1u); }
-#else
 #define PF_GADD(p, v) atomicAdd(p, v)
 __device__ __forceinline__ uint32_t pf_copy_of_block(int pl) { return blockIdx.x & ((1u << pl) - 1u); }
-#endif
 struct AggTab { uint32_t tag[PT_TAB]; uint32_t cnt[PT_TAB]; uint32_t base[PT_TAB]; };
 __device__ __forceinline__ int agg_find(AggTab& t, uint32_t z) {
     uint32_t h = (z * 0x9E3779B1u) >> (32 - PT_TAB_LG);
@@ -310,25 +303,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_pf_hist(const unsigned long long
     for (int q = 0; q < PT_KPT; q++) {
         if (!((ok >> q) & 1u)) continue;
         const uint32_t z = zq[q];
-#ifdef XCK_EXP_HIST_NOLDS
-        if (z == 0xfffffff0u) atomicAdd(&hist[0], 1u);
-#else
         const int slot = agg_find(t, z);
         if (slot >= 0) atomicAdd(&t.cnt[slot], 1u); else PF_GADD(&hist[(z << pl) | copy], 1u);
-#endif
     }
     __syncthreads();
-#ifndef XCK_EXP_HIST_NOFLUSH
     for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) if (t.tag[s] != 0xffffffffu) PF_GADD(&hist[(t.tag[s] << pl) | copy], t.cnt[s]);
-#endif
 }
 
-#ifdef XCK_EXP_PART_STAMPS
-__device__ unsigned long long pf_stamps[8];
-#define PF_STAMP(slot) do { const long long t_ = clock64(); if (threadIdx.x == 0) atomicAdd(&pf_stamps[slot], (unsigned long long)(t_ - t_s0)); t_s0 = t_; } while (0)
-#else
-#define PF_STAMP(slot) do {} while (0)
-#endif
 // cursor[z << pl | copy] = first free index of that copy of z in the output (starts at the exclusive scan of the histogram)
 template <int LEVEL>
 __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pf_part(const unsigned long long* __restrict__ keys, ShardChunks sc, BigChunks bc, PartGeom g, int pl,
@@ -336,9 +317,6 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
                                                         const uint64_t* __restrict__ vals = nullptr, uint64_t* __restrict__ out_vals = nullptr) {
     __shared__ AggTab t;
     __shared__ uint32_t s_b;
-#ifdef XCK_EXP_PART_STAMPS
-    long long t_s0 = clock64();
-#endif
     for (int s = threadIdx.x; s < PT_TAB; s += PT_THREADS) { t.tag[s] = 0xffffffffu; t.cnt[s] = 0; }
     __shared__ unsigned long long s_rc[LEVEL == 1 ? PT_RC : 1];
     if (LEVEL == 1) for (int s = threadIdx.x; s < PT_RC; s += PT_THREADS) s_rc[s] = ~0ull;
@@ -348,7 +326,6 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     unsigned long long k[PT_KPT];
     const uint32_t ok = pf_load_keys<LEVEL>(keys, sc, L, k);
     __syncthreads();
-    PF_STAMP(0);                                                          // keys arrived
     uint32_t sr[PT_KPT];                                                  // first the key's cell, then slot << 16 | rank in the slot's run; ~0 = not in the table
     static_assert(PT_CHUNK <= 65536 && PT_TAB <= 32768, "slot and rank share a word");
 #pragma unroll
@@ -356,14 +333,6 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         if (!((ok >> q) & 1u)) { sr[q] = 0xffffffffu; continue; }
         sr[q] = LEVEL == 1 ? pf_cell1_cached(k[q], g, s_rc, q > 0) : pf_cell<LEVEL>(k[q], g, L);
     }
-#ifdef XCK_EXP_PART_STAMPS
-    { uint32_t x = 0;
-#pragma unroll
-      for (int q = 0; q < PT_KPT; q++) x ^= sr[q];
-      if (x == 0x12345678u) atomicAdd(&pf_stamps[7], 1ull); }            // (forces the look-ups to have arrived)
-    __syncthreads();
-    PF_STAMP(5);                                                          // cells looked up
-#endif
 #pragma unroll
     for (int q = 0; q < PT_KPT; q++) {
         if (!((ok >> q) & 1u)) continue;
@@ -371,7 +340,6 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         sr[q] = slot >= 0 ? ((uint32_t)slot << 16) | atomicAdd(&t.cnt[slot], 1u) : 0xffffffffu;
     }
     __syncthreads();
-    PF_STAMP(1);                                                          // slots and ranks
     // run bases: one returning atomic per (chunk, cell); the runs' places inside the chunk by a block scan of the slot counts
     __shared__ uint32_t s_wave[PT_THREADS / 64];
     constexpr int SPT = PT_TAB / PT_THREADS;                              // slots per thread (blocked)
@@ -381,18 +349,13 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         const int sl = threadIdx.x * SPT + i;
         c4[i] = t.tag[sl] != 0xffffffffu ? t.cnt[sl] : 0u; g4[i] = 0; sum += c4[i];
         if (c4[i])
-#ifdef XCK_EXP_PART_NOATOM
-            g4[i] = cursor[(t.tag[sl] << pl) | copy];
-#else
             g4[i] = PF_GADD(&cursor[(t.tag[sl] << pl) | copy], c4[i]);
-#endif
     }
     uint32_t n_tab;
     uint32_t run = block_excl_scan_t<PT_THREADS>(sum, s_wave, n_tab);      // (its barriers also end the reads of t.cnt)
 #pragma unroll
     for (int i = 0; i < SPT; i++) { const int sl = threadIdx.x * SPT + i; t.cnt[sl] = run; t.base[sl] = g4[i] - run; run += c4[i]; }   // cnt := place in the chunk, base := destination - place
     __syncthreads();
-    PF_STAMP(2);                                                          // run bases (returning global atomics)
     // the keys leave through an LDS window in run order: consecutive lanes then store to consecutive addresses (a scattered 8-byte
     // store costs the address unit a cycle per lane: 55 k cycles per chunk when every key went out on its own)
     __shared__ unsigned long long s_key[PT_WIN];
@@ -409,9 +372,6 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         const uint32_t m = min((uint32_t)PT_WIN, n_tab - w0);
         for (uint32_t i = threadIdx.x; i < m; i += PT_THREADS) {
             const uint32_t dst = t.base[s_slot[i]] + w0 + i;
-#ifdef XCK_EXP_PART_NOSTORE
-            if (dst == 0xfffffff0u)
-#endif
             { out[dst] = s_key[i]; if (vals) out_vals[dst] = vals[pf_src_index<LEVEL>(sc, L, s_src[i])]; }   // (pileup hits: the value travels with its key)
         }
         __syncthreads();
@@ -423,11 +383,6 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         out[dst] = k[q];
         if (vals) out_vals[dst] = vals[pf_src_index<LEVEL>(sc, L, q * PT_THREADS + threadIdx.x)];
     }
-#ifdef XCK_EXP_PART_STAMPS
-    PF_STAMP(3);                                                          // stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PF_STAMP(4);                                                          // stores acknowledged
-#endif
 }
 
 // ---- work items --------------------------------------------------------------------------------------------------------
@@ -829,12 +784,6 @@ static int fold_partition(EngineImpl* im, KeyLayout<unsigned long long> kl, size
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((k_pf_part<1>), dim3(n_blocks1), dim3(PT_THREADS), 0, im->s_comp, (const K*)im->d_keys, sc, bc0, g, pl, S1, A);   // (S1 is the cursor array from here on)
     HIP_TRY(hipGetLastError());
-#ifdef XCK_EXP_PART_STAMPS
-    { unsigned long long st[8]; HIP_TRY(hipStreamSynchronize(im->s_comp)); HIP_TRY(hipMemcpyFromSymbol(st, HIP_SYMBOL(pf_stamps), sizeof st));
-      fprintf(stderr, "[stamps part<1>] blocks=%u cycles per block: load %.0f  cells %.0f  find+rank %.0f  atomics %.0f  store-issue %.0f  store-ack %.0f\n", n_blocks1,
-              (double)st[0] / n_blocks1, (double)st[5] / n_blocks1, (double)st[1] / n_blocks1, (double)st[2] / n_blocks1, (double)st[3] / n_blocks1, (double)st[4] / n_blocks1);
-      memset(st, 0, sizeof st); HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pf_stamps), st, sizeof st)); }
-#endif
     const int lds = pf_bucket_lds(g.sb);
     const size_t bucket_grid = (size_t)std::max(1, im->eng->knobs.fold_bucket_blocks);     // resident blocks (4 per CU by LDS) x 2: the tail evens out
     size_t n_wi2 = 0;
