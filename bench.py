@@ -26,6 +26,8 @@ Sub-records of the same JSON line:
                    users hold: BGZF blocks written by zlib level 6 (htslib's default; the headline file is written by this repo's own
                    fast compressor), and on top of that Cell Ranger's record shape (39-character read names, 16 aux tags with CB / UB
                    near the end: twice the bytes per record) - with their ratio to the headline rate.
+  configs4_well    BASELINE configs[4] (384 per-cell BAMs, SMART-seq shape, no CB / UB) at 250 k records per BAM through the same code as
+                   --workload well, rows of the sampled contigs compared with the oracle in the run.
   roofline         dominant hand-written kernel on the HBM-resident form of the same workload shape (500 M synthetic
                    reads generated on the device; one fused launch per pass), HIP-event time per launch against SURVEY
                    section 8d's algorithmic bytes;  `device_resident` holds that pass's rate and stage times.
@@ -329,6 +331,7 @@ def main():
     ap.add_argument("--workload", default="10x", choices=["10x", "well"], help="10x: BASELINE configs[2] (default); well: configs[4], 384 per-cell BAMs")
     ap.add_argument("--well-bams", type=int, default=384)
     ap.add_argument("--well-reads", type=int, default=2_000_000, help="records per per-cell BAM (--workload well)")
+    ap.add_argument("--well-sub-reads", type=int, default=250_000, help="10x run: records per per-cell BAM of the configs[4] sub-record (0 = skip it)")
     ap.add_argument("--make-room", action="store_true", help="--workload well with a short disk: delete the 10x workload's generated BAMs (those with a .ok marker of this tool) under --work")
     ap.add_argument("--selfcheck", action="store_true", help="N > 1: first count a --selfcheck-reads file with N ranks and with rank 0 alone; the output files must be identical")
     ap.add_argument("--selfcheck-reads", type=int, default=50_000_000)
@@ -535,6 +538,21 @@ def main():
             log("%s: %.2f M reads/s (%.2f of the headline)" % (key, subs[key]["value"] / 1e6, subs[key]["ratio_to_headline"]))
     eng.close()
 
+    # ---- BASELINE configs[4] at a reduced read count, so that every driver run carries a number for the multi-BAM well-based path ----
+    well = None
+    if args.well_sub_reads > 0 and world == 1:
+        try:
+            a4 = argparse.Namespace(**vars(args))
+            a4.well_reads, a4.cpu_sample, a4.warmup = args.well_sub_reads, min(args.cpu_sample, 4_000_000), 1
+            w = well_workload(a4, dev_idx, device, threads, cores, log)
+            well = dict(value=w["value"], unit="reads/s", records=w["end_to_end"]["records"], seconds=w["end_to_end"]["seconds"], bams=args.well_bams, records_per_bam=args.well_sub_reads,
+                        nnz=w["config"]["nnz"], gpu_rows_vs_oracle=w["gpu_rows_vs_oracle"], phase_seconds=w["end_to_end"]["phase_seconds"], engine_ms=w["end_to_end"]["engine_ms"],
+                        key_bits=w["end_to_end"]["key_bits"], bam_gb=w["end_to_end"]["bam_gb"], workload=w["config"]["workload"],
+                        note="configs[4] shape (384 per-cell BAMs, paired-end, no CB / UB) at %d records per BAM instead of 2 M; the full size is `bench.py --workload well`" % args.well_sub_reads)
+            log("configs[4] sub-record: %.2f M reads/s" % (w["value"] / 1e6))
+        except SystemExit as e:                                   # (a short disk, ...): the headline does not depend on it
+            well = dict(skipped=str(e))
+
     # ---- HBM-resident sub-record + roofline of the dominant kernel ----
     resident, roofline = None, None
     if args.resident_passes > 0 and world == 1:
@@ -551,7 +569,7 @@ def main():
                             host_threads_per_rank=threads, nnz=nnz),
                 multi_gpu=mgpu,
                 end_to_end=e2e, end_to_end_zlib6=subs.get("end_to_end_zlib6"), cellranger_shape=subs.get("cellranger_shape"),
-                device_resident=resident, roofline=roofline, cpu_baseline=cpu, selfcheck=selfcheck)
+                configs4_well=well, device_resident=resident, roofline=roofline, cpu_baseline=cpu, selfcheck=selfcheck)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

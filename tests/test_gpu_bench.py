@@ -34,7 +34,8 @@ def test_bench_line_and_two_rank_outputs(tmp_path):
     env = dict(os.environ, XCK_BENCH_DIR=work, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-sample", "400000", "--resident-passes", "1", "--sub-reads", "1000000"] + SIZE, env)
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-sample", "400000", "--resident-passes", "1", "--sub-reads", "1000000",
+              "--well-bams", "12", "--well-sub-reads", "20000"] + SIZE, env)
     assert d["metric"] == "reads/sec into AD/DP+basefc matrices" and d["unit"] == "reads/s" and d["n_gpus"] == 1
     assert d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["scaling"] == "strong"                               # the same file at every N: total work fixed
@@ -52,6 +53,8 @@ def test_bench_line_and_two_rank_outputs(tmp_path):
     assert z6["records"] == 1000000 and cr["records"] == 1000000 and "zlib level 6" in z6["bgzf_writer"]
     assert cr["inflated_bytes_per_record"] > 1.7 * z6["inflated_bytes_per_record"] and 0 < cr["ratio_to_headline"] and 0 < z6["ratio_to_headline"]
     assert z6["passes"] == 3 and len(z6["values_all_passes"]) == 3 and z6["value_min"] <= z6["value"] <= z6["value_max"] and "zlib level 6" in cr["bgzf_writer"]
+    w4 = d["configs4_well"]                                        # configs[4] at a reduced size inside the default run
+    assert w4["bams"] == 12 and w4["value"] > 0 and w4["gpu_rows_vs_oracle"].startswith("ok") and w4["nnz"]["count"] > 100 and "configs[4]" in w4["workload"]
     one = _read(work, 1)
     assert one["basefc/matrix.mtx"].startswith(b"%%MatrixMarket matrix coordinate integer general\n%%\n8000\t2000\t")
     for extra in (["--selfcheck", "--selfcheck-reads", "1500000"], ["--gather"]):

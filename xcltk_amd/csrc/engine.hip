@@ -159,7 +159,9 @@ __device__ __forceinline__ void frac_bounds(ReadInfo& r, double f) {
     r.m_acc = (int32_t)floor(p * (1.0 + 0x1p-50)) + 1;
 }
 __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double f) {
-    ReadInfo r = r0; frac_bounds(r, f);                               // only (read, region) pairs with a partial overlap get here
+    ReadInfo r = r0;
+    asm volatile("" : "+v"(r.n_al));                                  // (keeps the fp64 bounds here: hoisted, they cost every read of every sweep ~14 instructions)
+    frac_bounds(r, f);                                                // only (read, region) pairs with a partial overlap get here
     if (m < r.m_rej) return true;
     if (m >= r.m_acc) return false;
     return (double)m / (double)r.n_al < f;
@@ -191,13 +193,13 @@ __device__ __forceinline__ bool frac_below(int32_t m, const ReadInfo& r0, double
 #define XCK_BAF_SPLIT 1           // pileup, 64-bit keys: hits without a base go to a second stream that is never sorted
 #endif
 #ifndef XCK_BAF_NQUEUE_BYTES
-#define XCK_BAF_NQUEUE_BYTES 4096   // split mode: queue of the gap records (16 B each, about one per spliced read), flushed at the tile end
+#define XCK_BAF_NQUEUE_BYTES 3072   // split mode: queue of the gap records (16 B each, about one per spliced read), flushed at the tile end
 #endif
 #ifndef XCK_BAF_BQUEUE_BYTES
-#define XCK_BAF_BQUEUE_BYTES 4096   // split mode: queue of the hits with a base (~1 in 10), flushed at the tile end
+#define XCK_BAF_BQUEUE_BYTES 3072   // split mode: queue of the hits with a base (~1 in 10), flushed at the tile end
 #endif
 #ifndef XCK_CX_CAP
-#define XCK_CX_CAP 192            // pileup: spliced / indel reads of a tile set aside for the joint walk (beyond it they are walked in place)
+#define XCK_CX_CAP 128            // pileup: spliced / indel reads of a tile set aside for the joint walk (beyond it they are walked in place)
 #endif
 #ifndef XCK_HS_BYTES
 #define XCK_HS_BYTES 16384
@@ -212,7 +214,11 @@ constexpr int TILE_ITEMS = XCK_TILE_ITEMS;
 constexpr int TILE = JOIN_BLOCK * TILE_ITEMS;
 constexpr int HS_BYTES = XCK_HS_BYTES;   // LDS set / queue storage per block
 constexpr int HS_SLOTS = HS_BYTES / 8;   // slots of the 64-bit key set
-constexpr int CG_CAP = XCK_CG_CAP;       // staged CIGAR words
+constexpr int CG_CAP = XCK_CG_CAP;       // staged CIGAR words (basefc)
+#ifndef XCK_CG_CAP_BAF
+#define XCK_CG_CAP_BAF 1408       // pileup: with the 3 KB queues and 128 set-aside reads below its block fits 26.5 KB of LDS, i.e. 6 blocks per CU (6.14 -> 5.94 ms)
+#endif
+template <int MODE> struct CigCap { static constexpr int value = MODE == XCK_MODE_BAF ? XCK_CG_CAP_BAF : CG_CAP; };
 constexpr int ST_CAP = XCK_ST_CAP;       // staged regions / SNPs
 constexpr int ST_WIN = 64;               // staged index windows
 
@@ -230,11 +236,12 @@ template <class K, int MODE> struct JoinSmem {
     static constexpr int  STORE_BYTES = USE_SET ? SLOTS * 8 : (HAS_VAL ? (SPLIT ? XCK_BAF_BQUEUE_BYTES : 6144) : HS_BYTES);
     static constexpr int  QCAP = STORE_BYTES / (int)(sizeof(K) + (HAS_VAL ? 8 : 0));
     alignas(16) unsigned char store[STORE_BYTES];
-    uint32_t cig[CG_CAP];
+    uint32_t cig[CigCap<MODE>::value];
     static constexpr int ST_BC = MODE == XCK_MODE_BASEFC ? ST_CAP : 1;    // region ends / rows: basefc only
     int32_t  st_a[ST_CAP], st_b[ST_BC], st_c[ST_BC];
     int32_t  st_w[ST_WIN + 1];
     uint32_t cg_lo, cg_n;                // staged CIGAR range [cg_lo, cg_lo + cg_n)
+    int32_t  cg_all;                     // 1: that is the tile's whole CIGAR run
     int32_t  w0, nw;                     // basefc: staged regions [w0, w0 + nw) of the start-sorted arrays; pileup: staged SNP windows
     int32_t  k0, nk;                     // pileup: staged SNPs [k0, k0 + nk); basefc: k0 = position of the tile's first read
     uint32_t count;                      // entries currently in the queue
@@ -259,9 +266,12 @@ template <class K, int MODE> struct JoinSmem {
     __device__ unsigned long long* hkeys() { return reinterpret_cast<unsigned long long*>(store); }            // set mode
 };
 
+// (sm.cg_all - block-uniform, from k_tile_meta - says that the tile's whole CIGAR run is staged: practically always at the capacities
+// above, and the two-path form costs a handful of exec-mask instructions per word)
 template <class K, int MODE>
 __device__ __forceinline__ uint32_t cig_at(const JoinArgs<K>& a, const BatchDesc& d, const JoinSmem<K, MODE>& sm, uint32_t c) {
     uint32_t rel = c - sm.cg_lo;
+    if (__builtin_amdgcn_readfirstlane(sm.cg_all)) return sm.cig[rel];
     return rel < sm.cg_n ? sm.cig[rel] : as_global(d.cigar)[c];
 }
 
@@ -540,12 +550,18 @@ __device__ __forceinline__ uint32_t join_regions(const JoinArgs<K>& a, const Bat
     for (int32_t kb = __ballot(r.ok && r.pos < p_first) ? reg_lo : lb; kb < reg_hi; kb += 64) {
         const int32_t k = kb + lane;
         const uint32_t rel = (uint32_t)(k - lb);
-        const bool in = k < reg_hi, staged = rel < (uint32_t)n_st;
+        // (scalar: the whole chunk is staged and inside the contig - the usual case; the per-lane form below is the general one)
+        const bool whole = (uint32_t)(kb - lb) + 64u <= (uint32_t)n_st && kb + 64 <= reg_hi;
+        bool in = true, staged = true;
         int32_t s0 = std::numeric_limits<int32_t>::max(), e0 = std::numeric_limits<int32_t>::min(), row = 0;
-        if (in) { s0 = staged ? sm.st_a[rel] : as_global(a.reg_s0)[k]; e0 = staged ? sm.st_b[rel] : as_global(a.reg_e0)[k]; }
+        if (whole) { s0 = sm.st_a[rel]; e0 = sm.st_b[rel]; }
+        else {
+            in = k < reg_hi; staged = rel < (uint32_t)n_st;
+            if (in) { s0 = staged ? sm.st_a[rel] : as_global(a.reg_s0)[k]; e0 = staged ? sm.st_b[rel] : as_global(a.reg_e0)[k]; }
+        }
         const bool last = __ballot(!in || s0 >= wmax) != 0;          // sorted by start: no read of the wave reaches a region after this chunk
         unsigned long long cand = __ballot(in && s0 < wmax && e0 > wmin);
-        if (cand && in) row = staged ? sm.st_c[rel] : as_global(a.reg_row)[k];
+        if (cand) { if (whole) row = sm.st_c[rel]; else if (in) row = staged ? sm.st_c[rel] : as_global(a.reg_row)[k]; }
 #if XCK_STAMPS == 2
         if (sweep == 0) { XCK_STAMP(ts, 4); ts->d[11] += (uint32_t)__popcll(cand); }      // (slot 11: candidate regions of sweep 0)
 #endif
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     m.b = lo; m.r0 = (t - d.tile0) * TILE; m.r1 = min(m.r0 + TILE, d.n); m.pad = 0;
     const uint32_t c_lo = as_global(d.cig_off)[m.r0], c_hi = as_global(d.cig_off)[m.r1];
     const int32_t p_first = max(as_global(d.pos)[m.r0], 0), p_last = max(as_global(d.pos)[m.r1 - 1], 0);
-    m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CG_CAP);
+    m.c_lo = c_lo; m.cg_n = min(c_hi - c_lo, (uint32_t)CigCap<MODE>::value); m.pad = c_hi - c_lo <= (uint32_t)CigCap<MODE>::value ? 1 : 0;
     m.w0 = p_first >> WSS; m.nw = 0; m.e0 = 0; m.n_ent = 0; m.k0 = 0; m.nk = 0;
     if (MODE == XCK_MODE_BASEFC) {
         // first candidate region of the tile: the first one whose running-maximum end lies beyond the first read's position
@@ -680,11 +696,10 @@ __global__ __launch_bounds__(256) void k_tile_meta(BatchTable bt, TileMeta* __re
     out[t] = m;
 }
 
-#ifndef XCK_JOIN_WAVES
-#define XCK_JOIN_WAVES 4
-#endif
+// (64-bit pileup: asked to stay at 80 VGPRs, i.e. 6 waves per SIMD beside its 26.5 KB of LDS; the others have room anyway, and the
+// 128-bit pileup kernel would spill under that bound)
 template <class K, int MODE>
-__global__ __launch_bounds__(JOIN_BLOCK) __attribute__((amdgpu_waves_per_eu(XCK_JOIN_WAVES, 8))) void k_join(JoinArgs<K> a) {
+__global__ __launch_bounds__(JOIN_BLOCK) __attribute__((amdgpu_waves_per_eu((sizeof(K) == 8 && MODE == XCK_MODE_BAF) ? 6 : 4, 8))) void k_join(JoinArgs<K> a) {
     __shared__ JoinSmem<K, MODE> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     StampRec t_s0;
@@ -710,12 +725,12 @@ __global__ __launch_bounds__(JOIN_BLOCK) __attribute__((amdgpu_waves_per_eu(XCK_
         unsigned long long* set = sm.hkeys();                         // all ones = empty
         for (int s = tid; s < JoinSmem<K, MODE>::SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
     }
-    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cx_n = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.k0 = k0; sm.nk = nk;
+    if (tid == 0) { sm.count = 0; sm.ncount = 0; sm.cx_n = 0; sm.cg_lo = c_lo; sm.cg_n = cg_n; sm.cg_all = mp->pad; sm.k0 = k0; sm.nk = nk;
                     if (MODE == XCK_MODE_BASEFC) { sm.w0 = e0; sm.nw = n_ent; } else { sm.w0 = w0; sm.nw = nw; } }
     // Every global load of the prologue is issued BEFORE the first LDS store: written as load/store loops the
     // compiler waits (s_waitcnt vmcnt(0)) inside each iteration, which serialised ~7 HBM round trips per tile.
     static_assert(ST_CAP <= JOIN_BLOCK && ST_WIN + 1 <= JOIN_BLOCK, "staging assumes one element per thread");
-    constexpr int CG_IT = (CG_CAP + JOIN_BLOCK - 1) / JOIN_BLOCK;
+    constexpr int CG_IT = (CigCap<MODE>::value + JOIN_BLOCK - 1) / JOIN_BLOCK;
     uint32_t cw[CG_IT];
 #pragma unroll
     for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; cw[q] = c < cg_n ? as_global(d.cigar)[c_lo + c] : 0u; }
