@@ -277,12 +277,15 @@ __device__ __forceinline__ uint32_t cig_at(const JoinArgs<K>& a, const BatchDesc
 
 // the seven SoA fields of one read, fetched one sweep ahead of their use (software prefetch)
 struct RawRead { int32_t pos, cell; uint64_t umi; uint32_t c0, c1; uint32_t flag; int32_t mapq; uint32_t s0, s1; bool valid; };
+// The arrays are addressed as (scalar base + tile start) + a per-lane offset below 8 KB: the loads then take the base from SGPRs
+// and ONE 32-bit offset register per element size, where base + 64-bit index arithmetic cost ~12 VALU instructions per sweep -
+// in a kernel that is bound by VALU issue.  tile0 is wave-uniform; k = read of the tile (< TILE).
 template <bool WITH_SEQ>
-__device__ __forceinline__ RawRead fetch_read(const BatchDesc& d, int i) {
-    RawRead w; w.valid = i < d.n; w.pos = 0; w.cell = -1; w.umi = 0; w.c0 = w.c1 = 0; w.flag = 0; w.mapq = 0; w.s0 = w.s1 = 0;
-    if (w.valid) { w.flag = as_global(d.flag)[i]; w.mapq = as_global(d.mapq)[i]; w.cell = as_global(d.cell)[i]; w.umi = as_global(d.umi)[i];
-                   w.pos = as_global(d.pos)[i]; w.c0 = as_global(d.cig_off)[i]; w.c1 = as_global(d.cig_off)[i + 1];
-                   if (WITH_SEQ) { w.s0 = as_global(d.seq_off)[i]; w.s1 = as_global(d.seq_off)[i + 1]; } }
+__device__ __forceinline__ RawRead fetch_read(const BatchDesc& d, int tile0, uint32_t k, bool valid) {
+    RawRead w; w.valid = valid; w.pos = 0; w.cell = -1; w.umi = 0; w.c0 = w.c1 = 0; w.flag = 0; w.mapq = 0; w.s0 = w.s1 = 0;
+    if (valid) { w.flag = (as_global(d.flag) + tile0)[k]; w.mapq = (as_global(d.mapq) + tile0)[k]; w.cell = (as_global(d.cell) + tile0)[k]; w.umi = (as_global(d.umi) + tile0)[k];
+                 w.pos = (as_global(d.pos) + tile0)[k]; w.c0 = (as_global(d.cig_off) + tile0)[k]; w.c1 = (as_global(d.cig_off) + tile0)[k + 1];
+                 if (WITH_SEQ) { w.s0 = (as_global(d.seq_off) + tile0)[k]; w.s1 = (as_global(d.seq_off) + tile0)[k + 1]; } }
     return w;
 }
 
@@ -369,10 +372,14 @@ __device__ __forceinline__ void emit(const JoinArgs<K>& a, JoinSmem<K, MODE>& sm
         unsigned long long* set = sm.hkeys();
         const unsigned long long kk = (unsigned long long)key;
         uint32_t slot = set_slot<SLOTS>(kk);
+        // double hashing: the 64 lanes of a wave wait for the LONGEST probe sequence among their keys, and linear probing's
+        // clusters make that 8 - 10 probes at the fill a tile reaches; an odd, key-dependent stride (any odd stride visits every
+        // slot of a power-of-two table) keeps the sequences geometric
+        const uint32_t stride = (((uint32_t)(kk >> 7) ^ (uint32_t)(kk >> 41)) | 1u) & (SLOTS - 1);
         for (int probe = 0; probe < 24; probe++) {
             unsigned long long prev = atomicCAS(&set[slot], ~0ull, kk);
             if (prev == ~0ull || prev == kk) return;                 // new key, or a duplicate (same region, cell, UMI); no shared counter: flush points are static
-            slot = (slot + 1) & (SLOTS - 1);
+            slot = (slot + stride) & (SLOTS - 1);
         }
         emit_global<K, MODE>(a, key, val);
     } else {
@@ -459,15 +466,17 @@ __device__ __forceinline__ void flush(const JoinArgs<K>& a, JoinSmem<K, MODE>& s
         __syncthreads();
         XCK_STAMP(ts, 9);
         unsigned long long dst = sm.base;
-        const bool fits = dst != ~0ull;
         for (int w = 0; w < wave; w++) dst += sm.wcnt[w];
+        // (wave-uniform: kept in SGPRs, so that the stores take base + fragment start from scalars and one 32-bit lane offset)
+        dst = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(dst >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dst);
+        const bool fits = sm.base != ~0ull;
         for (int s = wave * PER_WAVE + lane; s < (wave + 1) * PER_WAVE; s += 64) {
             unsigned long long v = set[s];
             bool valid = v != ~0ull;
             unsigned long long m = __ballot(valid);
             if (valid) {
                 uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (fits) a.keys[dst + pre] = (K)v;
+                if (fits) (a.keys + dst)[pre] = (K)v;
                 set[s] = ~0ull;
             }
             dst += __popcll(m);
@@ -719,8 +728,13 @@ __global__ __launch_bounds__(JOIN_BLOCK) __attribute__((amdgpu_waves_per_eu((siz
     unsigned long long uor = 0;
     STAMP(0);
     RawRead W[TILE_ITEMS];
+    if (__builtin_amdgcn_readfirstlane(tile0 + TILE <= d.n)) {        // a full tile (all but the last of a batch): no per-lane bounds
 #pragma unroll
-    for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read<MODE == XCK_MODE_BAF>(d, tile0 + j * JOIN_BLOCK + tid);   // the whole tile's loads fly during the staging
+        for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read<MODE == XCK_MODE_BAF>(d, tile0, (uint32_t)(j * JOIN_BLOCK + tid), true);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TILE_ITEMS; j++) W[j] = fetch_read<MODE == XCK_MODE_BAF>(d, tile0, (uint32_t)(j * JOIN_BLOCK + tid), tile0 + j * JOIN_BLOCK + tid < d.n);
+    }                                                                 // the whole tile's loads fly during the staging
     if constexpr (JoinSmem<K, MODE>::USE_SET) {
         unsigned long long* set = sm.hkeys();                         // all ones = empty
         for (int s = tid; s < JoinSmem<K, MODE>::SLOTS; s += JOIN_BLOCK) set[s] = ~0ull;
@@ -732,14 +746,16 @@ __global__ __launch_bounds__(JOIN_BLOCK) __attribute__((amdgpu_waves_per_eu((siz
     static_assert(ST_CAP <= JOIN_BLOCK && ST_WIN + 1 <= JOIN_BLOCK, "staging assumes one element per thread");
     constexpr int CG_IT = (CigCap<MODE>::value + JOIN_BLOCK - 1) / JOIN_BLOCK;
     uint32_t cw[CG_IT];
+    const uint32_t u_clo = __builtin_amdgcn_readfirstlane(c_lo);      // (scalar starts: the loads below take base + start from SGPRs, like fetch_read)
 #pragma unroll
-    for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; cw[q] = c < cg_n ? as_global(d.cigar)[c_lo + c] : 0u; }
+    for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; cw[q] = c < cg_n ? (as_global(d.cigar) + u_clo)[c] : 0u; }
     int32_t g_a = 0, g_b = 0, g_c = 0, g_w = 0;
     if (MODE == XCK_MODE_BASEFC) {
-        if (tid < n_ent) { g_a = as_global(a.reg_s0)[e0 + tid]; g_b = as_global(a.reg_e0)[e0 + tid]; g_c = as_global(a.reg_row)[e0 + tid]; }
+        if (tid < n_ent) { g_a = (as_global(a.reg_s0) + u_lb)[(uint32_t)tid]; g_b = (as_global(a.reg_e0) + u_lb)[(uint32_t)tid]; g_c = (as_global(a.reg_row) + u_lb)[(uint32_t)tid]; }
     } else {
-        if (tid < nk) g_a = as_global(a.snp_p0)[k0 + tid];
-        if (tid < nw) g_w = as_global(d.snp_win)[w0 + tid];           // first SNP of each window
+        const int32_t u_k0 = __builtin_amdgcn_readfirstlane(k0), u_w0 = __builtin_amdgcn_readfirstlane(w0);
+        if (tid < nk) g_a = (as_global(a.snp_p0) + u_k0)[(uint32_t)tid];
+        if (tid < nw) g_w = (as_global(d.snp_win) + u_w0)[(uint32_t)tid];   // first SNP of each window
     }
 #pragma unroll
     for (int q = 0; q < CG_IT; q++) { const uint32_t c = tid + q * JOIN_BLOCK; if (c < cg_n) sm.cig[c] = cw[q]; }

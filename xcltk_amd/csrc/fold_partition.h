@@ -579,11 +579,14 @@ __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 // longer queue on one LDS word)
                 if (!(bm[rcl >> 5] & (1u << (rcl & 31)))) atomicOr(&bm[rcl >> 5], 1u << (rcl & 31));
                 uint32_t slot = set_slot<PF_SLOTS>(key) & smask;
+                // (double hashing, as in the join's set: the wave waits for its longest probe sequence, and linear probing's clusters
+                // make that one long at a load of up to 0.5; any odd stride visits every slot of the power-of-two table)
+                const uint32_t stride = ((uint32_t)(key >> 7) ^ (uint32_t)(key >> 41)) | 1u;
                 for (;;) {
                     const unsigned long long prev = atomicCAS(&set[slot], ~0ull, key);
                     if (prev == ~0ull) { win |= 1u << q; break; }
                     if (prev == key) break;
-                    slot = (slot + 1) & smask;
+                    slot = (slot + stride) & smask;
                 }
             }
             PF_LDS_BARRIER();                                               // set dead from here on: cnt32 / stage / wpre alias it
@@ -1127,10 +1130,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_hap_items(const unsigned long lo
         if (e >= n) continue;
         const uint32_t p = (runid[r] << 3) | ((uint32_t)val[r] & 7u);
         uint32_t slot = set_slot<PF_SLOTS>(key[r]) & smask;
+        const uint32_t stride = ((uint32_t)(key[r] >> 7) ^ (uint32_t)(key[r] >> 41)) | 1u;     // double hashing (see k_pf_bucket)
         for (;;) {
             const unsigned long long prev = atomicCAS(&tab[slot], ~0ull, key[r]);
             if (prev == ~0ull || prev == key[r]) break;
-            slot = (slot + 1) & smask;
+            slot = (slot + stride) & smask;
         }
         atomicOr(&pay[slot >> 1], p << ((slot & 1u) * 16));
     }
