@@ -28,6 +28,12 @@
  *   XCK_PILEUP_LGG=<l>                    at most 2^l cell groups per SNP in the pileup partitions (default 10)
  *   XCK_HIT_CAP0, XCK_HIT_SLACK           first capacity / head room of the hit accumulators (tests: reach the overflow-replay path)
  *   XCK_PUSH_STAGE=0|1, XCK_PUSH_STAGE_BYTES   xck_push_batch: packed one-copy form always / never / below this size (default 2 MB)
+ *   XCK_GPU_INFLATE=auto|<percent>|0      share of the BGZF chunks that xck_ingest_bam inflates on the handle's GPU (csrc/inflate_dev.hip; record walk and
+ *                                         parse stay on the host).  auto (the default): files of at least XCK_GPU_INFLATE_MIN_MB (512) compressed MB keep
+ *                                         XCK_GPU_INFLATE_DEPTH (6) chunks on the device and leave the rest to the host pool, XCK_GPU_INFLATE_RING (12)
+ *                                         chunks in flight in all; <percent>: a fixed share; 0 = host only.  XCK_GPU_INFLATE_FREE_CUS (32): CUs the
+ *                                         inflate streams never use.  Bit-identical results either way (a block the kernel does not finish, and every
+ *                                         chunk after a runtime error, is inflated by the host); off for handles without a device and with XCK_F_VERIFY_CRC.
  * Decoder (read when a BAM is opened or once per process): XCK_THREADS, XCK_NUMA=0, XCK_INFLATE=zlib, XCK_CHUNK_BYTES,
  * XCK_WRITE_THREADS (writer threads of xck_write_mtx), XCK_TEST_INTERN_LIMIT (tests). */
 #ifndef XCK_H
@@ -185,7 +191,7 @@ typedef struct xck_stats {
     int32_t pileup_sort_path;   /* pileup hits of the last xck_finish: 0 none yet, 1 row partition + LDS sort per item, 2 radix sort */
     int32_t fold_refinements;   /* partition fold of the last xck_finish: times the level-2 geometry had to be refined (uneven cells) */
     int32_t pileup_sort2_path;  /* pileup, region-level hits of the last xck_finish: 0 none, 1 partition + per-item hash classification (no sort), 2 radix sort, 3 partition + LDS sort per item */
-    int32_t reserved0;
+    int32_t gpu_inflate_chunks; /* BGZF chunks (~740 blocks each) whose inflate ran on the GPU since the last xck_reset (XCK_GPU_INFLATE; was reserved0) */
 } xck_stats;
 
 typedef struct xck_engine xck_engine;     /* opaque: one per GPU */

@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/xck.h"
 #include "../../xcltk_amd/csrc/xck_internal.h"
+#include "../../xcltk_amd/csrc/inflate_dev.h"
 
 namespace xck {   // what engine.hip provides; never reached through a decode-only handle
 int  engine_create(const xck_config*, xck_engine*) { return XCK_E_ARG; }
@@ -22,6 +23,13 @@ int  engine_reset(xck_engine*) { return XCK_E_ARG; }
 int  engine_stats(const xck_engine*, xck_stats*) { return XCK_E_ARG; }
 int  engine_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }
 int  engine_numa_node(const xck_engine*) { return -1; }
+int  engine_device(const xck_engine*) { return -1; }                          // no device: the decoder's GPU share of the inflate never starts
+GpuInflateSlot* gpu_inflate_slot_create(int, int, bool) { return nullptr; }
+void gpu_inflate_slot_destroy(GpuInflateSlot*) {}
+bool gpu_inflate_slot_reserve(GpuInflateSlot*, size_t, size_t, size_t) { return false; }
+int  gpu_inflate_slot_launch(GpuInflateSlot*, size_t, size_t, size_t) { return -1; }
+int  gpu_inflate_slot_wait(GpuInflateSlot*) { return -1; }
+bool gpu_inflate_slot_done(GpuInflateSlot*) { return true; }
 int  engine_push_block(xck_engine*, const void*, size_t, const xck_batch*, int, void**) { return XCK_E_ARG; }
 void engine_release_staging(xck_engine*) {}
 void fence_wait(void*) {}

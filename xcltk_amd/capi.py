@@ -93,7 +93,7 @@ class Stats(C.Structure):
                 ("ms_join", C.c_double), ("ms_sort", C.c_double), ("ms_d2h", C.c_double),
                 ("algo_bytes_join", C.c_int64), ("n_join_launches", C.c_int64), ("key_bits", C.c_int32), ("umi_bits", C.c_int32),
                 ("fold_path", C.c_int32), ("fold_fallbacks", C.c_int32), ("pileup_sort_path", C.c_int32), ("fold_refinements", C.c_int32),
-                ("pileup_sort2_path", C.c_int32), ("reserved0", C.c_int32)]
+                ("pileup_sort2_path", C.c_int32), ("gpu_inflate_chunks", C.c_int32)]
 
 
 class IngestOpts(C.Structure):

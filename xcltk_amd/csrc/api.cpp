@@ -53,6 +53,11 @@ Knobs xck::Knobs::from_env() {
     k.hit_cap0 = std::max(64ll, num("XCK_HIT_CAP0", 1ll << 20));
     k.push_stage = (int)num("XCK_PUSH_STAGE", -1);
     k.push_stage_bytes = num("XCK_PUSH_STAGE_BYTES", 2ll << 20);
+    k.gpu_inflate_pct = (!*str("XCK_GPU_INFLATE") || !strcmp(str("XCK_GPU_INFLATE"), "auto")) ? -1 : (int)std::max(0ll, std::min(100ll, num("XCK_GPU_INFLATE", 0)));
+    k.gpu_inflate_depth = (int)std::max(1ll, std::min(8ll, num("XCK_GPU_INFLATE_DEPTH", 6)));
+    k.gpu_inflate_ring = (int)num("XCK_GPU_INFLATE_RING", 12);
+    k.gpu_inflate_min_mb = (int)std::max(0ll, num("XCK_GPU_INFLATE_MIN_MB", 512));
+    k.gpu_inflate_free_cus = (int)num("XCK_GPU_INFLATE_FREE_CUS", 32);
     return k;
 }
 
@@ -206,7 +211,7 @@ int xck_push_batch(xck_engine* e, const xck_batch* b) {
 }
 int xck_push_batch_device(xck_engine* e, const xck_batch* b) { if (!e || !b) return XCK_E_ARG; FOR_IMPLS(e, engine_push(e, b, true)); return XCK_OK; }
 int xck_flush(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_flush(e)); return XCK_OK; }
-int xck_reset(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_reset(e)); return XCK_OK; }
+int xck_reset(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_reset(e)); e->gpu_inflate_chunks = 0; return XCK_OK; }
 
 int xck_finish_async(xck_engine* e) { if (!e) return XCK_E_ARG; FOR_IMPLS(e, engine_finish_async(e)); return XCK_OK; }
 

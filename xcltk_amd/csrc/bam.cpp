@@ -27,6 +27,7 @@
 #include <thread>
 #include "xck_internal.h"
 #include "inflate_fast.h"
+#include "inflate_dev.h"
 
 namespace xck {
 
@@ -211,7 +212,7 @@ class Pool {
 public:
     explicit Pool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
     ~Pool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
-    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); } cv_.notify_one(); }
+    void submit(std::function<void()> f, bool front = false) { { std::lock_guard<std::mutex> lk(mu_); if (front) q_.push_front(std::move(f)); else q_.push_back(std::move(f)); } cv_.notify_one(); }
     int size() const { return (int)th_.size(); }
     void set_affinity(const cpu_set_t& set) { for (auto& t : th_) pthread_setaffinity_np(t.native_handle(), sizeof set, &set); }
 private:
@@ -231,7 +232,7 @@ struct TaskGroup {
     std::atomic<int> thrown{0};          // a task body threw: 1 = std::bad_alloc, 2 = anything else (checked by the waiter: an exception
                                          // that leaves a pool thread would otherwise end the process through std::terminate)
     int take_thrown() { return thrown.exchange(0); }
-    void add(Pool& p, std::function<void()> f) {
+    void add(Pool& p, std::function<void()> f, bool front = false) {     // front: ahead of what is queued (work the coordinator is waiting for)
         { std::lock_guard<std::mutex> lk(mu); pending++; }
         // The notify happens UNDER the lock: a TaskGroup on the waiter's stack may be destroyed as soon as wait() returns, and
         // wait() cannot return before this task has released the mutex - after which it touches the group no more.  (Notifying
@@ -240,7 +241,7 @@ struct TaskGroup {
         // than CPUs, tools/stress_e2e.py.)
         p.submit([this, f] {
             try { f(); } catch (const std::bad_alloc&) { thrown.store(1); } catch (...) { thrown.store(2); }
-            std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); });
+            std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); }, front);
     }
     void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return pending == 0; }); }
 };
@@ -331,14 +332,19 @@ struct WalkPart {
     size_t u_begin = 0, u_end = 0, spec_start = 0, stop = 0; std::vector<RecRef> recs;
     size_t n_out = 0, n_cig = 0, n_seq = 0; std::vector<ContigRun> runs;
     size_t out_base = 0, cig_base = 0, seq_base = 0;                      // filled by the coordinator (fast path)
+    size_t i0 = 0, i1 = 0;                                                // the part's blocks: [i0, i1) of the chunk
 };
 
 struct Chunk {
     std::vector<BlockRef> blocks;
     std::vector<uint8_t> ubuf; size_t usize = 0;
+    uint8_t* ubase = nullptr;          // where the chunk's inflated bytes live: ubuf, or the pinned output block of its GPU slot
     std::vector<WalkPart> parts;
     TaskGroup tg; std::atomic<bool> failed{false}; std::string err; std::mutex emu;
     bool valid = false, new_range = false; uint32_t first_skip = 0; int range_id = 0;
+    // GPU share of the inflate (csrc/inflate_dev.hip): the pool only gathers the compressed bytes into the slot's pinned block, the task
+    // that finishes last enqueues copy-in, kernel and copy-out; walk (and the blocks the kernel left) follow when the chunk is consumed
+    bool gpu = false; std::atomic<int> copy_left{0}; std::atomic<int> gpu_rc{0}; size_t in_total = 0;
 };
 
 struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
@@ -427,6 +433,13 @@ private:
 };
 
 constexpr int N_CHUNK = 3, N_SOA = 3;
+constexpr int N_CHUNK_GPU = 16;        // ring depth with the GPU share on: its chunks need several in flight on the device (one wave per block)
+// XCK_GPU_INFLATE=<percent>: that share of the chunks is inflated on the handle's GPU (0 = off).  State of one reader:
+struct GpuShare {
+    bool tried = false, on = false, broken = false, verbose = false; int pct = 0, acc = 0, device = -1, free_cus = 32, depth = 4;
+    GpuInflateSlot* slot[N_CHUNK_GPU] = {nullptr}; bool inflight[N_CHUNK_GPU] = {false};
+    uint64_t chunks = 0, blocks = 0, left_blocks = 0, wait_ns = 0, copy_ns = 0;
+};
 struct CallerBinding;
 struct xck_bam {
     std::string path; int fd = -1; const uint8_t* map = nullptr; uint64_t fsize = 0;
@@ -442,7 +455,8 @@ struct xck_bam {
     std::vector<int32_t> range_tid;                       // per_tid_ranges: reference of every range
     bool per_tid_ranges = false; int skip_range = -1;   // position windows: one range per reference; a range is dropped once a record starts beyond its window
     Pool* pool = nullptr; int n_threads = 1;
-    Chunk ch[N_CHUNK]; int head = 0, n_sched = 0;      // ring: ch[head] is decoded next, n_sched chunks are inflating / inflated
+    Chunk ch[N_CHUNK_GPU]; int n_ring = N_CHUNK, head = 0, n_sched = 0;      // ring of n_ring chunks: ch[head] is decoded next, n_sched chunks are inflating / inflated
+    GpuShare gi;
     std::vector<uint8_t> carry;        // partial record from the previous chunk
     std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
     std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // serial walk output (slow path)
@@ -512,6 +526,20 @@ struct BamScratch {
 };
 static std::mutex g_scratch_mu;
 static std::vector<BamScratch*> g_scratch;                            // at most 4 parked sets; kept until the process ends
+// ... and so are the GPU-inflate slots of closed readers: a slot is ~70 MB of pinned + 50 MB of device memory, and pinning it anew
+// for every file cost 0.2 s per open (a 20 M-record file decodes in 0.45 s)
+static std::vector<GpuInflateSlot*> g_gpu_slots;                      // at most 16; kept until the process ends
+static GpuInflateSlot* take_gpu_slot(int device, int free_cus, bool verbose) {
+    { std::lock_guard<std::mutex> lk(g_scratch_mu);
+      for (size_t i = 0; i < g_gpu_slots.size(); i++) if (g_gpu_slots[i]->device == device) { GpuInflateSlot* s = g_gpu_slots[i]; g_gpu_slots.erase(g_gpu_slots.begin() + (long)i); return s; } }
+    return gpu_inflate_slot_create(device, free_cus, verbose);
+}
+static void park_gpu_slot(GpuInflateSlot* s) {
+    if (!s) return;
+    gpu_inflate_slot_wait(s);                                          // nothing in flight on a parked slot
+    { std::lock_guard<std::mutex> lk(g_scratch_mu); if (g_gpu_slots.size() < 16) { g_gpu_slots.push_back(s); return; } }
+    gpu_inflate_slot_destroy(s);
+}
 
 extern "C" {
 
@@ -575,6 +603,11 @@ void xck_bam_close(xck_bam* b) {
     // it was recorded on dies with the engine's staging, and waiting on such an event later fails (hipErrorStreamCaptureUnsupported
     // on ROCm 7: the next reader's first launch check then reported that stale error; tests/test_gpu_random_e2e.py seed 9)
     for (auto& so : b->soa) if (so.fence) { fence_wait(so.fence); fence_destroy(so.fence); so.fence = nullptr; }
+    if (getenv("XCK_DEBUG_TIMING") && b->gi.chunks)
+        fprintf(stderr, "[xck] ingest %s: GPU share of the inflate: %llu chunks / %llu blocks on the device (%llu of them finished by the host), gather %.0f ms of pool time, coordinator waited %.0f ms%s\n",
+                b->path.c_str(), (unsigned long long)b->gi.chunks, (unsigned long long)b->gi.blocks, (unsigned long long)b->gi.left_blocks, b->gi.copy_ns * 1e-6, b->gi.wait_ns * 1e-6,
+                b->gi.broken ? "; the device path was given up (runtime error / no memory)" : "");
+    for (auto& gs : b->gi.slot) { park_gpu_slot(gs); gs = nullptr; }
     if (b->numa_bound && b->pool) b->pool->set_affinity(b->old_affinity);   // a parked pool goes back to the full mask
     if (getenv("XCK_DEBUG_TIMING") && b->tm.chunks) {
         const DecodeTimes& t = b->tm; const double ms = 1e-6;
@@ -669,8 +702,43 @@ static void set_ranges(xck_bam* b, const xck_ingest_opts* o) {
 
 // take the next plan from the scanner and start inflating it into c (asynchronous); tid_to_contig lets the walk tasks
 // prepare the output layout of their own records
-static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMap cm_in, bool want_seq) {
-    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0;
+// One part of a chunk: inflate its blocks (all of them, or - st given - only those the GPU kernel left: status != 0), then walk the
+// records of its byte range speculatively.  Pool task.
+static void run_part(Chunk* cp, const uint8_t* map, bool verify_crc, WalkPart* wpp, DecodeTimes* tmp_, const ContigMap cm, bool want_seq, const int32_t* st) {
+    if (!t_zs.ok) { cp->failed = true; return; }
+    const auto t_a = std::chrono::steady_clock::now();
+    struct Acc { DecodeTimes* t; std::chrono::steady_clock::time_point a, b; bool walked = false;
+                 ~Acc() { const auto e = std::chrono::steady_clock::now(); if (!walked) b = e;
+                          t->inflate += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+                          t->walk += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(e - b).count(); } } acc{tmp_, t_a, t_a};
+    for (size_t i = wpp->i0; i < wpp->i1; i++) {
+        if (st && st[i] == 0) continue;
+        std::string e;
+        if (!bgzf_inflate(map, cp->blocks[i], cp->ubase + cp->blocks[i].uoff, verify_crc, &t_zs.zs, &e)) {
+            std::lock_guard<std::mutex> lk(cp->emu); cp->failed = true; cp->err = e; return;
+        }
+    }
+    // speculative record walk over this range
+    acc.b = std::chrono::steady_clock::now(); acc.walked = true;
+    const uint8_t* u = cp->ubase; size_t o = wpp->spec_start; const size_t end = wpp->u_end;
+    if (o > end) { wpp->stop = o; return; }
+    int32_t cur_c = INT32_MIN;
+    while (o + 4 <= end) {
+        uint32_t bs = le32(u + o);
+        if (bs < 32 || o + 4 + (size_t)bs > end) break;
+        const uint8_t* r = u + o + 4;
+        const RecRef rr{r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)};
+        const int32_t ctg = cm(rr.tid, (int32_t)le32(r + 4));
+        if (ctg != cur_c) { wpp->runs.push_back({(uint32_t)wpp->recs.size(), ctg}); cur_c = ctg; }
+        if (ctg >= 0) { wpp->n_out++; wpp->n_cig += rr.n_cig; if (want_seq) wpp->n_seq += (rr.l_seq + 1) / 2; }
+        wpp->recs.push_back(rr);
+        o += 4 + (size_t)bs;
+    }
+    wpp->stop = o;
+}
+
+static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const ContigMap cm_in, bool want_seq) {
+    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0; c.gpu = false; c.gpu_rc = 0;
     if (b->scan_end) return;
     ChunkPlan pl = b->scanner->next();
     if (pl.end) { b->scan_end = true; return; }
@@ -679,50 +747,59 @@ static void schedule_chunk(xck_bam* b, Chunk& c, bool verify_crc, const ContigMa
     if (c.blocks.empty() && !c.failed) return;
     c.valid = true; c.usize = pl.usize;
     const size_t usz = pl.usize;
-    if (c.ubuf.size() < usz + 8) c.ubuf.resize(usz + 8);
     const size_t nb = c.blocks.size();
+    // ---- does this chunk go to the GPU?  (a fixed share of the chunks; small chunks - the tail of a range - stay on the host)
+    GpuShare& gi = b->gi;
+    GpuInflateSlot* gs = nullptr;
+    if (gi.on && !gi.broken && !verify_crc && nb >= 64 && usz < (size_t(1) << 31)) {
+        bool want;
+        if (gi.pct > 0) { gi.acc += gi.pct; want = gi.acc >= 100; if (want) gi.acc -= 100; }       // a fixed share
+        else {                                                            // auto: keep gi.depth chunks on the device, the pool takes the rest -
+            int busy = 0;                                                 // the shares then follow the two sides' speeds on this file and this box
+            for (int k = 0; k < b->n_ring; k++) if (gi.inflight[k] && gi.slot[k] && !gpu_inflate_slot_done(gi.slot[k])) busy++;
+            // ... but never the chunk the coordinator needs next or the one after (a device chunk takes tens of milliseconds, the pool
+            // delivers in three: the first chunks of a file, and whatever follows a drained ring, stay on the host)
+            want = busy < gi.depth && b->n_sched >= 2;
+        }
+        if (want) {
+            size_t tin = 0; for (size_t i = 0; i < nb; i++) tin += ((size_t)c.blocks[i].data_len + 3) & ~size_t(3);
+            if (!gi.slot[ci]) gi.slot[ci] = take_gpu_slot(gi.device, gi.free_cus, gi.verbose && ci == 0);
+            gs = gi.slot[ci];
+            if (gs && gi.inflight[ci]) { gpu_inflate_slot_wait(gs); gi.inflight[ci] = false; }   // (a chunk that was dropped unconsumed)
+            if (!gs || !gpu_inflate_slot_reserve(gs, tin + 8, usz + 8, nb)) { gi.broken = true; gs = nullptr; }   // no device memory: the host does it all from here on
+            else c.in_total = tin;
+        }
+    }
+    if (gs) { c.gpu = true; c.ubase = gs->h_out; gi.inflight[ci] = true; }
+    else { if (c.ubuf.size() < usz + 8) c.ubuf.resize(usz + 8); c.ubase = c.ubuf.data(); }
     const size_t per = std::max<size_t>(1, (nb + (size_t)b->n_threads * 4 - 1) / ((size_t)b->n_threads * 4));
     const size_t n_parts = (nb + per - 1) / per;
     c.parts.resize(n_parts);
     const size_t skip0 = c.first_skip;             // bytes before the first record (first chunk of the file / of an index range)
+    ContigMap cm = cm_in; cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
+    if (gs) {                                       // block table: where every block's stream sits in the gathered input, where its bytes go
+        size_t at = 0;
+        for (size_t i = 0; i < nb; i++) { gs->h_bl[i] = DevBlock{(uint32_t)at, c.blocks[i].data_len, (uint32_t)c.blocks[i].uoff, c.blocks[i].isize}; at += ((size_t)c.blocks[i].data_len + 3) & ~size_t(3); }
+        c.copy_left = (int)n_parts; gi.chunks++; gi.blocks += nb;
+    }
     for (size_t pi = 0; pi < n_parts; pi++) {
         size_t i0 = pi * per, i1 = std::min(nb, i0 + per);
         WalkPart& wp = c.parts[pi];
+        wp.i0 = i0; wp.i1 = i1;
         wp.u_begin = c.blocks[i0].uoff; wp.u_end = c.blocks[i1 - 1].uoff + c.blocks[i1 - 1].isize;
         wp.spec_start = wp.u_begin + (pi == 0 ? skip0 : 0); wp.stop = wp.spec_start; wp.recs.clear();
         wp.n_out = wp.n_cig = wp.n_seq = 0; wp.runs.clear();
         Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp; DecodeTimes* tmp_ = &b->tm;
-        ContigMap cm = cm_in; cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
-        c.tg.add(*b->pool, [cp, map, i0, i1, verify_crc, wpp, tmp_, cm, want_seq] {
-            if (!t_zs.ok) { cp->failed = true; return; }
+        if (!gs) { c.tg.add(*b->pool, [cp, map, verify_crc, wpp, tmp_, cm, want_seq] { run_part(cp, map, verify_crc, wpp, tmp_, cm, want_seq, nullptr); }); continue; }
+        GpuShare* gip = &gi; const size_t nb_ = nb, usz_ = usz;
+        c.tg.add(*b->pool, [cp, map, i0, i1, gs, gip, nb_, usz_] {
             const auto t_a = std::chrono::steady_clock::now();
-            struct Acc { DecodeTimes* t; std::chrono::steady_clock::time_point a, b; bool walked = false;
-                         ~Acc() { const auto e = std::chrono::steady_clock::now(); if (!walked) b = e;
-                                  t->inflate += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
-                                  t->walk += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(e - b).count(); } } acc{tmp_, t_a, t_a};
-            for (size_t i = i0; i < i1; i++) {
-                std::string e;
-                if (!bgzf_inflate(map, cp->blocks[i], cp->ubuf.data() + cp->blocks[i].uoff, verify_crc, &t_zs.zs, &e)) {
-                    std::lock_guard<std::mutex> lk(cp->emu); cp->failed = true; cp->err = e; return;
-                }
+            for (size_t i = i0; i < i1; i++) memcpy(gs->h_in + gs->h_bl[i].in_off, map + cp->blocks[i].coff + cp->blocks[i].data_off, cp->blocks[i].data_len);
+            __atomic_fetch_add(&gip->copy_ns, ns_since(t_a), __ATOMIC_RELAXED);
+            if (cp->copy_left.fetch_sub(1) == 1) {                         // the chunk's compressed bytes are gathered: hand it to the device
+                const int rc = gpu_inflate_slot_launch(gs, cp->in_total, usz_, nb_);
+                cp->gpu_rc = rc;
             }
-            // speculative record walk over this range
-            acc.b = std::chrono::steady_clock::now(); acc.walked = true;
-            const uint8_t* u = cp->ubuf.data(); size_t o = wpp->spec_start; const size_t end = wpp->u_end;
-            if (o > end) { wpp->stop = o; return; }
-            int32_t cur_c = INT32_MIN;
-            while (o + 4 <= end) {
-                uint32_t bs = le32(u + o);
-                if (bs < 32 || o + 4 + (size_t)bs > end) break;
-                const uint8_t* r = u + o + 4;
-                const RecRef rr{r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)};
-                const int32_t ctg = cm(rr.tid, (int32_t)le32(r + 4));
-                if (ctg != cur_c) { wpp->runs.push_back({(uint32_t)wpp->recs.size(), ctg}); cur_c = ctg; }
-                if (ctg >= 0) { wpp->n_out++; wpp->n_cig += rr.n_cig; if (want_seq) wpp->n_seq += (rr.l_seq + 1) / 2; }
-                wpp->recs.push_back(rr);
-                o += 4 + (size_t)bs;
-            }
-            wpp->stop = o;
         });
     }
 }
@@ -907,6 +984,15 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads)
         if (!e->dec.use_barcodes && !e->dec.use_umi) e->intern.clear();
         set_ranges(b, o);
+        if (!b->gi.tried) {                                    // GPU share of the inflate: a handle with a device, XCK_GPU_INFLATE > 0, no CRC checks asked for
+            b->gi.tried = true;
+            const int dev = engine_device(e), pct = e->knobs.gpu_inflate_pct;
+            // (files of a few chunks - the per-cell BAMs of a well-based run - are done before the device has returned its first chunk)
+            uint64_t span = b->fsize;
+            if (b->use_ranges) { span = 0; for (auto& r : b->ranges) span += (r.second >> 16) - (r.first >> 16); }
+            const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20;
+            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
+        }
         bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
         std::vector<ScanRange> rg;
         if (b->use_ranges) for (auto& r : b->ranges) rg.push_back({r.first >> 16, (uint32_t)(r.first & 0xffff), r.second >> 16});
@@ -916,9 +1002,10 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     auto t_ph = std::chrono::steady_clock::now();
     auto phase = [&](uint64_t& acc) { const auto now = std::chrono::steady_clock::now(); acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_ph).count(); t_ph = now; };
     // keep the ring full: while this chunk is stitched and parsed the pool inflates the next two
-    while (b->n_sched < N_CHUNK && !b->scan_end) {
-        Chunk& nc = b->ch[(b->head + b->n_sched) % N_CHUNK];
-        schedule_chunk(b, nc, crc, cm, e->dec.want_seq);
+    while (b->n_sched < b->n_ring && !b->scan_end) {
+        const int ci = (b->head + b->n_sched) % b->n_ring;
+        Chunk& nc = b->ch[ci];
+        schedule_chunk(b, nc, ci, crc, cm, e->dec.want_seq);
         if (b->scan_end) break;
         b->n_sched++;
     }
@@ -931,8 +1018,27 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
     c.tg.wait();
     if (const int th = c.tg.take_thrown()) { b->err = th == 1 ? "out of host memory (BGZF inflate / record walk)" : "C++ exception in a decoder task"; return th == 1 ? XCK_E_NOMEM : XCK_E_IO; }
+    if (c.gpu && c.valid && !c.failed && !(b->skip_range >= 0 && c.range_id == b->skip_range)) {
+        // the device's part is over (or never started): whatever it did not inflate - single blocks with a non-zero status, or the
+        // whole chunk after a runtime error - the pool inflates now, and every part walks its records as on the host path
+        GpuInflateSlot* gs = b->gi.slot[b->head];
+        const auto t_w = std::chrono::steady_clock::now();
+        bool dev_ok = c.gpu_rc.load() == 0 && gpu_inflate_slot_wait(gs) == 0;
+        b->gi.inflight[b->head] = false;
+        b->gi.wait_ns += ns_since(t_w);
+        if (!dev_ok) b->gi.broken = true;                                 // the device path stays off for the rest of this reader
+        else e->gpu_inflate_chunks++;
+        const int32_t* st = dev_ok ? gs->h_st : nullptr;
+        if (dev_ok) for (size_t i = 0; i < c.blocks.size(); i++) b->gi.left_blocks += st[i] != 0;
+        else b->gi.left_blocks += c.blocks.size();
+        Chunk* cp = &c; const uint8_t* map = b->map; DecodeTimes* tmp_ = &b->tm; const bool want_seq = e->dec.want_seq;
+        for (WalkPart& wp : c.parts) { WalkPart* wpp = &wp; c.tg.add(*b->pool, [cp, map, wpp, tmp_, cm, want_seq, st] { run_part(cp, map, false, wpp, tmp_, cm, want_seq, st); }, true); }   // (ahead of the later chunks' inflate tasks)
+        c.tg.wait();
+        if (const int th = c.tg.take_thrown()) { b->err = th == 1 ? "out of host memory (BGZF inflate / record walk)" : "C++ exception in a decoder task"; return th == 1 ? XCK_E_NOMEM : XCK_E_IO; }
+    }
     if (b->skip_range >= 0 && c.range_id == b->skip_range && !c.failed) {   // rest of a reference whose position window is behind us
-        b->head = (b->head + 1) % N_CHUNK; b->n_sched--;
+        if (c.gpu && b->gi.inflight[b->head]) { gpu_inflate_slot_wait(b->gi.slot[b->head]); b->gi.inflight[b->head] = false; }
+        b->head = (b->head + 1) % b->n_ring; b->n_sched--;
         b->carry.clear();
         return decode_next_chunk(e, b, o);
     }
@@ -942,7 +1048,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         if (!b->use_ranges && b->tm.chunks > 1 && !b->carry.empty()) { b->err = "internal: carry at a range start"; return XCK_E_IO; }
         b->carry.clear(); b->stitch_skip = c.first_skip;
     }
-    const uint8_t* u = c.ubuf.data(); const size_t usz = c.usize; size_t off = 0;
+    const uint8_t* u = c.ubase; const size_t usz = c.usize; size_t off = 0;
     if (b->stitch_skip) { off = b->stitch_skip; b->stitch_skip = 0; if (off > usz) { b->err = "corrupt BAM header offset"; return XCK_E_IO; } }
     // ---- fast path: no carried-over bytes, and every part's speculative walk began where the previous one ended ----
     bool fast = b->carry.empty() && !(o->max_records > 0);
@@ -992,7 +1098,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         phase(b->tm.layout);
         { TaskGroup tg; const int32_t smp = o->sample;
           for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
-              tg.add(*b->pool, [b, e, smp, wpp, cm, &flags] { parse_part(b, e, smp, wpp, cm, &flags); }); }
+              tg.add(*b->pool, [b, e, smp, wpp, cm, &flags] { parse_part(b, e, smp, wpp, cm, &flags); }, true); }   // (ahead of the later chunks' inflate tasks: the coordinator waits for these)
           tg.wait();
           if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
         phase(b->tm.wait_parse);
@@ -1071,7 +1177,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     // ---- parse (parallel) ----
     { TaskGroup tg; const int64_t per = std::max<int64_t>(4096, (limit + b->n_threads * 4 - 1) / (b->n_threads * 4));
       for (int64_t r0 = 0; r0 < limit; r0 += per) { int64_t r1 = std::min(limit, r0 + per); int32_t smp = o->sample;
-          tg.add(*b->pool, [b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }); }
+          tg.add(*b->pool, [b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }, true); }
       tg.wait();
       if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
     phase(b->tm.wait_parse);
@@ -1089,7 +1195,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         }
     }
     b->n_records += limit;
-    b->head = (b->head + 1) % N_CHUNK; b->n_sched--;
+    b->head = (b->head + 1) % b->n_ring; b->n_sched--;
     if (hit_limit) { b->done = true; for (auto& cc : b->ch) cc.tg.wait(); }
     return 1;
 }

@@ -2733,13 +2733,15 @@ int engine_reset(xck_engine* e) {
     return 0;
 }
 
+int engine_device(const xck_engine* e) { return e->n_impl > 0 && e->impls[0] ? ((const EngineImpl*)e->impls[0])->device : -1; }
+
 int engine_stats(const xck_engine* e, xck_stats* out) {
     const EngineImpl* im = (const EngineImpl*)e->impl;
     if (!im) return XCK_E_STATE;
     *out = im->st; out->key_bits = im->key_bits; out->umi_bits = im->ubits;
     out->n_join_launches = im->n_join_launches;
     out->fold_path = im->fold_path; out->fold_fallbacks = im->fold_fallbacks; out->pileup_sort_path = im->pileup_sort_path; out->fold_refinements = im->fold_refinements;
-    out->pileup_sort2_path = im->pileup_sort2_path; out->reserved0 = 0;
+    out->pileup_sort2_path = im->pileup_sort2_path; out->gpu_inflate_chunks = (int32_t)std::min<int64_t>(e->gpu_inflate_chunks.load(), INT32_MAX);
     return 0;
 }
 

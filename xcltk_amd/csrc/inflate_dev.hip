@@ -1,0 +1,394 @@
+// inflate_dev.hip - raw-DEFLATE decoder for BGZF blocks on the GPU (gfx950): one 64-lane wave per block.
+//
+// Replaces, for the share of the chunks the host decoder hands over (csrc/bam.cpp, XCK_GPU_INFLATE), the inflate that pysam / htslib
+// do inside AlignmentFile.fetch (xcltk/rdr/fc/core.py:73-76, utils/sam.py:105-118); the record walk and the field parse stay on the host.
+// Why: end to end the engine is bound by the host's BGZF inflate (73 - 85 % of the ingest CPU time on 16 cores,
+// profiles/r02_d_ingest_*.log) while the GPU idles.  BGZF blocks are independent <= 64 KiB deflate streams, so a chunk of
+// ~750 blocks is 750 waves of work.  Inside a block DEFLATE is serial - symbol boundaries are only known after decoding the
+// previous symbol - so lane 0 runs the Huffman state machine and the OTHER 63 lanes do what is parallel:
+//   * decode tables are built by all lanes into LDS (10-bit primary + sub-tables; a code that needs more LDS than the block's
+//     budget marks the block "not done" and the host inflates it - the compressed bytes never left the host);
+//   * lane 0 decodes a run of literals into a 64-byte LDS buffer until it meets a match (or the buffer is full); the wave then
+//     stores the literals with ONE coalesced byte store and copies the match with one load + one store per 64 bytes:
+//     out[op + i] = out[op - dist + i % dist] reads only bytes that already exist, so overlapping matches need no serial loop.
+// Status per block: 0 = inflated (exactly isize bytes), non-zero = left to the host decoder (csrc/inflate_fast.h / zlib).
+#include <cstdint>
+#include <cstdio>
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include "inflate_dev.h"
+
+namespace xck {
+
+namespace {
+
+struct DHuff { uint16_t val; uint8_t len; uint8_t op; };
+// op: 0 literal | 0x10+x length / distance base in val with x extra bits | 0x20 end of block | 0x40 invalid | 0x80+s sub-table link
+
+constexpr int D_LIT_TB = 10, D_DIST_TB = 8;
+constexpr int D_LIT_MAX = (1 << D_LIT_TB) + 768;          // primary + sub-table budget (blocks that need more go to the host)
+constexpr int D_DIST_MAX = (1 << D_DIST_TB) + 256;
+constexpr int LITBUF = 64;
+
+__device__ const uint16_t d_len_base[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+__device__ const uint8_t  d_len_extra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+__device__ const uint16_t d_dist_base[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
+__device__ const uint8_t  d_dist_extra[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+__device__ const uint8_t  d_cl_order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+
+struct Smem {
+    DHuff lit[D_LIT_MAX];
+    DHuff dist[D_DIST_MAX];
+    uint8_t lens[320];                    // code lengths: literal / length alphabet, then distance alphabet
+    uint16_t code[320];                   // canonical code (bit-reversed) of every symbol
+    uint16_t sub_off[1 << D_LIT_TB];      // sub-table offset per primary index (0 = none)
+    uint8_t  sub_bits[1 << D_LIT_TB];
+    uint8_t  litbuf[LITBUF];
+    int32_t  count[16], first[16];
+    int32_t  used, ok;
+};
+
+__device__ __forceinline__ uint32_t brev(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+
+// all 64 lanes: decode table for `n_sym` code lengths at lens[]; kind 0 literal / length, 1 distance.  Returns false (uniform)
+// when the code is over-subscribed or does not fit the LDS budget.
+__device__ bool build_table(Smem& sm, const uint8_t* lens, uint16_t* code, int n_sym, int tb, DHuff* tab, int tab_max, int kind, int lane) {
+    if (lane < 16) sm.count[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {                                       // counts, first codes, canonical code per symbol: 300 cheap serial steps
+        for (int i = 0; i < n_sym; i++) sm.count[lens[i]]++;
+        sm.count[0] = 0;
+        int left = 1, okf = 1; uint32_t c = 0;
+        for (int l = 1; l <= 15; l++) { left = left * 2 - sm.count[l]; if (left < 0) okf = 0; }
+        int nxt[16];
+        for (int l = 1; l <= 15; l++) { c = (c + (uint32_t)sm.count[l - 1]) << 1; nxt[l] = (int)c; }
+        for (int i = 0; i < n_sym; i++) { const int l = lens[i]; code[i] = l ? (uint16_t)brev((uint32_t)nxt[l]++, l) : 0; }
+        sm.ok = okf; sm.used = 1 << tb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!sm.ok) return false;
+    const int psize = 1 << tb;
+    DHuff inval; inval.val = 0; inval.len = 1; inval.op = 0x40;
+    for (int i = lane; i < psize; i += 64) { tab[i] = inval; sm.sub_bits[i] = 0; sm.sub_off[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    // long codes: extra bits every primary prefix needs (max over its codes) - LDS atomicMax on bytes is not available, use lane 0
+    if (lane == 0) {
+        bool any = false;
+        for (int s = 0; s < n_sym; s++) { const int l = lens[s]; if (l > tb) { any = true; const uint32_t p = code[s] & (uint32_t)(psize - 1); if (l - tb > sm.sub_bits[p]) sm.sub_bits[p] = (uint8_t)(l - tb); } }
+        if (any) {
+            int used = psize;
+            for (int p = 0; p < psize && used <= tab_max; p++) if (sm.sub_bits[p]) {
+                const int sz = 1 << sm.sub_bits[p];
+                if (used + sz > tab_max) { used = tab_max + 1; break; }
+                sm.sub_off[p] = (uint16_t)used;
+                DHuff lk; lk.val = (uint16_t)used; lk.len = (uint8_t)tb; lk.op = (uint8_t)(0x80 | sm.sub_bits[p]);
+                tab[p] = lk;
+                for (int k = 0; k < sz; k++) tab[used + k] = inval;
+                used += sz;
+            }
+            sm.used = used;
+            if (used > tab_max) sm.ok = 0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!sm.ok) return false;
+    for (int s = lane; s < n_sym; s += 64) {               // every lane fills the entries of its symbols
+        const int l = lens[s]; if (!l) continue;
+        DHuff e; e.len = (uint8_t)l;
+        if (kind == 0) {
+            if (s < 256) { e.val = (uint16_t)s; e.op = 0; }
+            else if (s == 256) { e.val = 0; e.op = 0x20; }
+            else if (s <= 285) { e.val = d_len_base[s - 257]; e.op = (uint8_t)(0x10 | d_len_extra[s - 257]); }
+            else { e.val = 0; e.op = 0x40; }
+        } else {
+            if (s < 30) { e.val = d_dist_base[s]; e.op = (uint8_t)(0x10 | d_dist_extra[s]); } else { e.val = 0; e.op = 0x40; }
+        }
+        const uint32_t r = code[s];
+        if (l <= tb) { for (uint32_t k = r; k < (uint32_t)psize; k += 1u << l) tab[k] = e; }
+        else {
+            const uint32_t p = r & (uint32_t)(psize - 1); const int sb = sm.sub_bits[p];
+            e.len = (uint8_t)(l - tb);
+            for (uint32_t k = r >> tb; k < (1u << sb); k += 1u << (l - tb)) tab[sm.sub_off[p] + k] = e;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// The compressed stream reaches lane 0 through an LDS window: the whole wave loads IN_WIN bytes at a time (aligned dwords,
+// coalesced), lane 0 takes aligned dwords out of LDS.  (A per-lane byte pointer into global memory cost four dependent byte
+// loads - about a microsecond - per 32 bits of input.)  Coordinates: byte s of the stream sits at c = s + A of the 4-byte
+// aligned buffer that starts at (stream address - A), A = address & 3.
+constexpr int IN_WIN = 1024;                               // bytes staged per fill (a multiple of 256)
+struct BitIn {
+    uint32_t pos;                                          // next aligned-buffer coordinate to load (multiple of 2)
+    uint32_t wlo;                                          // the window holds coordinates [wlo, wlo + IN_WIN)
+    uint64_t bb; int bc;
+    __device__ __forceinline__ uint32_t bits(int n) const { return (uint32_t)(bb & ((1ull << n) - 1)); }
+    __device__ __forceinline__ void drop(int n) { bb >>= n; bc -= n; }
+    // 16 bits at a time until more than 48 bits are buffered (a length + distance pair needs at most 48); false = the window
+    // is used up before that
+    __device__ __forceinline__ bool refill(const uint32_t* win) {
+        const uint16_t* w16 = (const uint16_t*)win;
+        while (bc <= 48) {
+            if (pos + 2 > wlo + IN_WIN) return false;
+            bb |= (uint64_t)w16[(pos - wlo) >> 1] << bc; bc += 16; pos += 2;
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, const DevBlock* __restrict__ blocks, int n_blocks,
+                                                uint8_t* out, int32_t* __restrict__ status) {
+    __shared__ Smem sm;
+    __shared__ uint32_t win[IN_WIN / 4];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n_blocks) return;
+    const DevBlock blk = blocks[b];
+    uint8_t* const o0 = out + blk.out_off;
+    const uint32_t out_len = blk.out_len;
+    if (out_len == 0) { if (lane == 0) status[b] = 0; return; }
+    const uint8_t* const sp = in + blk.in_off;
+    const uint32_t A = (uint32_t)((uintptr_t)sp & 3u);
+    const uint32_t* const abase = (const uint32_t*)(sp - A);           // 4-byte aligned view of the stream
+    const uint32_t c_end = A + blk.in_len;                             // first coordinate past the stream
+    auto fill = [&](uint32_t wlo) {                                    // all lanes; words past the stream read as zero
+#pragma unroll
+        for (int j = 0; j < IN_WIN / 256; j++) { const uint32_t c = wlo + (uint32_t)(j * 256 + lane * 4); win[j * 64 + lane] = c < c_end ? abase[c >> 2] : 0u; }
+        __builtin_amdgcn_wave_barrier();
+    };
+    BitIn bi; bi.pos = 0; bi.wlo = 0; bi.bb = 0; bi.bc = 0;            // (lane 0's state; the other lanes carry dead copies)
+    fill(0);
+    if (lane == 0) { bi.refill(win); bi.drop((int)(8 * A)); }          // skip the A bytes before the stream
+    uint32_t op = 0;                                                   // bytes produced so far (wave-uniform)
+    int err = 0;
+    for (;;) {
+        // ---- block header (lane 0), broadcast; the window is moved first so that a whole header (< 400 bytes) fits ----
+        { uint32_t pos = __builtin_amdgcn_readfirstlane(bi.pos), wlo = __builtin_amdgcn_readfirstlane(bi.wlo);
+          if (pos > wlo + IN_WIN - 512) { fill(pos & ~3u); bi.wlo = pos & ~3u; } }
+        int btype = 0, bfinal = 0, hlit = 0, hdist = 0;
+        if (lane == 0) {
+            bi.refill(win);
+            if (bi.bc < 3) err = 1;
+            bfinal = (int)bi.bits(1); btype = (int)((bi.bb >> 1) & 3); bi.drop(3);
+            if (btype == 3) err = 2;
+            if (!err && btype == 2) {
+                bi.refill(win);
+                hlit = (int)bi.bits(5) + 257; bi.drop(5); hdist = (int)bi.bits(5) + 1; bi.drop(5);
+                const int hclen = (int)bi.bits(4) + 4; bi.drop(4);
+                if (hlit > 286 || hdist > 30) err = 3;
+                uint8_t pl[19];
+                for (int i = 0; i < 19; i++) pl[i] = 0;
+                for (int i = 0; i < hclen && !err; i++) { if (bi.bc < 3) bi.refill(win); if (bi.bc < 3) { err = 4; break; } pl[d_cl_order[i]] = (uint8_t)bi.bits(3); bi.drop(3); }
+                // code-length code: canonical decode by counting (19 symbols, <= 7 bits)
+                int cnt[8] = {0}, firstc[8], firsts[8]; uint8_t sorted[19];
+                for (int i = 0; i < 19; i++) cnt[pl[i]]++;
+                cnt[0] = 0; { int c = 0, q = 0; for (int l = 1; l <= 7; l++) { c = (c + cnt[l - 1]) << 1; firstc[l] = c; firsts[l] = q; q += cnt[l]; } }
+                { int pos[8]; for (int l = 1; l <= 7; l++) pos[l] = firsts[l]; for (int i = 0; i < 19; i++) if (pl[i]) sorted[pos[pl[i]]++] = (uint8_t)i; }
+                int n = 0; const int tot = hlit + hdist;
+                while (n < tot && !err) {
+                    bi.refill(win);
+                    int code = 0, l = 0, sym = -1;
+                    for (l = 1; l <= 7; l++) {                         // bit-serial canonical decode (codes arrive most significant bit first)
+                        code = (code << 1) | (int)((bi.bb >> (l - 1)) & 1);
+                        const int d = code - firstc[l];
+                        if (cnt[l] && d >= 0 && d < cnt[l]) { sym = sorted[firsts[l] + d]; break; }
+                    }
+                    if (sym < 0 || l > bi.bc) { err = 5; break; }
+                    bi.drop(l);
+                    if (sym < 16) sm.lens[n++] = (uint8_t)sym;
+                    else {
+                        int r; uint8_t v = 0;
+                        if (sym == 16) { if (!n) { err = 6; break; } r = 3 + (int)bi.bits(2); bi.drop(2); v = sm.lens[n - 1]; }
+                        else if (sym == 17) { r = 3 + (int)bi.bits(3); bi.drop(3); }
+                        else { r = 11 + (int)bi.bits(7); bi.drop(7); }
+                        if (n + r > tot) { err = 7; break; }
+                        while (r--) sm.lens[n++] = v;
+                    }
+                    if (bi.bc < 0) { err = 8; break; }
+                }
+                if (!err && sm.lens[256] == 0) err = 9;
+            } else if (!err && btype == 1) {
+                for (int i = 0; i < 144; i++) sm.lens[i] = 8; for (int i = 144; i < 256; i++) sm.lens[i] = 9;
+                for (int i = 256; i < 280; i++) sm.lens[i] = 7; for (int i = 280; i < 288; i++) sm.lens[i] = 8;
+                for (int i = 0; i < 30; i++) sm.lens[288 + i] = 5;
+                hlit = 288; hdist = 30;
+            }
+        }
+        err = __builtin_amdgcn_readfirstlane(err);
+        if (err) break;
+        btype = __builtin_amdgcn_readfirstlane(btype); bfinal = __builtin_amdgcn_readfirstlane(bfinal);
+        hlit = __builtin_amdgcn_readfirstlane(hlit); hdist = __builtin_amdgcn_readfirstlane(hdist);
+        __builtin_amdgcn_wave_barrier();
+        if (btype == 0) {                                              // stored block: lane 0 finds the byte position, the wave copies
+            uint32_t len = 0, s_at = 0;
+            if (lane == 0) {
+                bi.drop(bi.bc & 7);
+                uint32_t c = bi.pos - (uint32_t)(bi.bc >> 3);          // coordinate of the next unread byte
+                bi.bb = 0; bi.bc = 0;
+                if (c + 4 > c_end) err = 10;
+                else {
+                    const uint8_t* q = sp - A + c;
+                    len = (uint32_t)q[0] | ((uint32_t)q[1] << 8); const uint32_t nlen = (uint32_t)q[2] | ((uint32_t)q[3] << 8);
+                    if ((len ^ nlen) != 0xffff) err = 11;
+                    c += 4;
+                    if (!err && (c + len > c_end || out_len - op < len)) err = 12;
+                    s_at = c;
+                    // resume the bit stream after the stored bytes: aligned coordinate + partial dword
+                    const uint32_t nxt = c + len;
+                    bi.pos = nxt & ~3u;                                // the window is moved here below (4-byte aligned for the fill)
+                    bi.bc = -(int)(8 * (nxt & 3u));                    // bits to discard once the next words are loaded
+                }
+            }
+            err = __builtin_amdgcn_readfirstlane(err);
+            if (err) break;
+            len = __builtin_amdgcn_readfirstlane(len); s_at = __builtin_amdgcn_readfirstlane(s_at);
+            const uint8_t* s0 = sp - A + s_at;
+            for (uint32_t i = lane; i < len; i += 64) o0[op + i] = s0[i];
+            op += len;
+            // re-prime the bit buffer for whatever follows the stored block
+            { const uint32_t pos = __builtin_amdgcn_readfirstlane(bi.pos); fill(pos & ~3u); bi.wlo = pos & ~3u; }
+            if (lane == 0) { const int skip = -bi.bc; bi.bc = 0; bi.bb = 0; bi.refill(win); if (skip) bi.drop(skip); }
+        } else {
+            if (!build_table(sm, sm.lens, sm.code, hlit, D_LIT_TB, sm.lit, D_LIT_MAX, 0, lane)) { err = 20; break; }
+            if (!build_table(sm, sm.lens + hlit, sm.code, hdist, D_DIST_TB, sm.dist, D_DIST_MAX, 1, lane)) { err = 21; break; }
+            // ---- symbols: lane 0 decodes a literal run + one match, the wave writes them ----
+            bool eob = false;
+            while (!eob) {
+                uint32_t n_lit = 0, mlen = 0, mdist = 0; int need = 0;
+                if (lane == 0) {
+                    while (n_lit < LITBUF) {
+                        if (bi.bc <= 48 && !bi.refill(win)) { need = 1; break; }   // window used up: the wave moves it
+                        DHuff e = sm.lit[bi.bits(D_LIT_TB)];
+                        if (e.op & 0x80) { bi.drop(D_LIT_TB); e = sm.lit[e.val + bi.bits(e.op & 15)]; }
+                        bi.drop(e.len);
+                        if (e.op == 0) { sm.litbuf[n_lit++] = (uint8_t)e.val; continue; }
+                        if (e.op == 0x20) { eob = true; break; }
+                        if ((e.op & 0x40) || bi.bc < 0) { err = 30; break; }
+                        mlen = e.val + bi.bits(e.op & 15); bi.drop(e.op & 15);
+                        DHuff dd = sm.dist[bi.bits(D_DIST_TB)];
+                        if (dd.op & 0x80) { bi.drop(D_DIST_TB); dd = sm.dist[dd.val + bi.bits(dd.op & 15)]; }
+                        bi.drop(dd.len);
+                        if (!(dd.op & 0x10) || (dd.op & 0x40)) { err = 31; break; }
+                        mdist = dd.val + bi.bits(dd.op & 15); bi.drop(dd.op & 15);
+                        if (bi.bc < 0) err = 32;
+                        break;
+                    }
+                    if (!err && (op + n_lit + mlen > out_len || mdist > op + n_lit)) err = 33;
+                }
+                err = __builtin_amdgcn_readfirstlane(err);
+                if (err) break;
+                n_lit = __builtin_amdgcn_readfirstlane(n_lit); mlen = __builtin_amdgcn_readfirstlane(mlen); mdist = __builtin_amdgcn_readfirstlane(mdist);
+                eob = __builtin_amdgcn_readfirstlane((int)eob) != 0; need = __builtin_amdgcn_readfirstlane(need);
+                __builtin_amdgcn_wave_barrier();
+                if ((uint32_t)lane < n_lit) o0[op + lane] = sm.litbuf[lane];
+                op += n_lit;
+                if (mlen) {
+                    __threadfence_block();                                 // the literals (and earlier copies) are visible to the loads below
+                    const uint8_t* src = o0 + op - mdist;
+                    if (mdist >= mlen) { for (uint32_t i = lane; i < mlen; i += 64) o0[op + i] = src[i]; }
+                    else { for (uint32_t i = lane; i < mlen; i += 64) o0[op + i] = src[i % mdist]; }   // overlapping: the pattern repeats
+                    op += mlen;
+                    __threadfence_block();
+                }
+                if (need) { const uint32_t pos = __builtin_amdgcn_readfirstlane(bi.pos); fill(pos & ~3u); bi.wlo = pos & ~3u; }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (err) break;
+        }
+        if (bfinal) break;
+    }
+    if (lane == 0) {
+        // consumed input must lie inside the stream (the window is zero beyond it: a truncated stream must not pass)
+        const long long used_bits = (long long)(bi.pos - A) * 8 - bi.bc;
+        if (!err && used_bits > (long long)blk.in_len * 8) err = 41;
+        status[b] = err ? err : (op == out_len ? 0 : 40);
+    }
+}
+
+int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status) {
+    if (n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_in, d_blocks, n_blocks, d_out, d_status);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- one chunk in flight (see inflate_dev.h) ------------------------------------------------------------------------------
+GpuInflateSlot* gpu_inflate_slot_create(int device, int free_cus, bool verbose) {
+    if (device < 0 || hipSetDevice(device) != hipSuccess) return nullptr;
+    GpuInflateSlot* s = new GpuInflateSlot(); s->device = device;
+    // LOWEST stream priority: an inflate launch runs for tens of milliseconds, and on a hardware queue it shares with the engine's
+    // streams the join kernels of the chunks being pushed queued up behind it (first version: the coordinator's push time went from
+    // 0.25 to 2.6 s per 100 M records)
+    // ... and a CU mask that leaves 32 CUs to the engine: the inflate waves live for tens of milliseconds and hold ~14 KB of LDS
+    // each; once a few chunks are in flight they fill every CU's LDS, and a join block (26 KB) found no room until some retired
+    // (low stream priority does not evict running waves: push time 1.6 s per 100 M records).  Fallback: a low-priority stream.
+    hipDeviceProp_t prop;
+    bool masked = false;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 64) {
+        const int n_cu = prop.multiProcessorCount, keep_free = std::max(8, std::min(free_cus, n_cu / 2));
+        uint32_t mask[16] = {0};
+        for (int cu = 0; cu < n_cu - keep_free && cu < 512; cu++) mask[cu >> 5] |= 1u << (cu & 31);
+        masked = hipExtStreamCreateWithCUMask(&s->stream, (uint32_t)((n_cu + 31) / 32), mask) == hipSuccess;
+        if (!masked) { (void)hipGetLastError(); s->stream = nullptr; }
+        if (verbose) fprintf(stderr, "[xck] GPU inflate stream: %d CUs, %d kept free of inflate waves: CU mask %s\n", n_cu, keep_free, masked ? "applied" : "REFUSED (low-priority stream instead)");
+    }
+    if (!masked) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, least) != hipSuccess) { gpu_inflate_slot_destroy(s); return nullptr; }
+    }
+    if (hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess) { gpu_inflate_slot_destroy(s); return nullptr; }
+    return s;
+}
+static void slot_free_buffers(GpuInflateSlot* s) {
+    if (s->h_in) hipHostFree(s->h_in); if (s->h_out) hipHostFree(s->h_out); if (s->d_out) hipFree(s->d_out);
+    if (s->h_bl) hipHostFree(s->h_bl); if (s->h_st) hipHostFree(s->h_st);
+    s->h_in = s->a_in = s->h_out = s->a_out = s->d_out = nullptr; s->h_bl = s->a_bl = nullptr; s->h_st = s->a_st = nullptr; s->cap_in = s->cap_out = s->cap_bl = 0;
+}
+void gpu_inflate_slot_destroy(GpuInflateSlot* s) {
+    if (!s) return;
+    if (hipSetDevice(s->device) == hipSuccess) {
+        if (s->stream) hipStreamSynchronize(s->stream);
+        slot_free_buffers(s);
+        if (s->done) hipEventDestroy(s->done);
+        if (s->stream) hipStreamDestroy(s->stream);
+    }
+    delete s;
+}
+bool gpu_inflate_slot_reserve(GpuInflateSlot* s, size_t in_bytes, size_t out_bytes, size_t n_blocks) {
+    if (in_bytes <= s->cap_in && out_bytes <= s->cap_out && n_blocks <= s->cap_bl) return true;
+    if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return false;
+    auto grow = [](size_t need, size_t have) { return need > have ? need + need / 4 + 4096 : have; };
+    const size_t ci = grow(in_bytes, s->cap_in), co = grow(out_bytes, s->cap_out), cb = grow(n_blocks, s->cap_bl);
+    slot_free_buffers(s);
+    auto host = [](void** h, void** a, size_t bytes) { return hipHostMalloc(h, bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(a, *h, 0) == hipSuccess; };
+    bool ok = host((void**)&s->h_in, (void**)&s->a_in, ci + 16) && host((void**)&s->h_out, (void**)&s->a_out, co + 64) && hipMalloc((void**)&s->d_out, co + 64) == hipSuccess &&
+              host((void**)&s->h_bl, (void**)&s->a_bl, cb * sizeof(DevBlock)) && host((void**)&s->h_st, (void**)&s->a_st, cb * sizeof(int32_t));
+    if (!ok) { slot_free_buffers(s); (void)hipGetLastError(); return false; }
+    s->cap_in = ci; s->cap_out = co; s->cap_bl = cb;
+    return true;
+}
+// inflated bytes: HBM -> mapped pinned host memory by CU stores (16 bytes per lane, coalesced)
+__global__ __launch_bounds__(256) void k_inflate_copy_out(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// No DMA engine on this path: the first version copied in and out with hipMemcpyAsync, and the engine's own copy of every decoded
+// chunk (one hipMemcpyAsync per chunk, csrc/engine.hip engine_push_block) queued up behind the 48 MB copy-outs - the coordinator's
+// push time rose from 0.25 to 1.6 s per 100 M records.  The kernel is bound by its serial Huffman chain, not by bytes: it takes
+// the compressed stream from host memory in 1 KB coalesced windows and the statuses go straight back.
+int gpu_inflate_slot_launch(GpuInflateSlot* s, size_t in_bytes, size_t out_bytes, size_t n_blocks) {
+    (void)in_bytes;
+    if (hipSetDevice(s->device) != hipSuccess) return -1;
+    for (size_t i = 0; i < n_blocks; i++) s->h_st[i] = -1;                  // (a block the kernel never reaches is left to the host)
+    if (dev_inflate_launch(s->stream, s->a_in, s->a_bl, (int)n_blocks, s->d_out, s->a_st) != 0) { (void)hipGetLastError(); return -1; }
+    const size_t n16 = (out_bytes + 15) / 16;
+    hipLaunchKernelGGL(k_inflate_copy_out, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 448)), dim3(256), 0, s->stream, (const uint4*)s->d_out, (uint4*)s->a_out, n16);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(s->done, s->stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return 0;
+}
+bool gpu_inflate_slot_done(GpuInflateSlot* s) { return hipEventQuery(s->done) != hipErrorNotReady; }
+int gpu_inflate_slot_wait(GpuInflateSlot* s) { return hipEventSynchronize(s->done) == hipSuccess ? 0 : -1; }
+
+}  // namespace xck

@@ -5,6 +5,7 @@
 #include <vector>
 #include <unordered_map>
 #include <mutex>
+#include <atomic>
 #include "../../include/xck.h"
 
 #define XCK_VERSION_STR "0.1.0 (gfx950)"
@@ -105,6 +106,11 @@ struct Knobs {
     long long hit_cap0 = 1 << 20;        // XCK_HIT_CAP0
     int  push_stage = -1;                // XCK_PUSH_STAGE (-1 = by size)
     long long push_stage_bytes = 2 << 20;   // XCK_PUSH_STAGE_BYTES
+    int  gpu_inflate_pct = -1;           // XCK_GPU_INFLATE: share (percent) of the BGZF chunks inflated on the handle's GPU; -1 = auto (keep gpu_inflate_depth chunks on the device)
+    int  gpu_inflate_depth = 6;          // XCK_GPU_INFLATE_DEPTH
+    int  gpu_inflate_ring = 12;          // XCK_GPU_INFLATE_RING: chunks in flight (host + device) while the GPU share is on
+    int  gpu_inflate_min_mb = 512;       // XCK_GPU_INFLATE_MIN_MB: auto mode only for files (index ranges) of at least this many compressed MB
+    int  gpu_inflate_free_cus = 32;      // XCK_GPU_INFLATE_FREE_CUS: CUs the inflate streams never use (they stay free for the join kernels)
     static Knobs from_env();             // api.cpp
 };
 
@@ -129,6 +135,7 @@ struct xck_engine {
     void* stager = nullptr;              // xck::Stager (engine.hip): device staging slots of engine_push_block
     struct PushRing { void* blk[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}; void* fence[3] = {nullptr, nullptr, nullptr}; int next = 0; } push_ring;   // pinned blocks of xck_push_batch's one-copy form (api.cpp)
     xck::Knobs knobs;                    // the environment, read once at xck_create
+    std::atomic<int64_t> gpu_inflate_chunks{0};   // chunks inflated on the device by the readers that fed this handle (xck_stats)
     int mode = 0;
     int umi_bits = 64;
     int32_t n_cells = 0, n_contigs = 0;  // bounds that caller-supplied batches are checked against (xck_push_batch)
@@ -147,6 +154,7 @@ int  engine_result_device(xck_engine* e, xck_result* out);
 int  engine_reset(xck_engine* e);
 int  engine_stats(const xck_engine* e, xck_stats* out);
 int  engine_umi_bits(const xck_engine* e);
+int  engine_device(const xck_engine* e);      // HIP device of the handle (-1: decode-only handle)
 int  engine_numa_node(const xck_engine* e);   // NUMA node of the handle's GPU (sysfs, by PCI bus id); -1 = unknown
 // One decoded chunk (all SoA columns in one pinned host block of `bytes` bytes at host_base; the batches point into it): ONE
 // asynchronous H2D copy into a device staging slot shared by the handle's pipelines, then the join kernel(s) on the batches.
