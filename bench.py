@@ -503,7 +503,10 @@ def main():
                inflated_bytes_per_record=round(bgzf_inflated_per_compressed(bam) * bam_bytes / max(n_total, 1), 1),
                mtx_output_mb=round(mtx_bytes / 1e6, 1), engine_setup_s=round(setup_s, 2),
                engine_ms=dict(h2d=round(stats["ms_h2d"], 1), join=round(stats["ms_join"], 1), fold=round(stats["ms_sort"], 1), d2h=round(stats["ms_d2h"], 1)),
-               hits=dict(accepted=int(stats["n_hits"]), after_lds_dedup=int(stats["n_hits_unique"])))
+               hits=dict(accepted=int(stats["n_hits"]), after_lds_dedup=int(stats["n_hits_unique"])),
+               # the device's share of the BGZF inflate (csrc/inflate_dev.hip; XCK_GPU_INFLATE, default auto): chunks of ~740 blocks; walk and parse are the host's
+               gpu_inflate=dict(mode=os.environ.get("XCK_GPU_INFLATE", "auto"), chunks_on_device=int(stats.get("gpu_inflate_chunks", 0)),
+                                chunks_total_estimate=int(round(bgzf_inflated_per_compressed(bam) * bam_bytes / (48 << 20)))))
     log("e2e: %.2f M reads/s (%s)" % (value / 1e6, e2e["phase_seconds"]))
 
     # ---- CPU baseline + parity of this run's matrices: whole contigs of the same BAM through the oracle ----
@@ -513,6 +516,19 @@ def main():
 
     # ---- the same pipeline on files that look like a user's: zlib-6 blocks; Cell Ranger's record shape on top ----
     subs = {}
+    eng_host = None
+    if args.sub_reads > 0 and world == 1 and int(stats.get("gpu_inflate_chunks", 0)) > 0:
+        # a second handle whose decoder never hands chunks to the GPU (the knob is read at xck_create): the side files are timed with it
+        # too, so that every line shows what the device share of the inflate buys on this box
+        prev = os.environ.get("XCK_GPU_INFLATE")
+        os.environ["XCK_GPU_INFLATE"] = "0"
+        try:
+            eng_host = Engine(capi.XCK_MODE_BOTH, names, regions, len(bcs), n_threads=threads, **eng_kw)
+        finally:
+            if prev is None:
+                os.environ.pop("XCK_GPU_INFLATE", None)
+            else:
+                os.environ["XCK_GPU_INFLATE"] = prev
     if args.sub_reads > 0 and world == 1:
         for key, level, shape, what in (("end_to_end_zlib6", 6, "", "the headline's record shape (12-character names, tags NH CB UB), BGZF blocks by zlib level 6"),
                                         ("cellranger_shape", 6, "cellranger", "Cell Ranger's record shape: 39-character read names, 16 aux tags (NH HI AS nM RE xf li RG TX GX GN CR CY CB UR UY UB), "
@@ -526,9 +542,14 @@ def main():
                 runs2.append(tm)
             runs2.sort(key=lambda t_: t_["seconds"])
             tm = runs2[len(runs2) // 2]
+            host_only = None
+            if eng_host is not None:
+                hr = sorted(whole_file_pass(eng_host, [bam2], os.path.join(args.work, "out_" + key), regions, bcs, threads)[0]["seconds"] for _ in range(2))
+                host_only = round(n2 / hr[0], 1)
             b2 = os.path.getsize(bam2)
             subs[key] = dict(value=round(n2 / tm["seconds"], 1), unit="reads/s", records=n2, seconds=round(tm["seconds"], 3),
-                             passes=len(runs2), value_stat="median of the passes", values_all_passes=[round(n2 / t_["seconds"], 1) for t_ in runs2],
+                             passes=len(runs2), value_stat="median of the passes", host_inflate_only_value=host_only,
+                             gpu_inflate_chunks_last_pass=int(eng.stats().get("gpu_inflate_chunks", 0)), values_all_passes=[round(n2 / t_["seconds"], 1) for t_ in runs2],
                              value_min=round(n2 / runs2[-1]["seconds"], 1), value_max=round(n2 / runs2[0]["seconds"], 1),
                              phase_seconds=dict(ingest=round(tm["ingest"], 3), finish=round(tm["finish"], 3), write=round(tm["seconds"], 3)),
                              bam_gb=round(b2 / 1e9, 2), bam_bytes_per_record=round(b2 / max(n2, 1), 1),
@@ -537,6 +558,8 @@ def main():
                              note="whole-file passes (no slicing), same engine / tables / threads / writer as the headline; value = the median pass")
             log("%s: %.2f M reads/s (%.2f of the headline)" % (key, subs[key]["value"] / 1e6, subs[key]["ratio_to_headline"]))
     eng.close()
+    if eng_host is not None:
+        eng_host.close()
 
     # ---- BASELINE configs[4] at a reduced read count, so that every driver run carries a number for the multi-BAM well-based path ----
     well = None
@@ -718,7 +741,8 @@ def well_workload(args, dev_idx, device, threads, cores, log, world=1, rank=0, d
                                 warmup_pass_seconds=round(runs[0][0]["seconds"], 3), bam_gb=round(bam_bytes / 1e9, 2), bam_bytes_per_record=round(bam_bytes / max(n_all, 1), 1),
                                 bgzf_writer=writer_name(args.level), host_threads_per_rank=threads, host_cores=cores, key_bits=int(stats["key_bits"]), basefc_fold_path=int(stats["fold_path"]),
                                 engine_ms=dict(h2d=round(stats["ms_h2d"], 1), join=round(stats["ms_join"], 1), fold=round(stats["ms_sort"], 1), d2h=round(stats["ms_d2h"], 1)),
-                                hits=dict(accepted=int(stats["n_hits"]), after_lds_dedup=int(stats["n_hits_unique"]))),
+                                hits=dict(accepted=int(stats["n_hits"]), after_lds_dedup=int(stats["n_hits_unique"])),
+                                gpu_inflate=dict(mode=os.environ.get("XCK_GPU_INFLATE", "auto"), chunks_on_device=int(stats.get("gpu_inflate_chunks", 0)))),
                 multi_gpu=mgpu, gpu_rows_vs_oracle=parity_all, roofline=None, cpu_baseline=cpu)
 
 
