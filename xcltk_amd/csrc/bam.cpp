@@ -368,7 +368,8 @@ struct ContigMap {
 // threads, and the phases of the coordinating thread
 struct DecodeTimes {
     std::atomic<uint64_t> inflate{0}, walk{0}, parse{0};                 // ns, summed over pool threads
-    uint64_t wait_inflate = 0, sched = 0, stitch = 0, layout = 0, wait_parse = 0, push = 0;   // ns, coordinating thread
+    uint64_t wait_inflate = 0, sched = 0, stitch = 0, layout = 0, wait_parse = 0, wait_push = 0;   // ns, coordinating thread
+    uint64_t push = 0;                                                   // ns, push thread (engine_push_block)
     uint64_t chunks = 0, slow_chunks = 0; std::chrono::steady_clock::time_point t_open;
 };
 static inline uint64_t ns_since(std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
@@ -433,11 +434,45 @@ private:
 };
 
 constexpr int N_CHUNK = 3, N_SOA = 3;
+// The push of a decoded chunk (engine_push_block: one H2D copy + the join launches, after waiting for the previous chunk's launch to be
+// confirmed) runs on a thread of its own while the coordinator decodes the next chunk: with the GPU share of the inflate the coordinator
+// had become the limiter of the ingest (schedule + wait for parse + push = 4.5 ms per chunk, the pool a third idle).  One push in
+// flight: the coordinator hands chunk i over only after chunk i - 1 has been pushed, so a SoA block is never rewritten before its own
+// push was issued (its fence then guards the copy, as before).
+struct Pusher {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    bool stop = false, has_job = false, busy = false; int rc = 0;
+    xck_engine* e = nullptr; const void* base = nullptr; size_t bytes = 0; std::vector<xck_batch> bts; void** fence = nullptr;
+    uint64_t push_ns = 0;
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return stop || has_job; });
+            if (!has_job) return;
+            has_job = false; busy = true;
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            int r;
+            try { r = xck::engine_push_block(e, base, bytes, bts.data(), (int)bts.size(), fence); } catch (const std::bad_alloc&) { r = XCK_E_NOMEM; } catch (...) { r = XCK_E_IO; }
+            const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            lk.lock();
+            push_ns += ns; if (r && !rc) rc = r; busy = false;
+            cv.notify_all();
+        }
+    }
+    int wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !has_job && !busy; }); const int r = rc; return r; }   // 0, or the first error of a push
+    void submit(xck_engine* e_, const void* base_, size_t bytes_, std::vector<xck_batch>& b_, void** fence_) {
+        std::lock_guard<std::mutex> lk(mu); e = e_; base = base_; bytes = bytes_; bts.swap(b_); fence = fence_; has_job = true; cv.notify_all();
+    }
+    ~Pusher() { { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+};
 constexpr int N_CHUNK_GPU = 16;        // ring depth with the GPU share on: its chunks need several in flight on the device (one wave per block)
 // XCK_GPU_INFLATE=<percent>: that share of the chunks is inflated on the handle's GPU (0 = off).  State of one reader:
 struct GpuShare {
     bool tried = false, on = false, broken = false, verbose = false; int pct = 0, acc = 0, device = -1, free_cus = 32, depth = 4;
-    GpuInflateSlot* slot[N_CHUNK_GPU] = {nullptr}; bool inflight[N_CHUNK_GPU] = {false};
+    GpuInflateSlot* slot[N_CHUNK_GPU] = {nullptr}; bool inflight[N_CHUNK_GPU] = {false};   // slot[k]: the slot that holds ring chunk k (its inflated bytes live there until the chunk is consumed)
+    std::vector<GpuInflateSlot*> free_slots;                             // slots of consumed chunks, reused before a new one is made
+    int max_held = 10;                                                   // device chunks in the ring at a time (in flight + inflated, not yet consumed) = slots this reader ever holds
     uint64_t chunks = 0, blocks = 0, left_blocks = 0, wait_ns = 0, copy_ns = 0;
 };
 struct CallerBinding;
@@ -457,6 +492,7 @@ struct xck_bam {
     Pool* pool = nullptr; int n_threads = 1;
     Chunk ch[N_CHUNK_GPU]; int n_ring = N_CHUNK, head = 0, n_sched = 0;      // ring of n_ring chunks: ch[head] is decoded next, n_sched chunks are inflating / inflated
     GpuShare gi;
+    Pusher* pusher = nullptr;          // made at the first push of a GPU-backed ingest
     std::vector<uint8_t> carry;        // partial record from the previous chunk
     std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
     std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // serial walk output (slow path)
@@ -597,6 +633,7 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
 
 void xck_bam_close(xck_bam* b) {
     if (!b) return;
+    if (b->pusher) { b->pusher->wait_idle(); b->tm.push += b->pusher->push_ns; delete b->pusher; b->pusher = nullptr; }
     delete b->scanner; b->scanner = nullptr;
     for (auto& c : b->ch) c.tg.wait();
     // no H2D copy may still read a block that is parked or freed - and a parked block must not keep its event: the copy stream
@@ -608,14 +645,16 @@ void xck_bam_close(xck_bam* b) {
                 b->path.c_str(), (unsigned long long)b->gi.chunks, (unsigned long long)b->gi.blocks, (unsigned long long)b->gi.left_blocks, b->gi.copy_ns * 1e-6, b->gi.wait_ns * 1e-6,
                 b->gi.broken ? "; the device path was given up (runtime error / no memory)" : "");
     for (auto& gs : b->gi.slot) { park_gpu_slot(gs); gs = nullptr; }
+    for (auto& gs : b->gi.free_slots) park_gpu_slot(gs);
+    b->gi.free_slots.clear();
     if (b->numa_bound && b->pool) b->pool->set_affinity(b->old_affinity);   // a parked pool goes back to the full mask
     if (getenv("XCK_DEBUG_TIMING") && b->tm.chunks) {
         const DecodeTimes& t = b->tm; const double ms = 1e-6;
         fprintf(stderr, "[xck] ingest %s: %lld records, %llu chunks (%llu stitched serially), %.0f ms since open, %d threads | pool CPU ms: inflate %.0f walk %.0f parse %.0f | "
-                        "coordinator ms: wait_inflate %.0f schedule %.0f stitch %.0f layout %.0f wait_parse %.0f push %.0f\n",
+                        "coordinator ms: wait_inflate %.0f schedule %.0f stitch %.0f layout %.0f wait_parse %.0f wait_push %.0f | push thread ms: %.0f\n",
                 b->path.c_str(), (long long)b->n_records, (unsigned long long)t.chunks, (unsigned long long)t.slow_chunks, ns_since(t.t_open) * ms, b->n_threads,
                 t.inflate.load() * ms, t.walk.load() * ms, t.parse.load() * ms,
-                t.wait_inflate * ms, t.sched * ms, t.stitch * ms, t.layout * ms, t.wait_parse * ms, t.push * ms);
+                t.wait_inflate * ms, t.sched * ms, t.stitch * ms, t.layout * ms, t.wait_parse * ms, t.wait_push * ms, t.push * ms);
     }
     { BamScratch* sc = new BamScratch();
       for (int i = 0; i < N_SOA; i++) { sc->soa[i] = b->soa[i]; b->soa[i] = HostSoA(); }
@@ -756,14 +795,18 @@ static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const 
         if (gi.pct > 0) { gi.acc += gi.pct; want = gi.acc >= 100; if (want) gi.acc -= 100; }       // a fixed share
         else {                                                            // auto: keep gi.depth chunks on the device, the pool takes the rest -
             int busy = 0;                                                 // the shares then follow the two sides' speeds on this file and this box
-            for (int k = 0; k < b->n_ring; k++) if (gi.inflight[k] && gi.slot[k] && !gpu_inflate_slot_done(gi.slot[k])) busy++;
+            int held = 0;
+            for (int k = 0; k < b->n_ring; k++) { if (!gi.slot[k]) continue; held++; if (gi.inflight[k] && !gpu_inflate_slot_done(gi.slot[k])) busy++; }
             // ... but never the chunk the coordinator needs next or the one after (a device chunk takes tens of milliseconds, the pool
             // delivers in three: the first chunks of a file, and whatever follows a drained ring, stay on the host)
-            want = busy < gi.depth && b->n_sched >= 2;
+            want = busy < gi.depth && held < gi.max_held && b->n_sched >= 2;
         }
         if (want) {
             size_t tin = 0; for (size_t i = 0; i < nb; i++) tin += ((size_t)c.blocks[i].data_len + 3) & ~size_t(3);
-            if (!gi.slot[ci]) gi.slot[ci] = take_gpu_slot(gi.device, gi.free_cus, gi.verbose && ci == 0);
+            if (!gi.slot[ci]) {
+                if (!gi.free_slots.empty()) { gi.slot[ci] = gi.free_slots.back(); gi.free_slots.pop_back(); }
+                else gi.slot[ci] = take_gpu_slot(gi.device, gi.free_cus, gi.verbose && !gi.chunks);
+            }
             gs = gi.slot[ci];
             if (gs && gi.inflight[ci]) { gpu_inflate_slot_wait(gs); gi.inflight[ci] = false; }   // (a chunk that was dropped unconsumed)
             if (!gs || !gpu_inflate_slot_reserve(gs, tin + 8, usz + 8, nb)) { gi.broken = true; gs = nullptr; }   // no device memory: the host does it all from here on
@@ -974,6 +1017,13 @@ static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart
 }
 
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
+// the chunk at the head of the ring is consumed (or dropped): its slot, if it had one and nothing is in flight on it, serves the next device chunk
+static void advance_head(xck_bam* b) {
+    GpuShare& gi = b->gi;
+    if (gi.slot[b->head] && !gi.inflight[b->head]) { gi.free_slots.push_back(gi.slot[b->head]); gi.slot[b->head] = nullptr; }
+    b->head = (b->head + 1) % b->n_ring; b->n_sched--;
+}
+
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
     const int n_refs = (int)b->ref_names.size();
@@ -991,7 +1041,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             uint64_t span = b->fsize;
             if (b->use_ranges) { span = 0; for (auto& r : b->ranges) span += (r.second >> 16) - (r.first >> 16); }
             const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20;
-            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
+            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = b->gi.depth + 4; b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
         }
         bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
         std::vector<ScanRange> rg;
@@ -1038,7 +1088,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     }
     if (b->skip_range >= 0 && c.range_id == b->skip_range && !c.failed) {   // rest of a reference whose position window is behind us
         if (c.gpu && b->gi.inflight[b->head]) { gpu_inflate_slot_wait(b->gi.slot[b->head]); b->gi.inflight[b->head] = false; }
-        b->head = (b->head + 1) % b->n_ring; b->n_sched--;
+        advance_head(b);
         b->carry.clear();
         return decode_next_chunk(e, b, o);
     }
@@ -1195,7 +1245,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         }
     }
     b->n_records += limit;
-    b->head = (b->head + 1) % b->n_ring; b->n_sched--;
+    advance_head(b);
     if (hit_limit) { b->done = true; for (auto& cc : b->ch) cc.tg.wait(); }
     return 1;
 }
@@ -1225,7 +1275,7 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
     while (b->pending.empty()) {
         if (b->done) return 0;
         int rc = decode_next_chunk(e, b, o);
-        if (rc < 0) { e->err = b->path + ": " + b->err; return rc; }
+        if (rc < 0) { if (b->pusher) b->pusher->wait_idle(); e->err = b->path + ": " + b->err; return rc; }
         if (rc == 0) { b->done = true; return 0; }
     }
     PendingBatch pb = b->pending.front(); b->pending.pop_front();
@@ -1261,16 +1311,19 @@ static int ingest_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int6
                 if (e->dec.want_seq) { bt.seq_off = s.seq_off + pb.r0; bt.seq = s.seq; }
                 bts.push_back(bt);
             }
-            const int prc = xck::engine_push_block(e, s.base, s.used, bts.data(), (int)bts.size(), &s.fence);
-            b->tm.push += ns_since(t_p);
-            if (prc) return prc;
+            if (!b->pusher) { b->pusher = new Pusher(); Pusher* pp = b->pusher; pp->th = std::thread([pp] { pp->run(); }); }
+            if (const int prc = b->pusher->wait_idle()) return prc;     // (chunk i - 1 is pushed; its error, if any, ends the ingest)
+            b->pusher->submit(e, s.base, s.used, bts, &s.fence);
+            b->tm.wait_push += ns_since(t_p);
         }
         b->pending.clear();
         if (pause > 0 && !b->done && b->n_records - start >= pause) {   // chunk boundary: the reader stays positioned
+            if (b->pusher) if (const int prc = b->pusher->wait_idle()) return prc;   // (the caller may talk to the engine now: nothing is in flight on the pusher)
             if (n_records) *n_records = b->n_records;
             return 1;
         }
     }
+    if (b->pusher) if (const int prc = b->pusher->wait_idle()) return prc;
     if (n_records) *n_records = b->n_records;
     return XCK_OK;
 }

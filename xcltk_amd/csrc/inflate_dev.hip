@@ -140,6 +140,21 @@ struct BitIn {
 
 }  // namespace
 
+// inclusive prefix sum over the wave (DPP: shifts inside the rows of 16, then the row totals travel on)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// VARIANT 0: lane 0 decodes symbol after symbol (a literal run + one match per round); VARIANT 1: every lane decodes the symbol that
+// WOULD start at its own bit offset of a 64-bit stretch, a scalar walk over the lanes' code lengths then finds the symbols that DO
+// start there (see the symbol loop).
+template <int VARIANT>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, const DevBlock* __restrict__ blocks, int n_blocks,
                                                 uint8_t* out, int32_t* __restrict__ status) {
     __shared__ Smem sm;
@@ -254,6 +269,84 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
         } else {
             if (!build_table(sm, sm.lens, sm.code, hlit, D_LIT_TB, sm.lit, D_LIT_MAX, 0, lane)) { err = 20; break; }
             if (!build_table(sm, sm.lens + hlit, sm.code, hdist, D_DIST_TB, sm.dist, D_DIST_MAX, 1, lane)) { err = 21; break; }
+            if constexpr (VARIANT == 1) {
+            // ---- symbols, 64 bit offsets at a time.  A symbol's boundaries depend on all symbols before it, but WHAT would be decoded at a
+            // given bit offset does not: lane i decodes the literal / length (+ distance) code that starts at bit `bitpos + i` - two
+            // table look-ups per lane, all lanes at once -, then a scalar walk (readlane of the code lengths, no vector work) hops from
+            // symbol start to symbol start across the 64 offsets.  The lanes that turned out to be starts store their literals in one
+            // go (positions by a prefix sum of the output lengths); the matches among them are copied by the whole wave, in order.
+            // ~7 literals per round on a literal-heavy stream instead of one per ~45 vector instructions of lane 0.
+            uint32_t bitpos = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bi.pos * 8u - (uint32_t)bi.bc));
+            uint32_t wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi.wlo);
+            uint32_t dirty_lo = 0;                                     // lowest output offset stored since the last fence (0 = assume everything)
+            bool eob = false;
+            while (!eob) {
+                const uint32_t byte0 = bitpos >> 3;
+                if (byte0 < wlo || byte0 + 32 > wlo + IN_WIN) { wlo = byte0 & ~3u; fill(wlo); }   // (bits lane 0 had buffered may lie before a window the header code moved)
+                const uint32_t wbase = wlo >> 2;
+                const uint32_t bp = bitpos + (uint32_t)lane;
+                uint32_t v;
+                { const uint32_t wi = (bp >> 5) - wbase; v = __builtin_amdgcn_alignbit(win[wi + 1], win[wi], bp & 31u); }   // 32 stream bits from offset bp
+                DHuff e = sm.lit[v & ((1u << D_LIT_TB) - 1)];
+                uint32_t used = e.len;
+                if (e.op & 0x80) { e = sm.lit[e.val + ((v >> D_LIT_TB) & ((1u << (e.op & 15)) - 1))]; used = D_LIT_TB + e.len; }
+                // kind: 0 literal, 1 match, 2 end of block, 3 invalid
+                uint32_t kind = e.op == 0 ? 0u : (e.op == 0x20 ? 2u : ((e.op & 0x50) == 0x10 ? 1u : 3u));
+                uint32_t mlen = 0, mdist = 0;
+                if (kind == 1) {
+                    const uint32_t x = e.op & 15u;
+                    mlen = e.val + ((v >> used) & ((1u << x) - 1)); used += x;                 // <= 20 bits so far
+                    const uint32_t bp2 = bp + used;
+                    uint32_t v2;
+                    { const uint32_t wi = (bp2 >> 5) - wbase; v2 = __builtin_amdgcn_alignbit(win[wi + 1], win[wi], bp2 & 31u); }
+                    DHuff dd = sm.dist[v2 & ((1u << D_DIST_TB) - 1)];
+                    uint32_t u2 = dd.len;
+                    if (dd.op & 0x80) { dd = sm.dist[dd.val + ((v2 >> D_DIST_TB) & ((1u << (dd.op & 15)) - 1))]; u2 = D_DIST_TB + dd.len; }
+                    if ((dd.op & 0xd0) != 0x10) kind = 3;
+                    else { const uint32_t y = dd.op & 15u; mdist = dd.val + ((v2 >> u2) & ((1u << y) - 1)); used += u2 + y; }   // <= 48 bits
+                }
+                if (used == 0) kind = 3;
+                const uint32_t packed = used | (kind << 8);
+                // the walk: which lanes start a symbol (scalar)
+                uint64_t starts = 0; uint32_t cur = 0, stop = 0;
+                while (cur < 64) {
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
+                    starts |= 1ull << cur;
+                    cur += p & 0xffu;
+                    if ((p >> 8) >= 2) { stop = p >> 8; break; }
+                }
+                if (stop == 3) { err = 30; break; }
+                eob = stop == 2;
+                const bool is_start = (starts >> lane) & 1;
+                const uint32_t olen = is_start ? (kind == 0 ? 1u : (kind == 1 ? mlen : 0u)) : 0u;
+                const uint32_t incl = wave_scan_incl(olen);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (total > out_len - op) { err = 33; break; }
+                const uint32_t off = op + incl - olen;                 // where this lane's output goes
+                if (is_start && kind == 0) o0[off] = (uint8_t)e.val;
+                uint64_t mm = starts & __ballot(kind == 1);
+                if (starts & ~mm) dirty_lo = min(dirty_lo, op);
+                while (mm) {
+                    const int l = __builtin_ctzll(mm); mm &= mm - 1;
+                    const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, l), md = (uint32_t)__builtin_amdgcn_readlane((int)mdist, l);
+                    const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
+                    if (md > dst) { err = 33; break; }
+                    const uint32_t src_hi = dst - md + min(ml, md);
+                    if (src_hi > dirty_lo) { __threadfence_block(); dirty_lo = 0xffffffffu; }   // the bytes it reads were stored since the last fence
+                    const uint8_t* src = o0 + dst - md;
+                    if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) o0[dst + i] = src[i]; }
+                    else { for (uint32_t i = lane; i < ml; i += 64) o0[dst + i] = src[i % md]; }   // overlapping: the pattern repeats
+                    dirty_lo = min(dirty_lo, dst);
+                }
+                if (err) break;
+                op += total; bitpos += cur;
+            }
+            if (err) break;
+            // hand the bit position back to lane 0's serial reader (block headers, stored blocks)
+            { const uint32_t pos = (bitpos >> 4) << 1;
+              if (pos < wlo || pos + 16 > wlo + IN_WIN) { wlo = pos & ~3u; fill(wlo); }
+              bi.wlo = wlo; bi.pos = pos; bi.bb = 0; bi.bc = 0; bi.refill(win); bi.drop((int)(bitpos & 15u)); }
+            } else {
             // ---- symbols: lane 0 decodes a literal run + one match, the wave writes them ----
             bool eob = false;
             while (!eob) {
@@ -297,6 +390,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
                 __builtin_amdgcn_wave_barrier();
             }
             if (err) break;
+            }
         }
         if (bfinal) break;
     }
@@ -308,9 +402,13 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
     }
 }
 
+static int g_inflate_variant = 1;
+void dev_inflate_set_variant(int v) { g_inflate_variant = v; }
+
 int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status) {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_in, d_blocks, n_blocks, d_out, d_status);
+    if (g_inflate_variant == 0) hipLaunchKernelGGL(k_inflate<0>, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_in, d_blocks, n_blocks, d_out, d_status);
+    else hipLaunchKernelGGL(k_inflate<1>, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_in, d_blocks, n_blocks, d_out, d_status);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
