@@ -35,6 +35,9 @@ int main(int argc, char** argv) {
             if (xck::dev_inflate_launch(s, d_in, d_bl + b0, nb, d_out, d_st + b0)) { fprintf(stderr, "launch failed\n"); return 1; } }
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (getenv("INFLATE_VARIANT") && atoi(getenv("INFLATE_VARIANT")) >= 10) { unsigned long long pr[8]; xck::dev_inflate_read_prof(pr); double t = 0; for (int k = 0; k < 8; k++) t += (double)pr[k];
+            static const char* nm[8] = {"header", "tables", "window", "decode", "walk", "scan+literals", "matches", "flush+rest"};
+            printf("  wave cycles per block %.0f:", t / bl.size()); for (int k = 0; k < 8; k++) printf(" %s %.1f%%", nm[k], 100.0 * pr[k] / t); printf("\n"); }
         printf("rep %d: %.2f ms  = %.1f GB/s inflated, %.1f GB/s compressed\n", rep, ms, tot / ms / 1e6, o / ms / 1e6);
     }
     std::vector<uint8_t> got(tot); std::vector<int32_t> st(bl.size());

@@ -9,8 +9,8 @@ python3 tools/ingest_scaling.py $W/zlib6.bam $W/barcodes.tsv --gen $n --level 6 
 XCK_SYNTH_SHAPE=cellranger python3 tools/ingest_scaling.py $W/cr.bam $W/barcodes.tsv --gen $n --level 6 --threads 24 --snps 1000 > $out/host_cr.log 2>&1
 for f in fast zlib6 cr; do
   echo "== $f: $(ls -l $W/$f.bam | awk '{print $5}') bytes"
-  for v in 0 1; do for per in 0 740; do
+  for v in ${VARIANTS:-0 1 2}; do for per in 0 740; do
     if [ $per = 0 ]; then a=""; else a="$per"; fi
-    echo "-- variant $v, blocks per launch: ${per/#0/all}"; INFLATE_VARIANT=$v timeout -k 10 120 $W/gpu_inflate_bench $W/$f.bam 3000000000 $a 2>&1 | grep -E "blocks,|rep 2|verified|differs"
+    echo "-- variant $v, blocks per launch: ${per/#0/all}"; INFLATE_VARIANT=$v timeout -k 10 120 $W/gpu_inflate_bench $W/$f.bam 3000000000 $a 2>&1 | grep -E "blocks,|rep 2|verified|differs|wave cycles" | tail -4
   done; done
 done | tee $out/summary.txt

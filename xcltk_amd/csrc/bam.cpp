@@ -433,7 +433,7 @@ private:
     std::atomic<int> abandoned_{-1};
 };
 
-constexpr int N_CHUNK = 3, N_SOA = 3;
+constexpr int N_CHUNK = 4, N_SOA = 3;
 // The push of a decoded chunk (engine_push_block: one H2D copy + the join launches, after waiting for the previous chunk's launch to be
 // confirmed) runs on a thread of its own while the coordinator decodes the next chunk: with the GPU share of the inflate the coordinator
 // had become the limiter of the ingest (schedule + wait for parse + push = 4.5 ms per chunk, the pool a third idle).  One push in
@@ -493,6 +493,12 @@ struct xck_bam {
     Chunk ch[N_CHUNK_GPU]; int n_ring = N_CHUNK, head = 0, n_sched = 0;      // ring of n_ring chunks: ch[head] is decoded next, n_sched chunks are inflating / inflated
     GpuShare gi;
     Pusher* pusher = nullptr;          // made at the first push of a GPU-backed ingest
+    // The parse of chunk i (pool tasks: record fields -> SoA block) runs while the coordinator already schedules, waits for and lays out
+    // chunk i + 1: xck_ingest_bam only (defer_parse), fast path only.  Chunk i's ring slot (its inflated bytes, the parts' record lists)
+    // and its SoA block stay untouched until finish_parse() has seen the tasks end; then the chunk goes to the push thread.
+    struct ParseJob { bool active = false; TaskGroup tg; std::atomic<int> flags{0}; int soa = -1, ring_idx = -1; std::deque<PendingBatch> pending; } pj;
+    bool defer_parse = false;          // set by xck_ingest_bam for GPU-backed handles
+    int held = 0;                      // ring chunks behind `head` still in use by a parse in flight (0 / 1)
     std::vector<uint8_t> carry;        // partial record from the previous chunk
     std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
     std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // serial walk output (slow path)
@@ -633,6 +639,7 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
 
 void xck_bam_close(xck_bam* b) {
     if (!b) return;
+    if (b->pj.active) { b->pj.tg.wait(); b->pj.active = false; }
     if (b->pusher) { b->pusher->wait_idle(); b->tm.push += b->pusher->push_ns; delete b->pusher; b->pusher = nullptr; }
     delete b->scanner; b->scanner = nullptr;
     for (auto& c : b->ch) c.tg.wait();
@@ -997,11 +1004,11 @@ static void parse_range(xck_bam* b, xck_engine* e, int32_t sample, int64_t r0, i
 }
 
 // fast path: the records of one walk part, whose output slots start at the part's bases (prefix sums over the parts)
-static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart* wp, const ContigMap cm, std::atomic<int>* flags) {
+static void parse_part(xck_bam* b, xck_engine* e, HostSoA* sp, int32_t sample, const WalkPart* wp, const ContigMap cm, std::atomic<int>* flags) {
     const auto t_parse0 = std::chrono::steady_clock::now();
     struct PAcc { xck_bam* b; std::chrono::steady_clock::time_point t0; ~PAcc() { b->tm.parse += ns_since(t0); } } pacc{b, t_parse0};
     const DecodeCfg& dc = e->dec;
-    HostSoA& s = b->soa[b->soa_i];
+    HostSoA& s = *sp;
     std::vector<InternTable::Item> names;
     if (!dc.use_umi) names.reserve(wp->n_out);
     int64_t o = (int64_t)wp->out_base; uint32_t co = (uint32_t)wp->cig_base, so = (uint32_t)wp->seq_base;
@@ -1018,11 +1025,17 @@ static void parse_part(xck_bam* b, xck_engine* e, int32_t sample, const WalkPart
 
 // decode the next chunk into the SoA and fill b->pending. returns 1 (decoded), 0 (eof), <0 error
 // the chunk at the head of the ring is consumed (or dropped): its slot, if it had one and nothing is in flight on it, serves the next device chunk
-static void advance_head(xck_bam* b) {
+static void release_chunk(xck_bam* b, int ci) {
     GpuShare& gi = b->gi;
-    if (gi.slot[b->head] && !gi.inflight[b->head]) { gi.free_slots.push_back(gi.slot[b->head]); gi.slot[b->head] = nullptr; }
+    if (gi.slot[ci] && !gi.inflight[ci]) { gi.free_slots.push_back(gi.slot[ci]); gi.slot[ci] = nullptr; }
+}
+static void advance_head(xck_bam* b, bool hold = false) {           // hold: a parse in flight still reads the chunk (finish_parse releases it)
+    if (hold) { b->pj.ring_idx = b->head; b->held = 1; } else release_chunk(b, b->head);
     b->head = (b->head + 1) % b->n_ring; b->n_sched--;
 }
+
+// chunk i - 1: its parse tasks have ended -> errors, ring slot back, batches to the push thread (declared here, defined with the ingest)
+extern "C" { static int finish_parse(xck_engine* e, xck_bam* b); }
 
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
@@ -1041,7 +1054,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             uint64_t span = b->fsize;
             if (b->use_ranges) { span = 0; for (auto& r : b->ranges) span += (r.second >> 16) - (r.first >> 16); }
             const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20;
-            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = b->gi.depth + 4; b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
+            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = b->gi.depth + 4; b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; xck::dev_inflate_set_variant(e->knobs.gpu_inflate_lds_ring); b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
         }
         bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
         std::vector<ScanRange> rg;
@@ -1052,7 +1065,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     auto t_ph = std::chrono::steady_clock::now();
     auto phase = [&](uint64_t& acc) { const auto now = std::chrono::steady_clock::now(); acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_ph).count(); t_ph = now; };
     // keep the ring full: while this chunk is stitched and parsed the pool inflates the next two
-    while (b->n_sched < b->n_ring && !b->scan_end) {
+    while (b->n_sched + b->held < b->n_ring && !b->scan_end) {
         const int ci = (b->head + b->n_sched) % b->n_ring;
         Chunk& nc = b->ch[ci];
         schedule_chunk(b, nc, ci, crc, cm, e->dec.want_seq);
@@ -1146,15 +1159,34 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
           }
           if (cur_c >= 0 && (int64_t)n_out > seg0) b->pending.push_back({cur_c, seg0, (int64_t)n_out, ord_hi | (uint64_t)(b->n_records + seg_r)}); }
         phase(b->tm.layout);
-        { TaskGroup tg; const int32_t smp = o->sample;
+        limit = (int64_t)n_rec;
+        if (b->defer_parse) {
+            if (const int frc = finish_parse(e, b)) return frc;         // chunk i - 1 first: pushes stay in file order, one parse in flight
+            phase(b->tm.wait_parse);
+            const int32_t smp = o->sample; HostSoA* sp = &s; std::atomic<int>* fl = &b->pj.flags;
+            b->pj.flags.store(0); b->pj.soa = b->soa_i; b->pj.pending.swap(b->pending); b->pending.clear(); b->pj.active = true;
+            for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
+                b->pj.tg.add(*b->pool, [b, e, sp, smp, wpp, cm, fl] { parse_part(b, e, sp, smp, wpp, cm, fl); }, true); }
+            if (b->per_tid_ranges && cm.t_end) {                        // (same check as below: it only looks at the record lists)
+                const RecRef* last = nullptr;
+                for (size_t pi = c.parts.size(); pi-- > 0 && !last;) if (!c.parts[pi].recs.empty()) last = &c.parts[pi].recs.back();
+                if (last && last->tid >= 0 && last->tid < n_refs && cm.t_end[last->tid] > 0 && (int32_t)le32(last->p + 4) >= cm.t_end[last->tid]) {
+                    b->skip_range = c.range_id; b->scanner->abandon(c.range_id);
+                }
+            }
+            b->n_records += limit;
+            advance_head(b, true);
+            return 2;                                                   // parse in flight: b->pj
+        }
+        { TaskGroup tg; const int32_t smp = o->sample; HostSoA* sp = &s;
           for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
-              tg.add(*b->pool, [b, e, smp, wpp, cm, &flags] { parse_part(b, e, smp, wpp, cm, &flags); }, true); }   // (ahead of the later chunks' inflate tasks: the coordinator waits for these)
+              tg.add(*b->pool, [b, e, sp, smp, wpp, cm, &flags] { parse_part(b, e, sp, smp, wpp, cm, &flags); }, true); }   // (ahead of the later chunks' inflate tasks: the coordinator waits for these)
           tg.wait();
           if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
         phase(b->tm.wait_parse);
-        limit = (int64_t)n_rec;
     } else {
     // ---- slow path: stitch the per-task record lists serially; re-walk where the speculation failed ----
+    if (b->defer_parse) { if (const int frc = finish_parse(e, b)) return frc; }   // (b->recs / rec_out belong to one chunk at a time; pushes stay in file order)
     b->tm.slow_chunks++;
     b->recs.clear(); b->rec_contig.clear();
     b->stitch.clear();
@@ -1272,10 +1304,11 @@ int xck_bam_linear_index(xck_bam* b, int tid, int64_t* n, const uint64_t** voffs
 static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) {
     if (!e || !b || !o || !out) return XCK_E_ARG;
     CallerBinding on_node(b);
+    b->defer_parse = false;                                            // (this interface hands out finished batches: parse in place)
     while (b->pending.empty()) {
         if (b->done) return 0;
         int rc = decode_next_chunk(e, b, o);
-        if (rc < 0) { if (b->pusher) b->pusher->wait_idle(); e->err = b->path + ": " + b->err; return rc; }
+        if (rc < 0) { e->err = b->path + ": " + b->err; return rc; }
         if (rc == 0) { b->done = true; return 0; }
     }
     PendingBatch pb = b->pending.front(); b->pending.pop_front();
@@ -1288,42 +1321,68 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
     return 1;
 }
 
+// one decoded chunk -> the push thread: the whole chunk crosses PCIe as ONE block; its batches are slices of the block (fused handles:
+// both pipelines read the same copy).  Waits until the previous chunk's push has been issued.
+static int push_chunk(xck_engine* e, xck_bam* b, int soa_i, const std::deque<PendingBatch>& pend) {
+    if (e->n_impl <= 0 || pend.empty()) return XCK_OK;          // (a decode-only handle decodes and discards: host-ingest benchmarks)
+    const auto t_p = std::chrono::steady_clock::now();
+    HostSoA& s = b->soa[soa_i];
+    std::vector<xck_batch> bts; bts.reserve(pend.size());
+    for (const PendingBatch& pb : pend) {
+        xck_batch bt; memset(&bt, 0, sizeof bt);
+        bt.contig = pb.contig; bt.n_reads = (int32_t)(pb.r1 - pb.r0); bt.ordinal_base = pb.ordinal_base;
+        bt.pos = s.pos + pb.r0; bt.flag = s.flag + pb.r0; bt.mapq = s.mapq + pb.r0; bt.cell = s.cell + pb.r0; bt.umi = s.umi + pb.r0;
+        bt.cig_off = s.cig_off + pb.r0; bt.cigar = s.cigar;
+        if (e->dec.want_seq) { bt.seq_off = s.seq_off + pb.r0; bt.seq = s.seq; }
+        bts.push_back(bt);
+    }
+    if (!b->pusher) { b->pusher = new Pusher(); Pusher* pp = b->pusher; pp->th = std::thread([pp] { pp->run(); }); }
+    if (const int prc = b->pusher->wait_idle()) { b->err = e->err; return prc; }     // (chunk i - 1 is pushed; its error, if any, ends the ingest)
+    b->pusher->submit(e, s.base, s.used, bts, &s.fence);
+    b->tm.wait_push += ns_since(t_p);
+    return XCK_OK;
+}
+
+static int finish_parse(xck_engine* e, xck_bam* b) {
+    if (!b->pj.active) return XCK_OK;
+    b->pj.tg.wait(); b->pj.active = false;
+    int fl = b->pj.flags.load();
+    if (const int th = b->pj.tg.take_thrown()) fl |= th == 1 ? 4 : 8;
+    release_chunk(b, b->pj.ring_idx); b->held = 0;
+    if (fl & 4) { b->err = "out of host memory (record parse)"; return XCK_E_NOMEM; }
+    if (fl & 8) { b->err = "C++ exception in a parse task"; return XCK_E_IO; }
+    if (fl & 1) { b->err = "corrupt BAM record (fields exceed block_size)"; return XCK_E_IO; }
+    if (fl & 2) { b->err = "too many distinct non-ACGT keys for the key width"; return XCK_E_CAPACITY; }
+    return push_chunk(e, b, b->pj.soa, b->pj.pending);
+}
+
+// nothing of this reader is in flight any more: parse tasks ended (their chunk pushed unless `rc` already reports an error), push thread idle
+static int drain_ingest(xck_engine* e, xck_bam* b, int rc) {
+    if (b->pj.active) { if (rc < 0) { b->pj.tg.wait(); b->pj.active = false; (void)b->pj.tg.take_thrown(); release_chunk(b, b->pj.ring_idx); b->held = 0; } else rc = finish_parse(e, b); }
+    if (b->pusher) { const int prc = b->pusher->wait_idle(); if (rc >= 0 && prc) { b->err = e->err; rc = prc; } }
+    return rc;
+}
+
 static int ingest_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) {
     if (!e || !b || !o) return XCK_E_ARG;
     CallerBinding on_node(b);
     const int64_t pause = o->struct_size >= offsetof(xck_ingest_opts, pause_records) + sizeof(int64_t) ? o->pause_records : 0;
     const int64_t start = b->n_records;
-    std::vector<xck_batch> bts;
+    b->defer_parse = e->n_impl > 0;
+    auto fail = [&](int rc) { rc = drain_ingest(e, b, rc); e->err = b->path + ": " + b->err; return rc; };
     while (!b->done) {
         int rc = decode_next_chunk(e, b, o);
-        if (rc < 0) { e->err = b->path + ": " + b->err; return rc; }
+        if (rc < 0) return fail(rc);
         if (rc == 0) { b->done = true; break; }
-        if (e->n_impl > 0 && !b->pending.empty()) {            // (a decode-only handle decodes and discards: host-ingest benchmarks)
-            // the whole chunk crosses PCIe as ONE block; its batches are slices of the block (fused handles: both pipelines read the same copy)
-            const auto t_p = std::chrono::steady_clock::now();
-            HostSoA& s = b->soa[b->soa_i];
-            bts.clear();
-            for (const PendingBatch& pb : b->pending) {
-                xck_batch bt; memset(&bt, 0, sizeof bt);
-                bt.contig = pb.contig; bt.n_reads = (int32_t)(pb.r1 - pb.r0); bt.ordinal_base = pb.ordinal_base;
-                bt.pos = s.pos + pb.r0; bt.flag = s.flag + pb.r0; bt.mapq = s.mapq + pb.r0; bt.cell = s.cell + pb.r0; bt.umi = s.umi + pb.r0;
-                bt.cig_off = s.cig_off + pb.r0; bt.cigar = s.cigar;
-                if (e->dec.want_seq) { bt.seq_off = s.seq_off + pb.r0; bt.seq = s.seq; }
-                bts.push_back(bt);
-            }
-            if (!b->pusher) { b->pusher = new Pusher(); Pusher* pp = b->pusher; pp->th = std::thread([pp] { pp->run(); }); }
-            if (const int prc = b->pusher->wait_idle()) return prc;     // (chunk i - 1 is pushed; its error, if any, ends the ingest)
-            b->pusher->submit(e, s.base, s.used, bts, &s.fence);
-            b->tm.wait_push += ns_since(t_p);
-        }
+        if (rc == 1) { if (const int prc = push_chunk(e, b, b->soa_i, b->pending)) return fail(prc); }   // (parsed in place: the slow path)
         b->pending.clear();
         if (pause > 0 && !b->done && b->n_records - start >= pause) {   // chunk boundary: the reader stays positioned
-            if (b->pusher) if (const int prc = b->pusher->wait_idle()) return prc;   // (the caller may talk to the engine now: nothing is in flight on the pusher)
+            if (const int drc = drain_ingest(e, b, 0)) return fail(drc);   // (the caller may talk to the engine now: nothing is in flight)
             if (n_records) *n_records = b->n_records;
             return 1;
         }
     }
-    if (b->pusher) if (const int prc = b->pusher->wait_idle()) return prc;
+    if (const int drc = drain_ingest(e, b, 0)) return fail(drc);
     if (n_records) *n_records = b->n_records;
     return XCK_OK;
 }

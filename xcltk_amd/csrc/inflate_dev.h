@@ -10,6 +10,7 @@ struct DevBlock { uint32_t in_off, in_len, out_off, out_len; };   // byte ranges
 // Enqueue the inflate of n_blocks blocks: d_in (compressed bytes of the chunk), d_out (inflated bytes), d_status[b] = 0 when block b
 // was inflated to exactly out_len bytes, non-zero when the block is left to the host decoder.  Returns 0 / -1 (launch error).
 void dev_inflate_set_variant(int v);      // 0 = the serial symbol loop (lane 0), 1 = the 64-offsets-at-a-time loop (default); test / bench harness only
+void dev_inflate_read_prof(unsigned long long out[8]);   // variants 10 / 11 (= 0 / 1 with phase clocks): cycles per phase, summed over the blocks
 int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status);
 
 // One chunk of BGZF blocks in flight on the GPU (the host decoder keeps a ring of these, csrc/bam.cpp): pinned host buffers for the

@@ -151,20 +151,30 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
     return x;
 }
 
-// VARIANT 0: lane 0 decodes symbol after symbol (a literal run + one match per round); VARIANT 1: every lane decodes the symbol that
-// WOULD start at its own bit offset of a 64-bit stretch, a scalar walk over the lanes' code lengths then finds the symbols that DO
-// start there (see the symbol loop).
-template <int VARIANT>
+// RING = 0: output bytes go straight to global memory and a match reads them back from there (behind a fence when they were stored
+// since the last one).  RING > 0: the last RING output bytes live in an LDS ring; a match whose source lies inside it - most do, the
+// record before this one is 230 - 450 bytes back - is an LDS-to-LDS copy without any global round trip; the ring is written out in
+// 1 KB segments of aligned 16-byte stores as soon as every byte of a segment is final, and only a match that reaches further back
+// than the ring loads from global memory (from segments that were stored - and, on first use, waited for - long before).
+__device__ unsigned long long d_prof[8];          // PROF builds only (tools/gpu_inflate_bench): cycles of wave-time per phase, summed over the blocks
+#define XCK_PROF_AT(k) do { if constexpr (PROF) { const long long t_ = clock64(); prof[k] += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0)
+
+template <int RING, bool PROF>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, const DevBlock* __restrict__ blocks, int n_blocks,
                                                 uint8_t* out, int32_t* __restrict__ status) {
     __shared__ Smem sm;
     __shared__ uint32_t win[IN_WIN / 4];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[RING > 0 ? RING : 16];
+    constexpr uint32_t RM = RING > 0 ? (uint32_t)RING - 1 : 0, SEG = 1024, CAP = 1024;    // CAP: output bytes per round (bounds what a round may evict from the ring)
+    static_assert(RING == 0 || (RING >= 4096 && (RING & (RING - 1)) == 0), "ring: a power of two >= 4096 (far matches must find their bytes flushed)");
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_blocks) return;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t_prev = PROF ? clock64() : 0;   // 0 header, 1 tables, 2 window, 3 decode, 4 walk, 5 scan + literals, 6 matches, 7 flush / rest
     const DevBlock blk = blocks[b];
-    uint8_t* const o0 = out + blk.out_off;
-    const uint32_t out_len = blk.out_len;
-    if (out_len == 0) { if (lane == 0) status[b] = 0; return; }
+    const uint32_t A_out = RING > 0 ? (uint32_t)((uintptr_t)(out + blk.out_off) & 15u) : 0u;
+    uint8_t* const o0v = out + blk.out_off - A_out;                    // byte p of the block's output sits at o0v[A_out + p]
+    const uint32_t out_end = A_out + blk.out_len;
+    if (blk.out_len == 0) { if (lane == 0) status[b] = 0; return; }
     const uint8_t* const sp = in + blk.in_off;
     const uint32_t A = (uint32_t)((uintptr_t)sp & 3u);
     const uint32_t* const abase = (const uint32_t*)(sp - A);           // 4-byte aligned view of the stream
@@ -177,7 +187,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
     BitIn bi; bi.pos = 0; bi.wlo = 0; bi.bb = 0; bi.bc = 0;            // (lane 0's state; the other lanes carry dead copies)
     fill(0);
     if (lane == 0) { bi.refill(win); bi.drop((int)(8 * A)); }          // skip the A bytes before the stream
-    uint32_t op = 0;                                                   // bytes produced so far (wave-uniform)
+    uint32_t op = A_out;                                               // output position (wave-uniform), in coordinates of the 16-byte aligned base o0v
+    uint32_t flushed = 0;                                              // RING > 0: ring bytes below this position are in global memory (a multiple of SEG)
     int err = 0;
     for (;;) {
         // ---- block header (lane 0), broadcast; the window is moved first so that a whole header (< 400 bytes) fits ----
@@ -237,6 +248,17 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
         btype = __builtin_amdgcn_readfirstlane(btype); bfinal = __builtin_amdgcn_readfirstlane(bfinal);
         hlit = __builtin_amdgcn_readfirstlane(hlit); hdist = __builtin_amdgcn_readfirstlane(hdist);
         __builtin_amdgcn_wave_barrier();
+        // RING > 0: every segment that ends at or below p is final -> global memory (the first one may start before the block's first byte)
+        auto flush_upto = [&](uint32_t p) {
+            if constexpr (RING > 0) {
+                while (flushed + SEG <= p) {
+                    if (flushed >= A_out) *(uint4*)(o0v + flushed + lane * 16) = *(const uint4*)&ring[(flushed & RM) + lane * 16];
+                    else for (uint32_t i = A_out + (uint32_t)lane; i < SEG; i += 64) o0v[i] = ring[i];
+                    flushed += SEG;
+                }
+            }
+        };
+        XCK_PROF_AT(0);
         if (btype == 0) {                                              // stored block: lane 0 finds the byte position, the wave copies
             uint32_t len = 0, s_at = 0;
             if (lane == 0) {
@@ -249,7 +271,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
                     len = (uint32_t)q[0] | ((uint32_t)q[1] << 8); const uint32_t nlen = (uint32_t)q[2] | ((uint32_t)q[3] << 8);
                     if ((len ^ nlen) != 0xffff) err = 11;
                     c += 4;
-                    if (!err && (c + len > c_end || out_len - op < len)) err = 12;
+                    if (!err && (c + len > c_end || out_end - op < len)) err = 12;
                     s_at = c;
                     // resume the bit stream after the stored bytes: aligned coordinate + partial dword
                     const uint32_t nxt = c + len;
@@ -261,7 +283,13 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
             if (err) break;
             len = __builtin_amdgcn_readfirstlane(len); s_at = __builtin_amdgcn_readfirstlane(s_at);
             const uint8_t* s0 = sp - A + s_at;
-            for (uint32_t i = lane; i < len; i += 64) o0[op + i] = s0[i];
+            if constexpr (RING > 0) {
+                for (uint32_t done = 0; done < len;) {
+                    const uint32_t n = min(SEG, len - done);
+                    for (uint32_t i = lane; i < n; i += 64) ring[(op + done + i) & RM] = s0[done + i];
+                    done += n; flush_upto(op + done);
+                }
+            } else { for (uint32_t i = lane; i < len; i += 64) o0v[op + i] = s0[i]; }
             op += len;
             // re-prime the bit buffer for whatever follows the stored block
             { const uint32_t pos = __builtin_amdgcn_readfirstlane(bi.pos); fill(pos & ~3u); bi.wlo = pos & ~3u; }
@@ -269,146 +297,140 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
         } else {
             if (!build_table(sm, sm.lens, sm.code, hlit, D_LIT_TB, sm.lit, D_LIT_MAX, 0, lane)) { err = 20; break; }
             if (!build_table(sm, sm.lens + hlit, sm.code, hdist, D_DIST_TB, sm.dist, D_DIST_MAX, 1, lane)) { err = 21; break; }
-            if constexpr (VARIANT == 1) {
+            XCK_PROF_AT(1);
             // ---- symbols, 64 bit offsets at a time.  A symbol's boundaries depend on all symbols before it, but WHAT would be decoded at a
             // given bit offset does not: lane i decodes the literal / length (+ distance) code that starts at bit `bitpos + i` - two
             // table look-ups per lane, all lanes at once -, then a scalar walk (readlane of the code lengths, no vector work) hops from
             // symbol start to symbol start across the 64 offsets.  The lanes that turned out to be starts store their literals in one
             // go (positions by a prefix sum of the output lengths); the matches among them are copied by the whole wave, in order.
-            // ~7 literals per round on a literal-heavy stream instead of one per ~45 vector instructions of lane 0.
+            // (The first form of this kernel - lane 0 decoding symbol after symbol, ~45 vector instructions per literal - is archived
+            // under profiles/experiments/gpu_inflate/; this loop is 2 - 2.9x faster on its own, r04_symbol_loop_ab.txt.)
             uint32_t bitpos = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bi.pos * 8u - (uint32_t)bi.bc));
             uint32_t wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi.wlo);
-            uint32_t dirty_lo = 0;                                     // lowest output offset stored since the last fence (0 = assume everything)
+            uint32_t dirty_lo = 0;                                     // RING == 0: lowest position stored since the last fence (0 = assume everything)
             bool eob = false;
             while (!eob) {
                 const uint32_t byte0 = bitpos >> 3;
                 if (byte0 < wlo || byte0 + 32 > wlo + IN_WIN) { wlo = byte0 & ~3u; fill(wlo); }   // (bits lane 0 had buffered may lie before a window the header code moved)
+                XCK_PROF_AT(2);
                 const uint32_t wbase = wlo >> 2;
                 const uint32_t bp = bitpos + (uint32_t)lane;
                 uint32_t v;
                 { const uint32_t wi = (bp >> 5) - wbase; v = __builtin_amdgcn_alignbit(win[wi + 1], win[wi], bp & 31u); }   // 32 stream bits from offset bp
-                DHuff e = sm.lit[v & ((1u << D_LIT_TB) - 1)];
-                uint32_t used = e.len;
-                if (e.op & 0x80) { e = sm.lit[e.val + ((v >> D_LIT_TB) & ((1u << (e.op & 15)) - 1))]; used = D_LIT_TB + e.len; }
+                // a table entry as one 32-bit LDS read: val | len << 16 | op << 24
+                uint32_t e = ((const uint32_t*)sm.lit)[v & ((1u << D_LIT_TB) - 1)];
+                uint32_t used = (e >> 16) & 0xffu;
+                if (e >> 31) { e = ((const uint32_t*)sm.lit)[(e & 0xffffu) + ((v >> D_LIT_TB) & ((1u << ((e >> 24) & 15u)) - 1))]; used = D_LIT_TB + ((e >> 16) & 0xffu); }
+                const uint32_t eop = e >> 24;
                 // kind: 0 literal, 1 match, 2 end of block, 3 invalid
-                uint32_t kind = e.op == 0 ? 0u : (e.op == 0x20 ? 2u : ((e.op & 0x50) == 0x10 ? 1u : 3u));
+                uint32_t kind = (eop & 0x50u) == 0x10u ? 1u : 3u;
+                kind = eop == 0x20u ? 2u : kind; kind = eop == 0u ? 0u : kind;
                 uint32_t mlen = 0, mdist = 0;
                 if (kind == 1) {
-                    const uint32_t x = e.op & 15u;
-                    mlen = e.val + ((v >> used) & ((1u << x) - 1)); used += x;                 // <= 20 bits so far
+                    const uint32_t x = eop & 15u;
+                    mlen = (e & 0xffffu) + ((v >> used) & ((1u << x) - 1)); used += x;         // <= 20 bits so far
                     const uint32_t bp2 = bp + used;
                     uint32_t v2;
                     { const uint32_t wi = (bp2 >> 5) - wbase; v2 = __builtin_amdgcn_alignbit(win[wi + 1], win[wi], bp2 & 31u); }
-                    DHuff dd = sm.dist[v2 & ((1u << D_DIST_TB) - 1)];
-                    uint32_t u2 = dd.len;
-                    if (dd.op & 0x80) { dd = sm.dist[dd.val + ((v2 >> D_DIST_TB) & ((1u << (dd.op & 15)) - 1))]; u2 = D_DIST_TB + dd.len; }
-                    if ((dd.op & 0xd0) != 0x10) kind = 3;
-                    else { const uint32_t y = dd.op & 15u; mdist = dd.val + ((v2 >> u2) & ((1u << y) - 1)); used += u2 + y; }   // <= 48 bits
+                    uint32_t dd = ((const uint32_t*)sm.dist)[v2 & ((1u << D_DIST_TB) - 1)];
+                    uint32_t u2 = (dd >> 16) & 0xffu;
+                    if (dd >> 31) { dd = ((const uint32_t*)sm.dist)[(dd & 0xffffu) + ((v2 >> D_DIST_TB) & ((1u << ((dd >> 24) & 15u)) - 1))]; u2 = D_DIST_TB + ((dd >> 16) & 0xffu); }
+                    if (((dd >> 24) & 0xd0u) != 0x10u) kind = 3;
+                    else { const uint32_t y = (dd >> 24) & 15u; mdist = (dd & 0xffffu) + ((v2 >> u2) & ((1u << y) - 1)); used += u2 + y; }   // <= 48 bits
                 }
                 if (used == 0) kind = 3;
-                const uint32_t packed = used | (kind << 8);
-                // the walk: which lanes start a symbol (scalar)
-                uint64_t starts = 0; uint32_t cur = 0, stop = 0;
+                uint32_t olen = kind == 0 ? 1u : (kind == 1 ? mlen : 0u);
+                const uint32_t packed = used | (kind << 6) | (olen << 8);
+                if constexpr (PROF) { asm volatile("" :: "v"(packed)); }
+                XCK_PROF_AT(3);
+                // the walk: which lanes start a symbol (scalar); a round ends after 64 offsets, at the end of the block, or before the
+                // symbol that would take its output past CAP bytes
+                uint64_t starts = 0; uint32_t cur = 0, stop = 0, total = 0;
                 while (cur < 64) {
                     const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
+                    if (total + (p >> 8) > CAP && starts) break;
                     starts |= 1ull << cur;
-                    cur += p & 0xffu;
-                    if ((p >> 8) >= 2) { stop = p >> 8; break; }
+                    total += p >> 8; cur += p & 63u;
+                    if (((p >> 6) & 3u) >= 2) { stop = (p >> 6) & 3u; break; }
                 }
+                XCK_PROF_AT(4);
                 if (stop == 3) { err = 30; break; }
                 eob = stop == 2;
+                if (total > out_end - op) { err = 33; break; }
                 const bool is_start = (starts >> lane) & 1;
-                const uint32_t olen = is_start ? (kind == 0 ? 1u : (kind == 1 ? mlen : 0u)) : 0u;
-                const uint32_t incl = wave_scan_incl(olen);
-                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (total > out_len - op) { err = 33; break; }
-                const uint32_t off = op + incl - olen;                 // where this lane's output goes
-                if (is_start && kind == 0) o0[off] = (uint8_t)e.val;
+                olen = is_start ? olen : 0u;
+                const uint32_t off = op + wave_scan_incl(olen) - olen;  // where this lane's output goes
+                if (is_start && kind == 0) { if constexpr (RING > 0) ring[off & RM] = (uint8_t)e; else o0v[off] = (uint8_t)e; }
                 uint64_t mm = starts & __ballot(kind == 1);
-                if (starts & ~mm) dirty_lo = min(dirty_lo, op);
+                if constexpr (RING == 0) { if (starts & ~mm) dirty_lo = min(dirty_lo, op); }
+                XCK_PROF_AT(5);
                 while (mm) {
                     const int l = __builtin_ctzll(mm); mm &= mm - 1;
                     const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, l), md = (uint32_t)__builtin_amdgcn_readlane((int)mdist, l);
                     const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
-                    if (md > dst) { err = 33; break; }
-                    const uint32_t src_hi = dst - md + min(ml, md);
-                    if (src_hi > dirty_lo) { __threadfence_block(); dirty_lo = 0xffffffffu; }   // the bytes it reads were stored since the last fence
-                    const uint8_t* src = o0 + dst - md;
-                    if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) o0[dst + i] = src[i]; }
-                    else { for (uint32_t i = lane; i < ml; i += 64) o0[dst + i] = src[i % md]; }   // overlapping: the pattern repeats
-                    dirty_lo = min(dirty_lo, dst);
+                    if (md > dst - A_out) { err = 33; break; }
+                    if constexpr (RING > 0) {
+                        flush_upto(dst);                                   // everything below this match is final
+                        if (dst - md + (uint32_t)RING >= op + total) {     // its source stays in the ring until the round is over
+                            if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) ring[(dst + i) & RM] = ring[(dst - md + i) & RM]; }
+                            else { for (uint32_t i = lane; i < ml; i += 64) ring[(dst + i) & RM] = ring[(dst - md + i % md) & RM]; }   // overlapping: the pattern repeats
+                        } else {                                           // further back than the ring: those segments were flushed long ago (RING >= 4096, CAP)
+                            if (dst - md + ml > flushed) { err = 34; break; }
+                            __threadfence_block();                         // (waits for nothing unless a segment was stored just now)
+                            for (uint32_t i = lane; i < ml; i += 64) ring[(dst + i) & RM] = o0v[dst - md + i];
+                        }
+                    } else {
+                        const uint32_t src_hi = dst - md + min(ml, md);
+                        if (src_hi > dirty_lo) { __threadfence_block(); dirty_lo = 0xffffffffu; }   // the bytes it reads were stored since the last fence
+                        const uint8_t* src = o0v + dst - md;
+                        if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) o0v[dst + i] = src[i]; }
+                        else { for (uint32_t i = lane; i < ml; i += 64) o0v[dst + i] = src[i % md]; }
+                        dirty_lo = min(dirty_lo, dst);
+                    }
                 }
                 if (err) break;
+                XCK_PROF_AT(6);
                 op += total; bitpos += cur;
+                flush_upto(op);
+                XCK_PROF_AT(7);
             }
             if (err) break;
             // hand the bit position back to lane 0's serial reader (block headers, stored blocks)
             { const uint32_t pos = (bitpos >> 4) << 1;
               if (pos < wlo || pos + 16 > wlo + IN_WIN) { wlo = pos & ~3u; fill(wlo); }
               bi.wlo = wlo; bi.pos = pos; bi.bb = 0; bi.bc = 0; bi.refill(win); bi.drop((int)(bitpos & 15u)); }
-            } else {
-            // ---- symbols: lane 0 decodes a literal run + one match, the wave writes them ----
-            bool eob = false;
-            while (!eob) {
-                uint32_t n_lit = 0, mlen = 0, mdist = 0; int need = 0;
-                if (lane == 0) {
-                    while (n_lit < LITBUF) {
-                        if (bi.bc <= 48 && !bi.refill(win)) { need = 1; break; }   // window used up: the wave moves it
-                        DHuff e = sm.lit[bi.bits(D_LIT_TB)];
-                        if (e.op & 0x80) { bi.drop(D_LIT_TB); e = sm.lit[e.val + bi.bits(e.op & 15)]; }
-                        bi.drop(e.len);
-                        if (e.op == 0) { sm.litbuf[n_lit++] = (uint8_t)e.val; continue; }
-                        if (e.op == 0x20) { eob = true; break; }
-                        if ((e.op & 0x40) || bi.bc < 0) { err = 30; break; }
-                        mlen = e.val + bi.bits(e.op & 15); bi.drop(e.op & 15);
-                        DHuff dd = sm.dist[bi.bits(D_DIST_TB)];
-                        if (dd.op & 0x80) { bi.drop(D_DIST_TB); dd = sm.dist[dd.val + bi.bits(dd.op & 15)]; }
-                        bi.drop(dd.len);
-                        if (!(dd.op & 0x10) || (dd.op & 0x40)) { err = 31; break; }
-                        mdist = dd.val + bi.bits(dd.op & 15); bi.drop(dd.op & 15);
-                        if (bi.bc < 0) err = 32;
-                        break;
-                    }
-                    if (!err && (op + n_lit + mlen > out_len || mdist > op + n_lit)) err = 33;
-                }
-                err = __builtin_amdgcn_readfirstlane(err);
-                if (err) break;
-                n_lit = __builtin_amdgcn_readfirstlane(n_lit); mlen = __builtin_amdgcn_readfirstlane(mlen); mdist = __builtin_amdgcn_readfirstlane(mdist);
-                eob = __builtin_amdgcn_readfirstlane((int)eob) != 0; need = __builtin_amdgcn_readfirstlane(need);
-                __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)lane < n_lit) o0[op + lane] = sm.litbuf[lane];
-                op += n_lit;
-                if (mlen) {
-                    __threadfence_block();                                 // the literals (and earlier copies) are visible to the loads below
-                    const uint8_t* src = o0 + op - mdist;
-                    if (mdist >= mlen) { for (uint32_t i = lane; i < mlen; i += 64) o0[op + i] = src[i]; }
-                    else { for (uint32_t i = lane; i < mlen; i += 64) o0[op + i] = src[i % mdist]; }   // overlapping: the pattern repeats
-                    op += mlen;
-                    __threadfence_block();
-                }
-                if (need) { const uint32_t pos = __builtin_amdgcn_readfirstlane(bi.pos); fill(pos & ~3u); bi.wlo = pos & ~3u; }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (err) break;
-            }
         }
         if (bfinal) break;
     }
+    if constexpr (RING > 0) { if (!err) for (uint32_t i = max(flushed, A_out) + (uint32_t)lane; i < op; i += 64) o0v[i] = ring[i & RM]; }   // the tail (and a block shorter than a segment)
+    if constexpr (PROF) { XCK_PROF_AT(7); if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&d_prof[k], prof[k]); }
     if (lane == 0) {
         // consumed input must lie inside the stream (the window is zero beyond it: a truncated stream must not pass)
         const long long used_bits = (long long)(bi.pos - A) * 8 - bi.bc;
         if (!err && used_bits > (long long)blk.in_len * 8) err = 41;
-        status[b] = err ? err : (op == out_len ? 0 : 40);
+        status[b] = err ? err : (op == out_end ? 0 : 40);
     }
 }
 
 static int g_inflate_variant = 1;
 void dev_inflate_set_variant(int v) { g_inflate_variant = v; }
 
+// PROF variants (10, 11): the per-phase cycle sums since the last call (and zeroes them)
+void dev_inflate_read_prof(unsigned long long out[8]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d_prof), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d_prof), z, sizeof z);
+}
+
 int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status) {
     if (n_blocks <= 0) return 0;
-    if (g_inflate_variant == 0) hipLaunchKernelGGL(k_inflate<0>, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_in, d_blocks, n_blocks, d_out, d_status);
-    else hipLaunchKernelGGL(k_inflate<1>, dim3((unsigned)n_blocks), dim3(64), 0, stream, d_in, d_blocks, n_blocks, d_out, d_status);
+    const dim3 g((unsigned)n_blocks), t(64);
+    switch (g_inflate_variant) {
+        case 0:  hipLaunchKernelGGL((k_inflate<0, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
+        case 2:  hipLaunchKernelGGL((k_inflate<8192, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
+        case 10: hipLaunchKernelGGL((k_inflate<0, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
+        case 11: hipLaunchKernelGGL((k_inflate<4096, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
+        default: hipLaunchKernelGGL((k_inflate<4096, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

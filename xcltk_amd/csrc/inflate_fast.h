@@ -10,6 +10,10 @@
 #include <cstdint>
 #include <cstring>
 
+#ifndef XCK_INFLATE_MATCH_HOOK
+#define XCK_INFLATE_MATCH_HOOK(offset, length)       // tools/inflate_stats.cpp counts the matches of a file through this; nothing in the product
+#endif
+
 namespace xck {
 
 #ifdef XCK_INFLATE_PROF
@@ -216,6 +220,7 @@ static inline int inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, si
                 if (!(d.op & 0x10) || (d.op & 0x40)) return -20;
                 uint32_t offset = d.val + XCK_BITS(d.op & 15); XCK_DROP(d.op & 15);
                 if (offset > (size_t)(op - out)) return -22;
+                XCK_INFLATE_MATCH_HOOK(offset, length);
                 const uint8_t* src = op - offset;
                 uint8_t* const stop = op + length;
                 if (offset >= 8) {
@@ -250,6 +255,7 @@ static inline int inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, si
                 uint32_t offset = d.val + XCK_BITS(d.op & 15); XCK_DROP(d.op & 15);
                 if (bc < 0) return -21;
                 if (offset > (size_t)(op - out) || length > (size_t)(out_end - op)) return -22;
+                XCK_INFLATE_MATCH_HOOK(offset, length);
                 const uint8_t* src = op - offset;
                 for (uint32_t k = 0; k < length; k++) op[k] = src[k];
                 op += length;
