@@ -15,7 +15,7 @@ from xcltk_amd.synth import soa
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("XCK_GPU_INFLATE", "XCK_GPU_INFLATE_DEPTH", "XCK_GPU_INFLATE_MIN_MB", "XCK_CHUNK_BYTES")
+KNOBS = ("XCK_GPU_INFLATE", "XCK_GPU_INFLATE_DEPTH", "XCK_GPU_INFLATE_MIN_MB", "XCK_CHUNK_BYTES", "XCK_GPU_INFLATE_LDS_RING")
 
 
 @pytest.fixture
@@ -68,13 +68,14 @@ def test_device_share_of_the_inflate_changes_nothing(level, knob_env, tmp_path):
     knob_env["XCK_GPU_INFLATE"] = "0"
     n0, host, st0 = _count(bam, regions, snps, names, bcs)
     assert n0 == 1500000 and st0["gpu_inflate_chunks"] == 0 and len(host["count"][0]) > 10000 and len(host["dp"][0]) > 100
-    for share, depth in (("50", "4"), ("auto", "3"), ("100", "4")):
-        knob_env["XCK_GPU_INFLATE"], knob_env["XCK_GPU_INFLATE_DEPTH"] = share, depth
+    # (the last two: the kernel's optional LDS ring of the last 4 / 8 KB of output, csrc/inflate_dev.hip)
+    for share, depth, ring in (("50", "4", "0"), ("auto", "3", "0"), ("100", "4", "0"), ("100", "4", "1"), ("50", "4", "2")):
+        knob_env["XCK_GPU_INFLATE"], knob_env["XCK_GPU_INFLATE_DEPTH"], knob_env["XCK_GPU_INFLATE_LDS_RING"] = share, depth, ring
         n1, dev, st1 = _count(bam, regions, snps, names, bcs, passes=2)
-        assert n1 == n0 and st1["gpu_inflate_chunks"] >= 5, (share, st1["gpu_inflate_chunks"])
+        assert n1 == n0 and st1["gpu_inflate_chunks"] >= 5, (share, ring, st1["gpu_inflate_chunks"])
         for k in host:
             for a, b in zip(host[k], dev[k]):
-                assert np.array_equal(a, b), (share, k)
+                assert np.array_equal(a, b), (share, ring, k)
     # CRC verification wanted: the inflate stays on the host (the device does not compute the checksum)
     knob_env["XCK_GPU_INFLATE"] = "50"
     n2, crc, st2 = _count(bam, regions, snps, names, bcs, flags=capi.XCK_F_VERIFY_CRC)

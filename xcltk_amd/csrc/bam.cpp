@@ -433,37 +433,28 @@ private:
     std::atomic<int> abandoned_{-1};
 };
 
-constexpr int N_CHUNK = 4, N_SOA = 3;
-// The push of a decoded chunk (engine_push_block: one H2D copy + the join launches, after waiting for the previous chunk's launch to be
-// confirmed) runs on a thread of its own while the coordinator decodes the next chunk: with the GPU share of the inflate the coordinator
-// had become the limiter of the ingest (schedule + wait for parse + push = 4.5 ms per chunk, the pool a third idle).  One push in
-// flight: the coordinator hands chunk i over only after chunk i - 1 has been pushed, so a SoA block is never rewritten before its own
-// push was issued (its fence then guards the copy, as before).
+constexpr int N_CHUNK = 5, N_SOA = 3;
+// What follows a chunk's layout - wait for its parse tasks, then push it (engine_push_block: one H2D copy + the join launches, after
+// waiting for the previous chunk's launch to be confirmed) - runs on a thread of its own, in file order, up to two chunks behind the
+// coordinator, which meanwhile schedules, waits for and lays out the next chunks.  With the GPU share of the inflate the coordinator
+// had become the limiter of the ingest (schedule + wait for parse + push = 4.5 ms per chunk, the pool a third idle).
+// A job owns: the chunk's SoA block, its ring chunk (inflated bytes + record lists, until `parsed`), its batch list.
+struct IngestJob {
+    TaskGroup tg; std::atomic<int> flags{0}; bool has_parse = false; int soa = -1, ring_idx = -1; std::deque<PendingBatch> pending;
+    std::atomic<int> parsed{0};        // set by the push thread once the parse tasks have ended: the coordinator may take the ring chunk back
+    bool released = true;              // (coordinator) the ring chunk was taken back
+};
 struct Pusher {
+    static constexpr int MAXQ = 2;     // jobs the coordinator may run ahead
     std::thread th; std::mutex mu; std::condition_variable cv;
-    bool stop = false, has_job = false, busy = false; int rc = 0;
-    xck_engine* e = nullptr; const void* base = nullptr; size_t bytes = 0; std::vector<xck_batch> bts; void** fence = nullptr;
-    uint64_t push_ns = 0;
-    void run() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [this] { return stop || has_job; });
-            if (!has_job) return;
-            has_job = false; busy = true;
-            lk.unlock();
-            const auto t0 = std::chrono::steady_clock::now();
-            int r;
-            try { r = xck::engine_push_block(e, base, bytes, bts.data(), (int)bts.size(), fence); } catch (const std::bad_alloc&) { r = XCK_E_NOMEM; } catch (...) { r = XCK_E_IO; }
-            const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            lk.lock();
-            push_ns += ns; if (r && !rc) rc = r; busy = false;
-            cv.notify_all();
-        }
-    }
-    int wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !has_job && !busy; }); const int r = rc; return r; }   // 0, or the first error of a push
-    void submit(xck_engine* e_, const void* base_, size_t bytes_, std::vector<xck_batch>& b_, void** fence_) {
-        std::lock_guard<std::mutex> lk(mu); e = e_; base = base_; bytes = bytes_; bts.swap(b_); fence = fence_; has_job = true; cv.notify_all();
-    }
+    bool stop = false; IngestJob* q[MAXQ] = {nullptr, nullptr}; int qh = 0, qn = 0;
+    int rc = 0; std::string err;       // first failure (parse flags or push); later jobs are waited for, not pushed
+    xck_engine* e = nullptr; xck_bam* b = nullptr;
+    uint64_t push_ns = 0, parse_wait_ns = 0;
+    void run();                        // (below: needs xck_bam)
+    // blocks while MAXQ jobs are outstanding; returns the first failure so far (the job is queued regardless: its parse must be waited for)
+    int submit(IngestJob* j) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return qn < MAXQ; }); q[(qh + qn) % MAXQ] = j; qn++; cv.notify_all(); return rc; }
+    int wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return qn == 0; }); return rc; }
     ~Pusher() { { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); } if (th.joinable()) th.join(); }
 };
 constexpr int N_CHUNK_GPU = 16;        // ring depth with the GPU share on: its chunks need several in flight on the device (one wave per block)
@@ -493,12 +484,11 @@ struct xck_bam {
     Chunk ch[N_CHUNK_GPU]; int n_ring = N_CHUNK, head = 0, n_sched = 0;      // ring of n_ring chunks: ch[head] is decoded next, n_sched chunks are inflating / inflated
     GpuShare gi;
     Pusher* pusher = nullptr;          // made at the first push of a GPU-backed ingest
-    // The parse of chunk i (pool tasks: record fields -> SoA block) runs while the coordinator already schedules, waits for and lays out
-    // chunk i + 1: xck_ingest_bam only (defer_parse), fast path only.  Chunk i's ring slot (its inflated bytes, the parts' record lists)
-    // and its SoA block stay untouched until finish_parse() has seen the tasks end; then the chunk goes to the push thread.
-    struct ParseJob { bool active = false; TaskGroup tg; std::atomic<int> flags{0}; int soa = -1, ring_idx = -1; std::deque<PendingBatch> pending; } pj;
+    // xck_ingest_bam on a GPU-backed handle (defer_parse): the parse of a chunk (pool tasks: record fields -> SoA block) and its push run
+    // behind the coordinator (Pusher).  jobs[k % 3] belongs to the k-th chunk handed over; at most Pusher::MAXQ are outstanding.
+    IngestJob jobs[3]; uint64_t job_n = 0;
     bool defer_parse = false;          // set by xck_ingest_bam for GPU-backed handles
-    int held = 0;                      // ring chunks behind `head` still in use by a parse in flight (0 / 1)
+    int held = 0;                      // ring chunks behind `head` whose parse may still read them (taken back by reap_jobs)
     std::vector<uint8_t> carry;        // partial record from the previous chunk
     std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
     std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // serial walk output (slow path)
@@ -639,8 +629,8 @@ static int bam_open_impl(const char* path, int n_threads, xck_bam** out, char* e
 
 void xck_bam_close(xck_bam* b) {
     if (!b) return;
-    if (b->pj.active) { b->pj.tg.wait(); b->pj.active = false; }
-    if (b->pusher) { b->pusher->wait_idle(); b->tm.push += b->pusher->push_ns; delete b->pusher; b->pusher = nullptr; }
+    if (b->pusher) { b->pusher->wait_idle(); b->tm.push += b->pusher->push_ns; b->tm.wait_parse += b->pusher->parse_wait_ns; delete b->pusher; b->pusher = nullptr; }
+    for (auto& j : b->jobs) j.tg.wait();
     delete b->scanner; b->scanner = nullptr;
     for (auto& c : b->ch) c.tg.wait();
     // no H2D copy may still read a block that is parked or freed - and a parked block must not keep its event: the copy stream
@@ -1029,13 +1019,63 @@ static void release_chunk(xck_bam* b, int ci) {
     GpuShare& gi = b->gi;
     if (gi.slot[ci] && !gi.inflight[ci]) { gi.free_slots.push_back(gi.slot[ci]); gi.slot[ci] = nullptr; }
 }
-static void advance_head(xck_bam* b, bool hold = false) {           // hold: a parse in flight still reads the chunk (finish_parse releases it)
-    if (hold) { b->pj.ring_idx = b->head; b->held = 1; } else release_chunk(b, b->head);
+static void advance_head(xck_bam* b, IngestJob* hold = nullptr) {     // hold: that job's parse still reads the chunk (reap_jobs takes it back)
+    if (hold) { hold->ring_idx = b->head; hold->released = false; b->held++; } else release_chunk(b, b->head);
     b->head = (b->head + 1) % b->n_ring; b->n_sched--;
 }
+// ring chunks whose parse has ended go back to the ring (coordinator only)
+static void reap_jobs(xck_bam* b) {
+    for (auto& j : b->jobs) if (!j.released && j.parsed.load(std::memory_order_acquire)) { release_chunk(b, j.ring_idx); j.released = true; b->held--; }
+}
+static Pusher* get_pusher(xck_engine* e, xck_bam* b) {
+    if (!b->pusher) { b->pusher = new Pusher(); Pusher* pp = b->pusher; pp->e = e; pp->b = b; pp->th = std::thread([pp] { pp->run(); }); }
+    return b->pusher;
+}
 
-// chunk i - 1: its parse tasks have ended -> errors, ring slot back, batches to the push thread (declared here, defined with the ingest)
-extern "C" { static int finish_parse(xck_engine* e, xck_bam* b); }
+void Pusher::run() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+        cv.wait(lk, [this] { return stop || qn > 0; });
+        if (qn == 0) return;
+        IngestJob* j = q[qh];
+        const bool failed = rc != 0;
+        lk.unlock();
+        int r = 0; std::string msg;
+        if (j->has_parse) {
+            const auto t0 = std::chrono::steady_clock::now();
+            j->tg.wait();
+            parse_wait_ns += ns_since(t0);
+            int fl = j->flags.load();
+            if (const int th = j->tg.take_thrown()) fl |= th == 1 ? 4 : 8;
+            if (fl & 4) { msg = "out of host memory (record parse)"; r = XCK_E_NOMEM; }
+            else if (fl & 8) { msg = "C++ exception in a parse task"; r = XCK_E_IO; }
+            else if (fl & 1) { msg = "corrupt BAM record (fields exceed block_size)"; r = XCK_E_IO; }
+            else if (fl & 2) { msg = "too many distinct non-ACGT keys for the key width"; r = XCK_E_CAPACITY; }
+        }
+        j->parsed.store(1, std::memory_order_release);
+        if (!failed && !r && e->n_impl > 0 && !j->pending.empty()) {
+            // the whole chunk crosses PCIe as ONE block; its batches are slices of the block (fused handles: both pipelines read the same copy)
+            const auto t0 = std::chrono::steady_clock::now();
+            HostSoA& s = b->soa[j->soa];
+            std::vector<xck_batch> bts; bts.reserve(j->pending.size());
+            for (const PendingBatch& pb : j->pending) {
+                xck_batch bt; memset(&bt, 0, sizeof bt);
+                bt.contig = pb.contig; bt.n_reads = (int32_t)(pb.r1 - pb.r0); bt.ordinal_base = pb.ordinal_base;
+                bt.pos = s.pos + pb.r0; bt.flag = s.flag + pb.r0; bt.mapq = s.mapq + pb.r0; bt.cell = s.cell + pb.r0; bt.umi = s.umi + pb.r0;
+                bt.cig_off = s.cig_off + pb.r0; bt.cigar = s.cigar;
+                if (e->dec.want_seq) { bt.seq_off = s.seq_off + pb.r0; bt.seq = s.seq; }
+                bts.push_back(bt);
+            }
+            try { r = xck::engine_push_block(e, s.base, s.used, bts.data(), (int)bts.size(), &s.fence); } catch (const std::bad_alloc&) { r = XCK_E_NOMEM; } catch (...) { r = XCK_E_IO; }
+            if (r) msg = e->err;
+            push_ns += ns_since(t0);
+        }
+        lk.lock();
+        if (r && !rc) { rc = r; err = msg; }
+        qh = (qh + 1) % MAXQ; qn--;
+        cv.notify_all();
+    }
+}
 
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
@@ -1065,7 +1105,11 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     auto t_ph = std::chrono::steady_clock::now();
     auto phase = [&](uint64_t& acc) { const auto now = std::chrono::steady_clock::now(); acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_ph).count(); t_ph = now; };
     // keep the ring full: while this chunk is stitched and parsed the pool inflates the next two
-    while (b->n_sched + b->held < b->n_ring && !b->scan_end) {
+    reap_jobs(b);
+    // (the chunks behind `head` that a parse in flight still reads must not be scheduled over: `back` = how far the oldest of them lies behind)
+    int back = 0;
+    for (auto& j : b->jobs) if (!j.released) back = std::max(back, (b->head - j.ring_idx + b->n_ring) % b->n_ring);
+    while (b->n_sched + back < b->n_ring && !b->scan_end) {
         const int ci = (b->head + b->n_sched) % b->n_ring;
         Chunk& nc = b->ch[ci];
         schedule_chunk(b, nc, ci, crc, cm, e->dec.want_seq);
@@ -1161,12 +1205,12 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         phase(b->tm.layout);
         limit = (int64_t)n_rec;
         if (b->defer_parse) {
-            if (const int frc = finish_parse(e, b)) return frc;         // chunk i - 1 first: pushes stay in file order, one parse in flight
-            phase(b->tm.wait_parse);
-            const int32_t smp = o->sample; HostSoA* sp = &s; std::atomic<int>* fl = &b->pj.flags;
-            b->pj.flags.store(0); b->pj.soa = b->soa_i; b->pj.pending.swap(b->pending); b->pending.clear(); b->pj.active = true;
+            IngestJob& jb = b->jobs[b->job_n % 3];                      // (free: at most two jobs are outstanding, and this one is the third)
+            reap_jobs(b);
+            const int32_t smp = o->sample; HostSoA* sp = &s; std::atomic<int>* fl = &jb.flags;
+            jb.flags.store(0); jb.parsed.store(0); jb.has_parse = true; jb.soa = b->soa_i; jb.pending.swap(b->pending); b->pending.clear();
             for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
-                b->pj.tg.add(*b->pool, [b, e, sp, smp, wpp, cm, fl] { parse_part(b, e, sp, smp, wpp, cm, fl); }, true); }
+                jb.tg.add(*b->pool, [b, e, sp, smp, wpp, cm, fl] { parse_part(b, e, sp, smp, wpp, cm, fl); }, true); }   // (ahead of the later chunks' inflate tasks)
             if (b->per_tid_ranges && cm.t_end) {                        // (same check as below: it only looks at the record lists)
                 const RecRef* last = nullptr;
                 for (size_t pi = c.parts.size(); pi-- > 0 && !last;) if (!c.parts[pi].recs.empty()) last = &c.parts[pi].recs.back();
@@ -1175,8 +1219,12 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
                 }
             }
             b->n_records += limit;
-            advance_head(b, true);
-            return 2;                                                   // parse in flight: b->pj
+            advance_head(b, &jb);
+            b->job_n++;
+            const int prc = get_pusher(e, b)->submit(&jb);              // waits while two chunks are outstanding behind this one
+            phase(b->tm.wait_push);
+            if (prc) { b->err = b->pusher->err; return prc; }
+            return 2;                                                   // parse + push in flight
         }
         { TaskGroup tg; const int32_t smp = o->sample; HostSoA* sp = &s;
           for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
@@ -1186,7 +1234,6 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         phase(b->tm.wait_parse);
     } else {
     // ---- slow path: stitch the per-task record lists serially; re-walk where the speculation failed ----
-    if (b->defer_parse) { if (const int frc = finish_parse(e, b)) return frc; }   // (b->recs / rec_out belong to one chunk at a time; pushes stay in file order)
     b->tm.slow_chunks++;
     b->recs.clear(); b->rec_contig.clear();
     b->stitch.clear();
@@ -1321,45 +1368,26 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
     return 1;
 }
 
-// one decoded chunk -> the push thread: the whole chunk crosses PCIe as ONE block; its batches are slices of the block (fused handles:
-// both pipelines read the same copy).  Waits until the previous chunk's push has been issued.
-static int push_chunk(xck_engine* e, xck_bam* b, int soa_i, const std::deque<PendingBatch>& pend) {
-    if (e->n_impl <= 0 || pend.empty()) return XCK_OK;          // (a decode-only handle decodes and discards: host-ingest benchmarks)
+// a chunk that was parsed in place (slow path) -> the push thread, behind the chunks already queued there
+static int push_chunk(xck_engine* e, xck_bam* b) {
+    if (e->n_impl <= 0 || b->pending.empty()) return XCK_OK;    // (a decode-only handle decodes and discards: host-ingest benchmarks)
     const auto t_p = std::chrono::steady_clock::now();
-    HostSoA& s = b->soa[soa_i];
-    std::vector<xck_batch> bts; bts.reserve(pend.size());
-    for (const PendingBatch& pb : pend) {
-        xck_batch bt; memset(&bt, 0, sizeof bt);
-        bt.contig = pb.contig; bt.n_reads = (int32_t)(pb.r1 - pb.r0); bt.ordinal_base = pb.ordinal_base;
-        bt.pos = s.pos + pb.r0; bt.flag = s.flag + pb.r0; bt.mapq = s.mapq + pb.r0; bt.cell = s.cell + pb.r0; bt.umi = s.umi + pb.r0;
-        bt.cig_off = s.cig_off + pb.r0; bt.cigar = s.cigar;
-        if (e->dec.want_seq) { bt.seq_off = s.seq_off + pb.r0; bt.seq = s.seq; }
-        bts.push_back(bt);
-    }
-    if (!b->pusher) { b->pusher = new Pusher(); Pusher* pp = b->pusher; pp->th = std::thread([pp] { pp->run(); }); }
-    if (const int prc = b->pusher->wait_idle()) { b->err = e->err; return prc; }     // (chunk i - 1 is pushed; its error, if any, ends the ingest)
-    b->pusher->submit(e, s.base, s.used, bts, &s.fence);
+    IngestJob& jb = b->jobs[b->job_n % 3];
+    reap_jobs(b);
+    jb.flags.store(0); jb.parsed.store(0); jb.has_parse = false; jb.soa = b->soa_i; jb.ring_idx = -1; jb.released = true;
+    jb.pending.swap(b->pending); b->pending.clear();
+    b->job_n++;
+    const int prc = get_pusher(e, b)->submit(&jb);
     b->tm.wait_push += ns_since(t_p);
-    return XCK_OK;
+    if (prc) b->err = b->pusher->err;
+    return prc;
 }
 
-static int finish_parse(xck_engine* e, xck_bam* b) {
-    if (!b->pj.active) return XCK_OK;
-    b->pj.tg.wait(); b->pj.active = false;
-    int fl = b->pj.flags.load();
-    if (const int th = b->pj.tg.take_thrown()) fl |= th == 1 ? 4 : 8;
-    release_chunk(b, b->pj.ring_idx); b->held = 0;
-    if (fl & 4) { b->err = "out of host memory (record parse)"; return XCK_E_NOMEM; }
-    if (fl & 8) { b->err = "C++ exception in a parse task"; return XCK_E_IO; }
-    if (fl & 1) { b->err = "corrupt BAM record (fields exceed block_size)"; return XCK_E_IO; }
-    if (fl & 2) { b->err = "too many distinct non-ACGT keys for the key width"; return XCK_E_CAPACITY; }
-    return push_chunk(e, b, b->pj.soa, b->pj.pending);
-}
-
-// nothing of this reader is in flight any more: parse tasks ended (their chunk pushed unless `rc` already reports an error), push thread idle
+// nothing of this reader is in flight any more: parse tasks ended, their chunks pushed (unless something failed), push thread idle
 static int drain_ingest(xck_engine* e, xck_bam* b, int rc) {
-    if (b->pj.active) { if (rc < 0) { b->pj.tg.wait(); b->pj.active = false; (void)b->pj.tg.take_thrown(); release_chunk(b, b->pj.ring_idx); b->held = 0; } else rc = finish_parse(e, b); }
-    if (b->pusher) { const int prc = b->pusher->wait_idle(); if (rc >= 0 && prc) { b->err = e->err; rc = prc; } }
+    (void)e;
+    if (b->pusher) { const int prc = b->pusher->wait_idle(); if (rc >= 0 && prc) { b->err = b->pusher->err; rc = prc; } }
+    reap_jobs(b);
     return rc;
 }
 
@@ -1374,7 +1402,7 @@ static int ingest_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int6
         int rc = decode_next_chunk(e, b, o);
         if (rc < 0) return fail(rc);
         if (rc == 0) { b->done = true; break; }
-        if (rc == 1) { if (const int prc = push_chunk(e, b, b->soa_i, b->pending)) return fail(prc); }   // (parsed in place: the slow path)
+        if (rc == 1) { if (const int prc = push_chunk(e, b)) return fail(prc); }   // (parsed in place: the slow path, or no deferral)
         b->pending.clear();
         if (pause > 0 && !b->done && b->n_records - start >= pause) {   // chunk boundary: the reader stays positioned
             if (const int drc = drain_ingest(e, b, 0)) return fail(drc);   // (the caller may talk to the engine now: nothing is in flight)
