@@ -99,6 +99,21 @@ def gen_bam(args, work, bam, reads, level, shape, threads, log, seed=11):
     if os.path.isfile(ok) and os.path.isfile(bam) and os.path.isfile(bam + ".bai"):
         return False
     t0 = time.time()
+    import shutil
+    need = int(reads * (130 if shape == "cellranger" else 100)) + (1 << 30)      # (compressed bytes per record, generously)
+    if shutil.disk_usage(work).free < need and getattr(args, "make_room", False):
+        # the work directory is scratch: BAMs this tool generated itself (marked by their .ok file) give way, nothing else is touched
+        import glob
+        for okf in glob.glob(os.path.join(args.work, "synth_*.bam.ok")) + glob.glob(os.path.join(args.work, "well", "cell_*.bam.ok")):
+            if okf == ok:
+                continue
+            for fn in (okf[:-3], okf[:-3] + ".bai", okf):
+                if os.path.isfile(fn):
+                    os.remove(fn)
+        log("--make-room: removed earlier generated BAMs from %s" % args.work)
+    if shutil.disk_usage(work).free < need:
+        sys.exit("bench.py: %s has %.1f GB free, %s needs about %.1f GB (--make-room deletes the BAMs earlier runs of this tool generated there; --work picks another directory)"
+                 % (work, shutil.disk_usage(work).free / 1e9, os.path.basename(bam), need / 1e9))
     env = dict(os.environ)
     env.pop("XCK_SYNTH_SHAPE", None)
     if shape:
@@ -332,7 +347,7 @@ def main():
     ap.add_argument("--well-bams", type=int, default=384)
     ap.add_argument("--well-reads", type=int, default=2_000_000, help="records per per-cell BAM (--workload well)")
     ap.add_argument("--well-sub-reads", type=int, default=250_000, help="10x run: records per per-cell BAM of the configs[4] sub-record (0 = skip it)")
-    ap.add_argument("--make-room", action="store_true", help="--workload well with a short disk: delete the 10x workload's generated BAMs (those with a .ok marker of this tool) under --work")
+    ap.add_argument("--make-room", action="store_true", help="short disk: delete the BAMs earlier runs of this tool generated under --work (those with its .ok marker) before generating new ones")
     ap.add_argument("--selfcheck", action="store_true", help="N > 1: first count a --selfcheck-reads file with N ranks and with rank 0 alone; the output files must be identical")
     ap.add_argument("--selfcheck-reads", type=int, default=50_000_000)
     args = ap.parse_args()

@@ -64,7 +64,7 @@ def _count(bam, regions, snps, names, bcs, flags=0, passes=1):
 def test_device_share_of_the_inflate_changes_nothing(level, knob_env, tmp_path):
     bam, regions, snps, names, bcs = _make_bam(str(tmp_path), 1500000, level)
     knob_env["XCK_CHUNK_BYTES"] = str(6 << 20)                    # ~90 blocks per chunk: dozens of chunks, each large enough for the device
-    knob_env["XCK_GPU_INFLATE_MIN_MB"] = "0"                      # (auto mode leaves files below 512 MB to the host)
+    knob_env["XCK_GPU_INFLATE_MIN_MB"] = "0"                      # (auto mode leaves files below 96 MB to the host)
     knob_env["XCK_GPU_INFLATE"] = "0"
     n0, host, st0 = _count(bam, regions, snps, names, bcs)
     assert n0 == 1500000 and st0["gpu_inflate_chunks"] == 0 and len(host["count"][0]) > 10000 and len(host["dp"][0]) > 100
