@@ -15,7 +15,7 @@ python3 tools/fold_times.py "$OUT/trace_resident" > "$OUT/fold_kernel_times.txt"
 echo "== unprofiled: bench.py --resident-only"
 timeout -k 10 300 python3 bench.py --resident-only --resident-passes 5 > "$OUT/bench_resident.json" 2>/dev/null || exit 1
 echo "== kernel trace: end-to-end pass"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_e2e" -- python3 bench.py --cpu-sample 0 --resident-passes 0 --sub-reads 0 > "$OUT/bench_e2e_profiled.json" 2> "$OUT/trace_e2e.err" || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_e2e" -- python3 bench.py --make-room --cpu-sample 0 --resident-passes 0 --sub-reads 0 > "$OUT/bench_e2e_profiled.json" 2> "$OUT/trace_e2e.err" || exit 1
 for label in fc fc_filtered baf; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $label $ctr"

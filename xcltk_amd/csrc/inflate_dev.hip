@@ -348,15 +348,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING > 0 ? 3
                 const uint32_t packed = used | (kind << 6) | (olen << 8);
                 if constexpr (PROF) { asm volatile("" :: "v"(packed)); }
                 XCK_PROF_AT(3);
-                // the walk: which lanes start a symbol (scalar); a round ends after 64 offsets, at the end of the block, or before the
-                // symbol that would take its output past CAP bytes
+                // the walk: which lanes start a symbol (scalar); a round ends after 64 offsets, at the end of the block, or (with the LDS
+                // ring) before the symbol that would take its output past CAP bytes
                 uint64_t starts = 0; uint32_t cur = 0, stop = 0, total = 0;
-                while (cur < 64) {
-                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
-                    if (total + (p >> 8) > CAP && starts) break;
-                    starts |= 1ull << cur;
-                    total += p >> 8; cur += p & 63u;
-                    if (((p >> 6) & 3u) >= 2) { stop = (p >> 6) & 3u; break; }
+                if constexpr (RING > 0) {
+                    while (cur < 64) {
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
+                        if (total + (p >> 8) > CAP && starts) break;
+                        starts |= 1ull << cur;
+                        total += p >> 8; cur += p & 63u;
+                        if (((p >> 6) & 3u) >= 2) { stop = (p >> 6) & 3u; break; }
+                    }
+                } else {
+                    // ... four symbols per hop: every lane first learns, through two rounds of ds_bpermute, what a walk that STARTED at it would
+                    // cross with its next four symbols (bits, output bytes, which lanes, whether it stops) - the scalar walk then needs
+                    // three readlanes per four symbols instead of a readlane and two branches per symbol (the walk was 51 % of a round on the
+                    // literal-heavy streams, r04_phase_clocks.txt).  hop word: bits (8) | stop (2) << 8 | output bytes << 10
+                    auto join = [](uint32_t a, uint32_t b) { return a + (b & 0xffu) + (b & ~0x3ffu) + (b & 0x300u); };     // (a's stop field is 0 where this is used)
+                    const uint32_t h1 = used | ((kind >= 2 ? kind : 0u) << 8) | (olen << 10);
+                    const uint32_t lo1 = lane < 32 ? 1u << lane : 0u, hi1 = lane >= 32 ? 1u << (lane - 32) : 0u;
+                    const uint32_t s1 = (uint32_t)lane + used; const bool v1 = kind < 2 && s1 < 64;
+                    const uint32_t q1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((s1 & 63u) << 2), (int)h1);
+                    const uint32_t h2 = v1 ? join(h1, q1) : h1;
+                    const uint32_t lo2 = lo1 | (v1 && s1 < 32 ? 1u << s1 : 0u), hi2 = hi1 | (v1 && s1 >= 32 ? 1u << (s1 - 32) : 0u);
+                    const uint32_t s2 = (uint32_t)lane + (h2 & 0xffu); const bool v2 = !(h2 & 0x300u) && s2 < 64;
+                    const int a2 = (int)((s2 & 63u) << 2);
+                    const uint32_t q2 = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)h2);
+                    const uint32_t ql = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)lo2), qh = (uint32_t)__builtin_amdgcn_ds_bpermute(a2, (int)hi2);
+                    const uint32_t h4 = v2 ? join(h2, q2) : h2, lo4 = v2 ? lo2 | ql : lo2, hi4 = v2 ? hi2 | qh : hi2;
+                    uint32_t slo = 0, shi = 0;
+                    while (cur < 64) {
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)h4, (int)cur);
+                        slo |= (uint32_t)__builtin_amdgcn_readlane((int)lo4, (int)cur); shi |= (uint32_t)__builtin_amdgcn_readlane((int)hi4, (int)cur);
+                        total += p >> 10; cur += p & 0xffu;
+                        if (p & 0x300u) { stop = (p >> 8) & 3u; break; }
+                    }
+                    starts = ((uint64_t)shi << 32) | slo;
                 }
                 XCK_PROF_AT(4);
                 if (stop == 3) { err = 30; break; }
