@@ -433,7 +433,11 @@ private:
     std::atomic<int> abandoned_{-1};
 };
 
-constexpr int N_CHUNK = 5, N_SOA = 3;
+#ifndef XCK_PUSH_Q
+#define XCK_PUSH_Q 2
+#endif
+constexpr int PUSH_Q = XCK_PUSH_Q;      // chunks the coordinator may run ahead of the push thread (Pusher)
+constexpr int N_CHUNK = 3 + PUSH_Q, N_SOA = PUSH_Q + 1;
 // What follows a chunk's layout - wait for its parse tasks, then push it (engine_push_block: one H2D copy + the join launches, after
 // waiting for the previous chunk's launch to be confirmed) - runs on a thread of its own, in file order, up to two chunks behind the
 // coordinator, which meanwhile schedules, waits for and lays out the next chunks.  With the GPU share of the inflate the coordinator
@@ -445,9 +449,9 @@ struct IngestJob {
     bool released = true;              // (coordinator) the ring chunk was taken back
 };
 struct Pusher {
-    static constexpr int MAXQ = 2;     // jobs the coordinator may run ahead
+    static constexpr int MAXQ = PUSH_Q; // jobs the coordinator may run ahead
     std::thread th; std::mutex mu; std::condition_variable cv;
-    bool stop = false; IngestJob* q[MAXQ] = {nullptr, nullptr}; int qh = 0, qn = 0;
+    bool stop = false; IngestJob* q[MAXQ] = {}; int qh = 0, qn = 0;
     int rc = 0; std::string err;       // first failure (parse flags or push); later jobs are waited for, not pushed
     xck_engine* e = nullptr; xck_bam* b = nullptr;
     uint64_t push_ns = 0, parse_wait_ns = 0;
@@ -485,8 +489,8 @@ struct xck_bam {
     GpuShare gi;
     Pusher* pusher = nullptr;          // made at the first push of a GPU-backed ingest
     // xck_ingest_bam on a GPU-backed handle (defer_parse): the parse of a chunk (pool tasks: record fields -> SoA block) and its push run
-    // behind the coordinator (Pusher).  jobs[k % 3] belongs to the k-th chunk handed over; at most Pusher::MAXQ are outstanding.
-    IngestJob jobs[3]; uint64_t job_n = 0;
+    // behind the coordinator (Pusher).  jobs[k % (PUSH_Q + 1)] belongs to the k-th chunk handed over; at most Pusher::MAXQ are outstanding.
+    IngestJob jobs[PUSH_Q + 1]; uint64_t job_n = 0;
     bool defer_parse = false;          // set by xck_ingest_bam for GPU-backed handles
     int held = 0;                      // ring chunks behind `head` whose parse may still read them (taken back by reap_jobs)
     std::vector<uint8_t> carry;        // partial record from the previous chunk
@@ -566,10 +570,20 @@ static GpuInflateSlot* take_gpu_slot(int device, int free_cus, bool verbose) {
       for (size_t i = 0; i < g_gpu_slots.size(); i++) if (g_gpu_slots[i]->device == device) { GpuInflateSlot* s = g_gpu_slots[i]; g_gpu_slots.erase(g_gpu_slots.begin() + (long)i); return s; } }
     return gpu_inflate_slot_create(device, free_cus, verbose);
 }
+// (parked slots are destroyed at exit, BEFORE the HIP runtime's own teardown - this handler is registered after the runtime came up, so
+// it runs first: streams with a CU mask and mapped host blocks left alive made the process crash at exit under rocprofv3)
+static void destroy_parked_gpu_slots() {
+    std::vector<GpuInflateSlot*> v;
+    { std::lock_guard<std::mutex> lk(g_scratch_mu); v.swap(g_gpu_slots); }
+    for (GpuInflateSlot* s : v) gpu_inflate_slot_destroy(s);
+}
 static void park_gpu_slot(GpuInflateSlot* s) {
     if (!s) return;
     gpu_inflate_slot_wait(s);                                          // nothing in flight on a parked slot
-    { std::lock_guard<std::mutex> lk(g_scratch_mu); if (g_gpu_slots.size() < 16) { g_gpu_slots.push_back(s); return; } }
+    { std::lock_guard<std::mutex> lk(g_scratch_mu);
+      static bool at_exit = false;
+      if (!at_exit) { at_exit = true; std::atexit(destroy_parked_gpu_slots); }
+      if (g_gpu_slots.size() < 16) { g_gpu_slots.push_back(s); return; } }
     gpu_inflate_slot_destroy(s);
 }
 
@@ -1205,7 +1219,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         phase(b->tm.layout);
         limit = (int64_t)n_rec;
         if (b->defer_parse) {
-            IngestJob& jb = b->jobs[b->job_n % 3];                      // (free: at most two jobs are outstanding, and this one is the third)
+            IngestJob& jb = b->jobs[b->job_n % (PUSH_Q + 1)];           // (free: at most PUSH_Q jobs are outstanding)
             reap_jobs(b);
             const int32_t smp = o->sample; HostSoA* sp = &s; std::atomic<int>* fl = &jb.flags;
             jb.flags.store(0); jb.parsed.store(0); jb.has_parse = true; jb.soa = b->soa_i; jb.pending.swap(b->pending); b->pending.clear();
@@ -1372,7 +1386,7 @@ static int next_batch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, 
 static int push_chunk(xck_engine* e, xck_bam* b) {
     if (e->n_impl <= 0 || b->pending.empty()) return XCK_OK;    // (a decode-only handle decodes and discards: host-ingest benchmarks)
     const auto t_p = std::chrono::steady_clock::now();
-    IngestJob& jb = b->jobs[b->job_n % 3];
+    IngestJob& jb = b->jobs[b->job_n % (PUSH_Q + 1)];
     reap_jobs(b);
     jb.flags.store(0); jb.parsed.store(0); jb.has_parse = false; jb.soa = b->soa_i; jb.ring_idx = -1; jb.released = true;
     jb.pending.swap(b->pending); b->pending.clear();
