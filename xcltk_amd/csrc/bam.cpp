@@ -213,6 +213,15 @@ public:
     explicit Pool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { run(); }); }
     ~Pool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
     void submit(std::function<void()> f, bool front = false) { { std::lock_guard<std::mutex> lk(mu_); if (front) q_.push_front(std::move(f)); else q_.push_back(std::move(f)); } cv_.notify_one(); }
+    // many tasks under ONE lock and one wake-up: a chunk hands ~100 part tasks to the pool three times (inflate / gather, walk, parse), and a
+    // lock + futex wake per task cost the coordinator ~0.7 ms per chunk
+    void submit_many(std::vector<std::function<void()>>& fs, bool front = false) {
+        if (fs.empty()) return;
+        { std::lock_guard<std::mutex> lk(mu_);
+          if (front) for (size_t i = fs.size(); i-- > 0;) q_.push_front(std::move(fs[i])); else for (auto& f : fs) q_.push_back(std::move(f)); }
+        if (fs.size() == 1) cv_.notify_one(); else cv_.notify_all();
+        fs.clear();
+    }
     int size() const { return (int)th_.size(); }
     void set_affinity(const cpu_set_t& set) { for (auto& t : th_) pthread_setaffinity_np(t.native_handle(), sizeof set, &set); }
 private:
@@ -242,6 +251,18 @@ struct TaskGroup {
         p.submit([this, f] {
             try { f(); } catch (const std::bad_alloc&) { thrown.store(1); } catch (...) { thrown.store(2); }
             std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); }, front);
+    }
+    // collect tasks with later(), hand them to the pool in one go with flush()
+    std::vector<std::function<void()>> batch;
+    void later(std::function<void()> f) {
+        batch.push_back([this, f] {
+            try { f(); } catch (const std::bad_alloc&) { thrown.store(1); } catch (...) { thrown.store(2); }
+            std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv.notify_all(); });
+    }
+    void flush(Pool& p, bool front = false) {
+        if (batch.empty()) return;
+        { std::lock_guard<std::mutex> lk(mu); pending += (int)batch.size(); }
+        p.submit_many(batch, front);
     }
     void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return pending == 0; }); }
 };
@@ -844,9 +865,9 @@ static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const 
         wp.spec_start = wp.u_begin + (pi == 0 ? skip0 : 0); wp.stop = wp.spec_start; wp.recs.clear();
         wp.n_out = wp.n_cig = wp.n_seq = 0; wp.runs.clear();
         Chunk* cp = &c; const uint8_t* map = b->map; WalkPart* wpp = &wp; DecodeTimes* tmp_ = &b->tm;
-        if (!gs) { c.tg.add(*b->pool, [cp, map, verify_crc, wpp, tmp_, cm, want_seq] { run_part(cp, map, verify_crc, wpp, tmp_, cm, want_seq, nullptr); }); continue; }
+        if (!gs) { c.tg.later([cp, map, verify_crc, wpp, tmp_, cm, want_seq] { run_part(cp, map, verify_crc, wpp, tmp_, cm, want_seq, nullptr); }); continue; }
         GpuShare* gip = &gi; const size_t nb_ = nb, usz_ = usz;
-        c.tg.add(*b->pool, [cp, map, i0, i1, gs, gip, nb_, usz_] {
+        c.tg.later([cp, map, i0, i1, gs, gip, nb_, usz_] {
             const auto t_a = std::chrono::steady_clock::now();
             for (size_t i = i0; i < i1; i++) memcpy(gs->h_in + gs->h_bl[i].in_off, map + cp->blocks[i].coff + cp->blocks[i].data_off, cp->blocks[i].data_len);
             __atomic_fetch_add(&gip->copy_ns, ns_since(t_a), __ATOMIC_RELAXED);
@@ -856,6 +877,7 @@ static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const 
             }
         });
     }
+    c.tg.flush(*b->pool);
 }
 
 // ---- NUMA: the decoder stays on ONE socket ---------------------------------------------------------------------------
@@ -1153,7 +1175,8 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         if (dev_ok) for (size_t i = 0; i < c.blocks.size(); i++) b->gi.left_blocks += st[i] != 0;
         else b->gi.left_blocks += c.blocks.size();
         Chunk* cp = &c; const uint8_t* map = b->map; DecodeTimes* tmp_ = &b->tm; const bool want_seq = e->dec.want_seq;
-        for (WalkPart& wp : c.parts) { WalkPart* wpp = &wp; c.tg.add(*b->pool, [cp, map, wpp, tmp_, cm, want_seq, st] { run_part(cp, map, false, wpp, tmp_, cm, want_seq, st); }, true); }   // (ahead of the later chunks' inflate tasks)
+        for (WalkPart& wp : c.parts) { WalkPart* wpp = &wp; c.tg.later([cp, map, wpp, tmp_, cm, want_seq, st] { run_part(cp, map, false, wpp, tmp_, cm, want_seq, st); }); }
+        c.tg.flush(*b->pool, true);                                       // (ahead of the later chunks' inflate tasks)
         c.tg.wait();
         if (const int th = c.tg.take_thrown()) { b->err = th == 1 ? "out of host memory (BGZF inflate / record walk)" : "C++ exception in a decoder task"; return th == 1 ? XCK_E_NOMEM : XCK_E_IO; }
     }
@@ -1224,7 +1247,8 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             const int32_t smp = o->sample; HostSoA* sp = &s; std::atomic<int>* fl = &jb.flags;
             jb.flags.store(0); jb.parsed.store(0); jb.has_parse = true; jb.soa = b->soa_i; jb.pending.swap(b->pending); b->pending.clear();
             for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
-                jb.tg.add(*b->pool, [b, e, sp, smp, wpp, cm, fl] { parse_part(b, e, sp, smp, wpp, cm, fl); }, true); }   // (ahead of the later chunks' inflate tasks)
+                jb.tg.later([b, e, sp, smp, wpp, cm, fl] { parse_part(b, e, sp, smp, wpp, cm, fl); }); }
+            jb.tg.flush(*b->pool, true);                                // (ahead of the later chunks' inflate tasks)
             if (b->per_tid_ranges && cm.t_end) {                        // (same check as below: it only looks at the record lists)
                 const RecRef* last = nullptr;
                 for (size_t pi = c.parts.size(); pi-- > 0 && !last;) if (!c.parts[pi].recs.empty()) last = &c.parts[pi].recs.back();
@@ -1242,7 +1266,8 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         }
         { TaskGroup tg; const int32_t smp = o->sample; HostSoA* sp = &s;
           for (const WalkPart& wp : c.parts) { if (!wp.n_out) continue; const WalkPart* wpp = &wp;
-              tg.add(*b->pool, [b, e, sp, smp, wpp, cm, &flags] { parse_part(b, e, sp, smp, wpp, cm, &flags); }, true); }   // (ahead of the later chunks' inflate tasks: the coordinator waits for these)
+              tg.later([b, e, sp, smp, wpp, cm, &flags] { parse_part(b, e, sp, smp, wpp, cm, &flags); }); }
+          tg.flush(*b->pool, true);                                     // (ahead of the later chunks' inflate tasks: the coordinator waits for these)
           tg.wait();
           if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
         phase(b->tm.wait_parse);
@@ -1320,7 +1345,8 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
     // ---- parse (parallel) ----
     { TaskGroup tg; const int64_t per = std::max<int64_t>(4096, (limit + b->n_threads * 4 - 1) / (b->n_threads * 4));
       for (int64_t r0 = 0; r0 < limit; r0 += per) { int64_t r1 = std::min(limit, r0 + per); int32_t smp = o->sample;
-          tg.add(*b->pool, [b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }, true); }
+          tg.later([b, e, smp, r0, r1, &flags] { parse_range(b, e, smp, r0, r1, &flags); }); }
+      tg.flush(*b->pool, true);
       tg.wait();
       if (const int th = tg.take_thrown()) flags.fetch_or(th == 1 ? 4 : 8); }
     phase(b->tm.wait_parse);
