@@ -83,3 +83,64 @@ def test_device_share_of_the_inflate_changes_nothing(level, knob_env, tmp_path):
     for k in host:
         for a, b in zip(host[k], crc[k]):
             assert np.array_equal(a, b)
+
+
+def _engine(regions, snps, names, bcs):
+    return Engine(capi.XCK_MODE_BOTH, names, regions, len(bcs), snps=snps, barcodes=bcs, cell_tag="CB", umi_tag="UB", min_include=0.9,
+                  min_count=1, min_maf=0, no_dup_hap=True, min_mapq=20, min_len=30, incl_flag=0, excl_flag=772, no_orphan=True, n_threads=8)
+
+
+@pytest.mark.parametrize("share", ["0", "100"])
+def test_sliced_ingest_equals_one_call(share, knob_env, tmp_path):
+    """xck_ingest_opts.pause_records: the parse and the push of a chunk run behind the decoder's coordinator (csrc/bam.cpp: IngestJob,
+    Pusher); a call that returns at a chunk boundary has drained them, so slices of any size give the matrices of one call."""
+    bam, regions, snps, names, bcs = _make_bam(str(tmp_path), 600000, 6)
+    knob_env["XCK_CHUNK_BYTES"] = str(3 << 20)
+    knob_env["XCK_GPU_INFLATE_MIN_MB"] = "0"
+    knob_env["XCK_GPU_INFLATE"] = share
+    n0, whole, _ = _count(bam, regions, snps, names, bcs)
+    eng = _engine(regions, snps, names, bcs)
+    try:
+        st = eng.open_stream(bam)
+        seen = []
+        while not st.done:
+            n, done = st.advance(70000)
+            assert n > (seen[-1] if seen else 0) or done
+            seen.append(n)
+        st.close()
+        assert seen[-1] == n0 and len(seen) >= 5
+        got = eng.finish()
+        for k in whole:
+            for a, b in zip(whole[k], got[k]):
+                assert np.array_equal(np.array(b), a), k
+    finally:
+        eng.close()
+
+
+def test_damaged_file_ends_the_ingest_with_an_error_and_the_handle_lives_on(knob_env, tmp_path):
+    """A BGZF block whose DEFLATE stream is damaged in the middle of the file: the device leaves it to the host (non-zero status), the
+    host decoder reports it, xck_ingest_bam returns XCK_E_IO after draining what was in flight - and after xck_reset the same handle
+    counts the intact file correctly."""
+    bam, regions, snps, names, bcs = _make_bam(str(tmp_path), 600000, 6)
+    knob_env["XCK_CHUNK_BYTES"] = str(3 << 20)
+    knob_env["XCK_GPU_INFLATE_MIN_MB"] = "0"
+    knob_env["XCK_GPU_INFLATE"] = "100"
+    n0, whole, _ = _count(bam, regions, snps, names, bcs)
+    raw = bytearray(open(bam, "rb").read())
+    at = len(raw) * 2 // 3
+    raw[at:at + 64] = bytes(64)                                   # zeros in the middle of some block's compressed stream
+    bad = os.path.join(str(tmp_path), "damaged.bam")
+    open(bad, "wb").write(raw)
+    eng = _engine(regions, snps, names, bcs)
+    try:
+        with pytest.raises(Exception) as ei:
+            eng.ingest_bam(bad)
+        assert getattr(ei.value, "code", capi.XCK_E_IO) in (capi.XCK_E_IO, capi.XCK_E_ARG), ei.value
+        eng.reset()
+        assert eng.ingest_bam(bam) == n0
+        got = eng.finish()
+        for k in whole:
+            for a, b in zip(whole[k], got[k]):
+                assert np.array_equal(np.array(b), a), k
+    finally:
+        eng.close()
