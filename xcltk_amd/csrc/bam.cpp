@@ -513,7 +513,6 @@ struct xck_bam {
     // behind the coordinator (Pusher).  jobs[k % (PUSH_Q + 1)] belongs to the k-th chunk handed over; at most Pusher::MAXQ are outstanding.
     IngestJob jobs[PUSH_Q + 1]; uint64_t job_n = 0;
     bool defer_parse = false;          // set by xck_ingest_bam for GPU-backed handles
-    int held = 0;                      // ring chunks behind `head` whose parse may still read them (taken back by reap_jobs)
     std::vector<uint8_t> carry;        // partial record from the previous chunk
     std::vector<uint8_t> stitch;       // boundary record assembled from carry + head of this chunk
     std::vector<RecRef> recs; std::vector<int32_t> rec_contig; std::vector<int64_t> rec_out;   // serial walk output (slow path)
@@ -1056,12 +1055,12 @@ static void release_chunk(xck_bam* b, int ci) {
     if (gi.slot[ci] && !gi.inflight[ci]) { gi.free_slots.push_back(gi.slot[ci]); gi.slot[ci] = nullptr; }
 }
 static void advance_head(xck_bam* b, IngestJob* hold = nullptr) {     // hold: that job's parse still reads the chunk (reap_jobs takes it back)
-    if (hold) { hold->ring_idx = b->head; hold->released = false; b->held++; } else release_chunk(b, b->head);
+    if (hold) { hold->ring_idx = b->head; hold->released = false; } else release_chunk(b, b->head);
     b->head = (b->head + 1) % b->n_ring; b->n_sched--;
 }
 // ring chunks whose parse has ended go back to the ring (coordinator only)
 static void reap_jobs(xck_bam* b) {
-    for (auto& j : b->jobs) if (!j.released && j.parsed.load(std::memory_order_acquire)) { release_chunk(b, j.ring_idx); j.released = true; b->held--; }
+    for (auto& j : b->jobs) if (!j.released && j.parsed.load(std::memory_order_acquire)) { release_chunk(b, j.ring_idx); j.released = true; }
 }
 static Pusher* get_pusher(xck_engine* e, xck_bam* b) {
     if (!b->pusher) { b->pusher = new Pusher(); Pusher* pp = b->pusher; pp->e = e; pp->b = b; pp->th = std::thread([pp] { pp->run(); }); }

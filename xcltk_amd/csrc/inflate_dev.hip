@@ -166,7 +166,7 @@ __device__ unsigned long long d_prof[8];          // PROF builds only (tools/gpu
 
 template <int RING, bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING > 0 ? 3 : 4, 8))) void k_inflate(const uint8_t* __restrict__ in, const DevBlock* __restrict__ blocks, int n_blocks,
-                                                uint8_t* out, int32_t* __restrict__ status) {
+                                                uint8_t* out, int32_t* __restrict__ status, uint8_t* host_out) {
     __shared__ Smem sm;
     __shared__ uint32_t win[IN_WIN / 4];
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING > 0 ? RING : 16];
@@ -436,11 +436,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING > 0 ? 3
     }
     if constexpr (RING > 0) { if (!err) for (uint32_t i = max(flushed, A_out) + (uint32_t)lane; i < op; i += 64) o0v[i] = ring[i & RM]; }   // the tail (and a block shorter than a segment)
     if constexpr (PROF) { XCK_PROF_AT(7); if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&d_prof[k], prof[k]); }
-    if (lane == 0) {
+    {
         // consumed input must lie inside the stream (the window is zero beyond it: a truncated stream must not pass)
-        const long long used_bits = (long long)(bi.pos - A) * 8 - bi.bc;
+        const long long used_bits = (long long)((uint32_t)__builtin_amdgcn_readfirstlane((int)bi.pos) - A) * 8 - __builtin_amdgcn_readfirstlane(bi.bc);
         if (!err && used_bits > (long long)blk.in_len * 8) err = 41;
-        status[b] = err ? err : (op == out_end ? 0 : 40);
+        if (!err && op != out_end) err = 40;
+        // the block's bytes -> the chunk's (mapped, pinned) host block, by the wave that made them: the copy-out then overlaps the other
+        // waves' decoding instead of following the whole launch as a kernel of its own (which cost every chunk 1 - 3 ms of latency and
+        // sent its 50 MB over PCIe in one burst).  16-byte stores where the block's own bytes fill an aligned 16, single bytes at its ends
+        // (the neighbours' bytes are theirs to write).  host_out and out are equally aligned (both allocations are page aligned).
+        if (host_out && !err) {
+            __threadfence_block();
+            const uint8_t* ob = out + blk.out_off; uint8_t* hb = host_out + blk.out_off; const uint32_t n = blk.out_len;
+            const uint32_t head = min((16u - (uint32_t)((uintptr_t)ob & 15u)) & 15u, n), body = (n - head) & ~15u;
+            if ((uint32_t)lane < head) hb[lane] = ob[lane];
+            for (uint32_t i = (uint32_t)lane * 16; i < body; i += 1024) *(uint4*)(hb + head + i) = *(const uint4*)(ob + head + i);
+            for (uint32_t i = head + body + (uint32_t)lane; i < n; i += 64) hb[i] = ob[i];
+        }
+        if (lane == 0) status[b] = err;
     }
 }
 
@@ -453,15 +466,15 @@ void dev_inflate_read_prof(unsigned long long out[8]) {
     unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d_prof), z, sizeof z);
 }
 
-int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status) {
+int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status, uint8_t* host_out) {
     if (n_blocks <= 0) return 0;
     const dim3 g((unsigned)n_blocks), t(64);
     switch (g_inflate_variant) {
-        case 0:  hipLaunchKernelGGL((k_inflate<0, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
-        case 2:  hipLaunchKernelGGL((k_inflate<8192, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
-        case 10: hipLaunchKernelGGL((k_inflate<0, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
-        case 11: hipLaunchKernelGGL((k_inflate<4096, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
-        default: hipLaunchKernelGGL((k_inflate<4096, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status); break;
+        case 0:  hipLaunchKernelGGL((k_inflate<0, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        case 2:  hipLaunchKernelGGL((k_inflate<8192, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        case 10: hipLaunchKernelGGL((k_inflate<0, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        case 11: hipLaunchKernelGGL((k_inflate<4096, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        default: hipLaunchKernelGGL((k_inflate<4096, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -522,22 +535,18 @@ bool gpu_inflate_slot_reserve(GpuInflateSlot* s, size_t in_bytes, size_t out_byt
     s->cap_in = ci; s->cap_out = co; s->cap_bl = cb;
     return true;
 }
-// inflated bytes: HBM -> mapped pinned host memory by CU stores (16 bytes per lane, coalesced)
-__global__ __launch_bounds__(256) void k_inflate_copy_out(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
 // No DMA engine on this path: the first version copied in and out with hipMemcpyAsync, and the engine's own copy of every decoded
 // chunk (one hipMemcpyAsync per chunk, csrc/engine.hip engine_push_block) queued up behind the 48 MB copy-outs - the coordinator's
 // push time rose from 0.25 to 1.6 s per 100 M records.  The kernel is bound by its serial Huffman chain, not by bytes: it takes
-// the compressed stream from host memory in 1 KB coalesced windows and the statuses go straight back.
+// the compressed stream from host memory in 1 KB coalesced windows, every wave stores its finished block to the host block, and the
+// statuses go straight back.
 int gpu_inflate_slot_launch(GpuInflateSlot* s, size_t in_bytes, size_t out_bytes, size_t n_blocks) {
     (void)in_bytes;
     if (hipSetDevice(s->device) != hipSuccess) return -1;
     for (size_t i = 0; i < n_blocks; i++) s->h_st[i] = -1;                  // (a block the kernel never reaches is left to the host)
-    if (dev_inflate_launch(s->stream, s->a_in, s->a_bl, (int)n_blocks, s->d_out, s->a_st) != 0) { (void)hipGetLastError(); return -1; }
-    const size_t n16 = (out_bytes + 15) / 16;
-    hipLaunchKernelGGL(k_inflate_copy_out, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 448)), dim3(256), 0, s->stream, (const uint4*)s->d_out, (uint4*)s->a_out, n16);
-    if (hipGetLastError() != hipSuccess || hipEventRecord(s->done, s->stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    (void)out_bytes;
+    if (dev_inflate_launch(s->stream, s->a_in, s->a_bl, (int)n_blocks, s->d_out, s->a_st, s->a_out) != 0) { (void)hipGetLastError(); return -1; }
+    if (hipEventRecord(s->done, s->stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return 0;
 }
 bool gpu_inflate_slot_done(GpuInflateSlot* s) { return hipEventQuery(s->done) != hipErrorNotReady; }
