@@ -366,6 +366,8 @@ struct Chunk {
     // GPU share of the inflate (csrc/inflate_dev.hip): the pool only gathers the compressed bytes into the slot's pinned block, the task
     // that finishes last enqueues copy-in, kernel and copy-out; walk (and the blocks the kernel left) follow when the chunk is consumed
     bool gpu = false; std::atomic<int> copy_left{0}; std::atomic<int> gpu_rc{0}; size_t in_total = 0;
+    std::atomic<int> launched{0};      // the last gather task has handed the chunk to the device (gpu_rc says how that went)
+    bool stage2 = false;               // the walk tasks that follow the device's inflate have been queued
 };
 
 struct PendingBatch { int32_t contig; int64_t r0, r1; uint64_t ordinal_base; };
@@ -808,7 +810,7 @@ static void run_part(Chunk* cp, const uint8_t* map, bool verify_crc, WalkPart* w
 }
 
 static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const ContigMap cm_in, bool want_seq) {
-    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0; c.gpu = false; c.gpu_rc = 0;
+    c.blocks.clear(); c.usize = 0; c.valid = false; c.failed = false; c.err.clear(); c.new_range = false; c.first_skip = 0; c.gpu = false; c.gpu_rc = 0; c.launched = 0; c.stage2 = false;
     if (b->scan_end) return;
     ChunkPlan pl = b->scanner->next();
     if (pl.end) { b->scan_end = true; return; }
@@ -872,7 +874,7 @@ static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const 
             __atomic_fetch_add(&gip->copy_ns, ns_since(t_a), __ATOMIC_RELAXED);
             if (cp->copy_left.fetch_sub(1) == 1) {                         // the chunk's compressed bytes are gathered: hand it to the device
                 const int rc = gpu_inflate_slot_launch(gs, cp->in_total, usz_, nb_);
-                cp->gpu_rc = rc;
+                cp->gpu_rc = rc; cp->launched.store(1, std::memory_order_release);
             }
         });
     }
@@ -1112,6 +1114,32 @@ void Pusher::run() {
     }
 }
 
+// A device chunk whose inflate is over: whatever the device did not inflate - single blocks with a non-zero status, or the whole chunk
+// after a runtime error - the pool inflates now, and every part walks its records as on the host path.  Called for the chunk the
+// coordinator has reached (wait = true: for the device if need be) and, without waiting, for the chunks behind it whose device part
+// has already ended - their walk is then over by the time the coordinator gets there (it used to wait ~0.5 ms per chunk for it).
+static void start_stage_two(xck_engine* e, xck_bam* b, int ci, ContigMap cm, bool wait) {
+    Chunk& c = b->ch[ci];
+    if (!c.gpu || c.stage2 || !c.valid || c.failed || (b->skip_range >= 0 && c.range_id == b->skip_range)) return;
+    GpuInflateSlot* gs = b->gi.slot[ci];
+    if (!wait && !(c.launched.load(std::memory_order_acquire) && (c.gpu_rc.load() != 0 || gpu_inflate_slot_done(gs)))) return;
+    if (wait) c.tg.wait();                                               // (the gather tasks: the last of them launches)
+    const auto t_w = std::chrono::steady_clock::now();
+    const bool dev_ok = c.gpu_rc.load() == 0 && gpu_inflate_slot_wait(gs) == 0;
+    b->gi.inflight[ci] = false;
+    if (wait) b->gi.wait_ns += ns_since(t_w);
+    if (!dev_ok) b->gi.broken = true;                                    // the device path stays off for the rest of this reader
+    else e->gpu_inflate_chunks++;
+    const int32_t* st = dev_ok ? gs->h_st : nullptr;
+    if (dev_ok) for (size_t i = 0; i < c.blocks.size(); i++) b->gi.left_blocks += st[i] != 0;
+    else b->gi.left_blocks += c.blocks.size();
+    cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
+    Chunk* cp = &c; const uint8_t* map = b->map; DecodeTimes* tmp_ = &b->tm; const bool want_seq = e->dec.want_seq;
+    for (WalkPart& wp : c.parts) { WalkPart* wpp = &wp; c.tg.later([cp, map, wpp, tmp_, cm, want_seq, st] { run_part(cp, map, false, wpp, tmp_, cm, want_seq, st); }); }
+    c.tg.flush(*b->pool, true);                                          // (ahead of the later chunks' inflate tasks)
+    c.stage2 = true;
+}
+
 static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
     const bool crc = e->dec.verify_crc;
     const int n_refs = (int)b->ref_names.size();
@@ -1156,26 +1184,13 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         if (!b->use_ranges && !b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
         return 0;
     }
+    if (b->gi.on) for (int k = 1; k < b->n_sched; k++) start_stage_two(e, b, (b->head + k) % b->n_ring, cm, false);   // device chunks that are back already: walk them now
     Chunk& c = b->ch[b->head];
     cm.only_tid = b->per_tid_ranges && (size_t)c.range_id < b->range_tid.size() ? b->range_tid[c.range_id] : -1;
     c.tg.wait();
     if (const int th = c.tg.take_thrown()) { b->err = th == 1 ? "out of host memory (BGZF inflate / record walk)" : "C++ exception in a decoder task"; return th == 1 ? XCK_E_NOMEM : XCK_E_IO; }
-    if (c.gpu && c.valid && !c.failed && !(b->skip_range >= 0 && c.range_id == b->skip_range)) {
-        // the device's part is over (or never started): whatever it did not inflate - single blocks with a non-zero status, or the
-        // whole chunk after a runtime error - the pool inflates now, and every part walks its records as on the host path
-        GpuInflateSlot* gs = b->gi.slot[b->head];
-        const auto t_w = std::chrono::steady_clock::now();
-        bool dev_ok = c.gpu_rc.load() == 0 && gpu_inflate_slot_wait(gs) == 0;
-        b->gi.inflight[b->head] = false;
-        b->gi.wait_ns += ns_since(t_w);
-        if (!dev_ok) b->gi.broken = true;                                 // the device path stays off for the rest of this reader
-        else e->gpu_inflate_chunks++;
-        const int32_t* st = dev_ok ? gs->h_st : nullptr;
-        if (dev_ok) for (size_t i = 0; i < c.blocks.size(); i++) b->gi.left_blocks += st[i] != 0;
-        else b->gi.left_blocks += c.blocks.size();
-        Chunk* cp = &c; const uint8_t* map = b->map; DecodeTimes* tmp_ = &b->tm; const bool want_seq = e->dec.want_seq;
-        for (WalkPart& wp : c.parts) { WalkPart* wpp = &wp; c.tg.later([cp, map, wpp, tmp_, cm, want_seq, st] { run_part(cp, map, false, wpp, tmp_, cm, want_seq, st); }); }
-        c.tg.flush(*b->pool, true);                                       // (ahead of the later chunks' inflate tasks)
+    if (c.gpu && !c.stage2) {
+        start_stage_two(e, b, b->head, cm, true);
         c.tg.wait();
         if (const int th = c.tg.take_thrown()) { b->err = th == 1 ? "out of host memory (BGZF inflate / record walk)" : "C++ exception in a decoder task"; return th == 1 ? XCK_E_NOMEM : XCK_E_IO; }
     }
