@@ -1,6 +1,9 @@
 // Host-only AddressSanitizer / UBSan harness for the BAM decoder (csrc/bam.cpp + csrc/api.cpp): the device side is
 // stubbed out, the handle is a decode-only one.  Every file given on the command line is opened and decoded to the
 // end in both modes (with and without sequences); corrupt input has to end in an error code, never in a bad access.
+// Each decode runs twice: batch by batch (xck_bam_next_batch: parse in place) and through xck_ingest_bam in slices with a
+// stand-in for engine_push_block - the path a GPU-backed handle takes (parse of a chunk and its push behind the coordinator
+// on the push thread, csrc/bam.cpp IngestJob / Pusher); both must see the same records, field for field.
 //   make -C tools/asan && tools/asan/decoder_asan FILE.bam...
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +34,22 @@ bool gpu_inflate_slot_reserve(GpuInflateSlot*, size_t, size_t, size_t) { return 
 int  gpu_inflate_slot_launch(GpuInflateSlot*, size_t, size_t, size_t) { return -1; }
 int  gpu_inflate_slot_wait(GpuInflateSlot*) { return -1; }
 bool gpu_inflate_slot_done(GpuInflateSlot*) { return true; }
-int  engine_push_block(xck_engine*, const void*, size_t, const xck_batch*, int, void**) { return XCK_E_ARG; }
+// stand-in for the engine's block push (called on the decoder's push thread): touches everything the batches claim to own
+static unsigned long long g_push_sum = 0; static long g_push_recs = 0;
+static unsigned long long batch_sum(const xck_batch& bt) {
+    unsigned long long s = 0;
+    for (int64_t i = 0; i < bt.n_reads; i++) s += (unsigned)bt.pos[i] + bt.flag[i] + bt.mapq[i] + (unsigned)bt.cell[i] + bt.umi[i] + (bt.cig_off[i] - bt.cig_off[0]);
+    if (bt.n_reads) { for (uint32_t c = bt.cig_off[0]; c < bt.cig_off[bt.n_reads]; c++) s += bt.cigar[c];
+                      if (bt.seq) for (uint32_t q = bt.seq_off[0]; q < bt.seq_off[bt.n_reads]; q++) s += bt.seq[q]; }
+    return s + (unsigned long long)bt.contig * 1000003ull + bt.ordinal_base;
+}
+int  engine_push_block(xck_engine*, const void* base, size_t bytes, const xck_batch* bts, int n, void**) {
+    for (int i = 0; i < n; i++) {
+        if (bts[i].n_reads > 0 && ((const char*)bts[i].pos < (const char*)base || (const char*)(bts[i].pos + bts[i].n_reads) > (const char*)base + bytes)) return XCK_E_ARG;
+        g_push_sum += batch_sum(bts[i]); g_push_recs += bts[i].n_reads;
+    }
+    return XCK_OK;
+}
 void engine_release_staging(xck_engine*) {}
 void fence_wait(void*) {}
 void fence_destroy(void*) {}
@@ -76,16 +94,27 @@ int main(int argc, char** argv) {
                     o.use_index = getenv("XCK_ASAN_INDEX") ? 1 : 0;          // PATH.bai is untrusted input as well
                     if (o.use_index) for (int t = 1; t < nref; t += 2) t2c[t] = -1;
                     xck_batch bt;
+                    unsigned long long sum_pull = 0; long recs_pull = 0;
                     while ((rc = xck_bam_next_batch(e, b, &o, &bt)) > 0) {
-                        recs += bt.n_reads;
-                        // touch everything the batch claims to own
-                        unsigned long long s = 0;
-                        for (int64_t i = 0; i < bt.n_reads; i++) s += (unsigned)bt.pos[i] + bt.flag[i] + bt.mapq[i] + (unsigned)bt.cell[i] + bt.umi[i] + bt.cig_off[i];
-                        if (bt.n_reads) { for (uint32_t c = bt.cig_off[0]; c < bt.cig_off[bt.n_reads]; c++) s += bt.cigar[c];
-                                          if (bt.seq) for (uint32_t q = bt.seq_off[0]; q < bt.seq_off[bt.n_reads]; q++) s += bt.seq[q]; }
-                        if (s == 0x123456789abcull) puts("");
+                        recs += bt.n_reads; recs_pull += bt.n_reads;
+                        sum_pull += xck::batch_sum(bt);                  // touches everything the batch claims to own
                     }
                     xck_bam_close(b);
+                    // the same file through xck_ingest_bam in slices, as a GPU-backed handle would take it (the stand-in above receives the chunks)
+                    b = nullptr;
+                    if (xck_bam_open(argv[a], threads, &b, err, sizeof err) == 0) {
+                        xck::g_push_sum = 0; xck::g_push_recs = 0;
+                        e->n_impl = 1;                                   // (no engine behind it: engine_push_block is the stand-in)
+                        o.pause_records = 3000;
+                        int64_t n = 0; int rc2;
+                        while ((rc2 = xck_ingest_bam(e, b, &o, &n)) == 1) {}
+                        e->n_impl = 0;
+                        xck_bam_close(b);
+                        if ((rc2 == 0) != (rc == 0) || (rc == 0 && (xck::g_push_recs != recs_pull || xck::g_push_sum != sum_pull))) {
+                            fprintf(stderr, "%s: pull decode rc %d, %ld records, sum %llx - ingest rc %d, %ld records, sum %llx\n", argv[a], rc, recs_pull, sum_pull, rc2, xck::g_push_recs, xck::g_push_sum);
+                            return 3;
+                        }
+                    }
                 }
                 (rc == 0 ? ok : bad)++;
                 xck_destroy(e);
