@@ -144,3 +144,71 @@ def test_damaged_file_ends_the_ingest_with_an_error_and_the_handle_lives_on(knob
                 assert np.array_equal(np.array(b), a), k
     finally:
         eng.close()
+
+
+def _bgzf_block(payload, level=6, strategy=None, flushes=()):
+    """One BGZF block around a raw DEFLATE stream made by zlib with the given level / strategy; `flushes` = offsets at which the
+    stream is flushed (Z_FULL_FLUSH: an empty stored block in the middle of the stream, then a new block)."""
+    import struct
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY if strategy is None else strategy)
+    out, at = b"", 0
+    for f in list(flushes) + [len(payload)]:
+        out += co.compress(payload[at:f])
+        if f < len(payload):
+            out += co.flush(zlib.Z_FULL_FLUSH)
+        at = f
+    out += co.flush()
+    assert len(out) + 26 <= 65536, len(out)
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(out) + 25) + out
+            + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
+
+
+def test_device_decoder_on_crafted_streams(tmp_path):
+    """csrc/inflate_dev.hip against zlib on streams the synthetic BAMs do not hold: stored blocks (incompressible bytes, level 0),
+    fixed-Huffman blocks, Huffman-only and run-length streams, several DEFLATE blocks per BGZF block with empty stored blocks between
+    them, distance-1 and short-period overlapping matches of the maximum length, code lengths up to 15 bits, empty and tiny blocks -
+    for the default kernel and both LDS-ring variants.  Every block must equal zlib's output or be left to the host (status != 0);
+    none may be wrong, and no more than a handful may be left."""
+    import zlib
+    exe = os.path.join(ROOT, "xcltk_amd", "csrc", "xck_gpu_inflate_check")
+    assert os.path.isfile(exe), "built by __graft_entry__.build() / make -C xcltk_amd/csrc"
+    rng = np.random.default_rng(5)
+    blocks = []
+    def add(payload, **kw):
+        blocks.append(_bgzf_block(bytes(payload), **kw))
+    add(b"")                                                          # the BGZF end-of-file block: a fixed-Huffman block holding only end-of-block
+    add(b"A"); add(b"AC"); add(b"ACG" * 5)
+    rnd = rng.integers(0, 256, 60000, dtype=np.uint8).tobytes()
+    add(rnd); add(rnd, level=0); add(rnd[:40000], flushes=(1, 2, 1000, 20000))   # stored blocks, also in the middle of a stream
+    add(bytes(65000))                                                 # zeros: distance 1, length 258, over and over
+    for period in (1, 2, 3, 5, 7, 13, 64, 255, 256, 257, 258, 259, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 32767, 32768):
+        unit = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+        add((unit * (65000 // period + 1))[:65000])
+        add((unit * (65000 // period + 1))[:65000], strategy=zlib.Z_RLE)
+    alphabet = np.frombuffer(b"ACGTN\n\t!#IF:,0123456789abcdefXYZxyz-_=+*", dtype=np.uint8)
+    w = np.array([2.0 ** -min(i, 20) for i in range(len(alphabet))])
+    text = bytes(rng.choice(alphabet, 64000, p=w / w.sum()))
+    for kw in (dict(), dict(level=1), dict(level=9), dict(strategy=zlib.Z_FIXED), dict(strategy=zlib.Z_HUFFMAN_ONLY), dict(strategy=zlib.Z_FILTERED),
+               dict(flushes=(10, 11, 5000, 5001, 30000))):
+        add(text, **kw)
+    # code lengths up to 15 bits: symbol frequencies that fall like Fibonacci numbers (Huffman-only: the literal code alone decides)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    skew = np.concatenate([np.full(f, i, dtype=np.uint8) for i, f in enumerate(fib)])
+    skew = np.concatenate([skew, np.arange(24, 256, dtype=np.uint8)])[:64000]
+    rng.shuffle(skew)
+    add(skew.tobytes(), strategy=zlib.Z_HUFFMAN_ONLY); add(skew.tobytes(), level=9)
+    # many blocks of BAM-like records at every level
+    rec = b"".join(b"%04d\0read%06d\0" % (i % 7919, i) + bytes(rng.integers(0, 4, 40, dtype=np.uint8)) + b"IIIIFFFF" * 6 + b"CBZACGTACGTACGTACGT-1\0UBZACGTACGTAC\0" for i in range(500))
+    for lvl in range(0, 10):
+        add(rec[: 60000], level=lvl)
+    fn = os.path.join(str(tmp_path), "crafted.bgzf")
+    open(fn, "wb").write(b"".join(blocks))
+    for variant in ("0", "1", "2"):
+        r = subprocess.run([exe, fn], env=dict(os.environ, INFLATE_VARIANT=variant), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
+        line = [l for l in r.stdout.splitlines() if l.startswith("verified against zlib")]
+        assert r.returncode == 0 and line, r.stdout[-2000:]
+        wrong, left = int(line[0].split(":")[1].split()[0]), int(line[0].split("wrong,")[1].split()[0])
+        assert "%d blocks" % len(blocks) in r.stdout and wrong == 0 and left <= 4, (variant, line[0])
