@@ -380,6 +380,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))
     gather_device = "cpu" if shared_gpu else device
+    if shared_gpu and world > 1:
+        os.environ.setdefault("XCK_GPU_INFLATE", "0")      # (ranks sharing a GPU keep the inflate on the host: fc_common.Dist has the reason)
 
     def barrier():
         torch.cuda.synchronize()

@@ -379,6 +379,16 @@ class Dist(object):
             if self.backend == "nccl":
                 self.device = "cuda:%d" % self.local_rank
             self.sharded_output = os.environ.get("XCK_DIST_GATHER", "0") in ("", "0")
+            # Ranks that SHARE a GPU (fewer devices than ranks on this node: test rehearsals, oversubscribed nodes) keep the BGZF inflate on the
+            # host: the device decoder's launches run for tens of milliseconds, and the GPU time-slices between processes at that grain - the
+            # other rank's join kernels then wait behind them (measured on one GPU with two ranks: 40 M reads/s host-only, 4.8 M with the
+            # device share).  One GPU per rank - the deployment - is not affected.  (The engine reads the knob at xck_create.)
+            try:
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+                if self.world > 1 and torch.cuda.device_count() < local_world:
+                    os.environ.setdefault("XCK_GPU_INFLATE", "0")
+            except Exception:
+                pass
 
     @property
     def active(self):
