@@ -396,6 +396,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING > 0 ? 3
                 uint64_t mm = starts & __ballot(kind == 1);
                 if constexpr (RING == 0) { if (starts & ~mm) dirty_lo = min(dirty_lo, op); }
                 XCK_PROF_AT(5);
+                if constexpr (RING == 0) {
+                    // All matches of the round in ONE load / store pair, lane j taking the j-th matched byte - when they fit 64 bytes and none
+                    // reads what an earlier match of the same round writes (the usual case: a round makes 30 - 60 bytes and a BAM record's
+                    // matches reach back a record or more).  The scalar loop over the matches only hands out (source, destination) per lane;
+                    // the memory round trip - and the fence, if any source was stored since the last one - is paid once per round instead of
+                    // once per match (matches were 44 - 48 % of a round on zlib-6 / Cell Ranger-shaped streams, r04_phase_clocks_4hop.txt).
+                    if (mm) {
+                        const bool is_m = is_start && kind == 1;
+                        const uint32_t minc = wave_scan_incl(is_m ? mlen : 0u);
+                        const uint32_t mtot = (uint32_t)__builtin_amdgcn_readlane((int)minc, 63);
+                        const uint32_t first_dst = (uint32_t)__builtin_amdgcn_readlane((int)off, __builtin_ctzll(mm));
+                        const uint32_t src_lo = off - mdist, src_hi = src_lo + min(mlen, mdist);
+                        const bool bad = is_m && mdist > off - A_out;
+                        const bool dep = is_m && off != first_dst && src_hi > first_dst;        // reads bytes an earlier match of this round makes
+                        if (__ballot(bad)) { err = 33; break; }
+                        if (mtot <= 64 && !__ballot(dep)) {
+                            const bool need_fence = __ballot(is_m && src_hi > dirty_lo) != 0;
+                            uint32_t my_src = 0, my_dst = 0; bool act = false;
+                            for (uint64_t m2 = mm; m2; m2 &= m2 - 1) {
+                                const int l = __builtin_ctzll(m2);
+                                const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, l), md = (uint32_t)__builtin_amdgcn_readlane((int)mdist, l);
+                                const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)off, l), mo = (uint32_t)__builtin_amdgcn_readlane((int)minc, l) - ml;
+                                const uint32_t t = (uint32_t)lane - mo;
+                                if (t < ml) { act = true; my_dst = dst + t; my_src = dst - md + (md >= ml ? t : t % md); }   // (overlapping: the pattern repeats)
+                            }
+                            if (need_fence) { __threadfence_block(); dirty_lo = 0xffffffffu; }   // a source was stored since the last fence
+                            uint8_t bv = 0;
+                            if (act) bv = o0v[my_src];
+                            if (act) o0v[my_dst] = bv;
+                            dirty_lo = min(dirty_lo, first_dst);
+                            mm = 0;
+                        }
+                    }
+                }
                 while (mm) {
                     const int l = __builtin_ctzll(mm); mm &= mm - 1;
                     const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, l), md = (uint32_t)__builtin_amdgcn_readlane((int)mdist, l);
