@@ -30,7 +30,7 @@
  *   XCK_PUSH_STAGE=0|1, XCK_PUSH_STAGE_BYTES   xck_push_batch: packed one-copy form always / never / below this size (default 2 MB)
  *   XCK_GPU_INFLATE=auto|<percent>|0      share of the BGZF chunks that xck_ingest_bam inflates on the handle's GPU (csrc/inflate_dev.hip; record walk and
  *                                         parse stay on the host).  auto (the default): files of at least XCK_GPU_INFLATE_MIN_MB (96) compressed MB keep
- *                                         XCK_GPU_INFLATE_DEPTH (8) chunks on the device and leave the rest to the host pool, XCK_GPU_INFLATE_RING (12)
+ *                                         XCK_GPU_INFLATE_DEPTH (10) chunks on the device and leave the rest to the host pool, XCK_GPU_INFLATE_RING (12)
  *                                         chunks in flight in all; <percent>: a fixed share; 0 = host only.  XCK_GPU_INFLATE_FREE_CUS (32): CUs the
  *                                         inflate streams never use.  XCK_GPU_INFLATE_LDS_RING=0|1|2: the kernel keeps its last 0 / 4 / 8 KB of output
  *                                         in LDS (default 0: more waves per CU).  Bit-identical results either way (a block the kernel does not finish, and every

@@ -54,7 +54,7 @@ Knobs xck::Knobs::from_env() {
     k.push_stage = (int)num("XCK_PUSH_STAGE", -1);
     k.push_stage_bytes = num("XCK_PUSH_STAGE_BYTES", 2ll << 20);
     k.gpu_inflate_pct = (!*str("XCK_GPU_INFLATE") || !strcmp(str("XCK_GPU_INFLATE"), "auto")) ? -1 : (int)std::max(0ll, std::min(100ll, num("XCK_GPU_INFLATE", 0)));
-    k.gpu_inflate_depth = (int)std::max(1ll, std::min(10ll, num("XCK_GPU_INFLATE_DEPTH", 8)));
+    k.gpu_inflate_depth = (int)std::max(1ll, std::min(10ll, num("XCK_GPU_INFLATE_DEPTH", 10)));
     k.gpu_inflate_ring = (int)num("XCK_GPU_INFLATE_RING", 12);
     k.gpu_inflate_min_mb = (int)std::max(0ll, num("XCK_GPU_INFLATE_MIN_MB", 96));
     k.gpu_inflate_free_cus = (int)num("XCK_GPU_INFLATE_FREE_CUS", 32);

@@ -1157,7 +1157,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             uint64_t span = b->fsize;
             if (b->use_ranges) { span = 0; for (auto& r : b->ranges) span += (r.second >> 16) - (r.first >> 16); }
             const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20;
-            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = b->gi.depth + 4; b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; xck::dev_inflate_set_variant(e->knobs.gpu_inflate_lds_ring); b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
+            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = std::min(b->gi.depth + 2, 12); b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; xck::dev_inflate_set_variant(e->knobs.gpu_inflate_lds_ring); b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
         }
         bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
         std::vector<ScanRange> rg;

@@ -107,7 +107,7 @@ struct Knobs {
     int  push_stage = -1;                // XCK_PUSH_STAGE (-1 = by size)
     long long push_stage_bytes = 2 << 20;   // XCK_PUSH_STAGE_BYTES
     int  gpu_inflate_pct = -1;           // XCK_GPU_INFLATE: share (percent) of the BGZF chunks inflated on the handle's GPU; -1 = auto (keep gpu_inflate_depth chunks on the device)
-    int  gpu_inflate_depth = 8;          // XCK_GPU_INFLATE_DEPTH
+    int  gpu_inflate_depth = 10;         // XCK_GPU_INFLATE_DEPTH
     int  gpu_inflate_ring = 12;          // XCK_GPU_INFLATE_RING: chunks in flight (host + device) while the GPU share is on
     int  gpu_inflate_min_mb = 96;        // XCK_GPU_INFLATE_MIN_MB: auto mode only for files (index ranges) of at least this many compressed MB
     int  gpu_inflate_lds_ring = 0;       // XCK_GPU_INFLATE_LDS_RING: 0 = the device decoder keeps its output in global memory only (15 waves per CU), 1 = + a 4 KB LDS ring of the last bytes (10 waves), 2 = 8 KB
