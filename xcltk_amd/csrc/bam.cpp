@@ -799,6 +799,9 @@ static void run_part(Chunk* cp, const uint8_t* map, bool verify_crc, WalkPart* w
         uint32_t bs = le32(u + o);
         if (bs < 32 || o + 4 + (size_t)bs > end) break;
         const uint8_t* r = u + o + 4;
+        // (a device chunk's bytes come from the GPU, not from this core's inflate: the hop from header to header is a chain of cache
+        // misses unless the lines a few records ahead are asked for early)
+        __builtin_prefetch(r + bs + 768); __builtin_prefetch(r + bs + 1280);
         const RecRef rr{r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)};
         const int32_t ctg = cm(rr.tid, (int32_t)le32(r + 4));
         if (ctg != cur_c) { wpp->runs.push_back({(uint32_t)wpp->recs.size(), ctg}); cur_c = ctg; }
@@ -1039,7 +1042,9 @@ static void parse_part(xck_bam* b, xck_engine* e, HostSoA* sp, int32_t sample, c
     std::vector<InternTable::Item> names;
     if (!dc.use_umi) names.reserve(wp->n_out);
     int64_t o = (int64_t)wp->out_base; uint32_t co = (uint32_t)wp->cig_base, so = (uint32_t)wp->seq_base;
+    const RecRef* const rend = wp->recs.data() + wp->recs.size();
     for (const RecRef& rr : wp->recs) {
+        if (&rr + 3 < rend) { const RecRef& nx = (&rr)[3]; __builtin_prefetch(nx.p); __builtin_prefetch(nx.p + 64); __builtin_prefetch(nx.p + nx.len - 64); __builtin_prefetch(nx.p + nx.len - 128); }
         const int32_t ctg = cm(rr.tid, (int32_t)le32(rr.p + 4));
         if (ctg < 0) continue;
         s.cig_off[o] = co; s.seq_off[o] = so;
