@@ -801,7 +801,7 @@ static void run_part(Chunk* cp, const uint8_t* map, bool verify_crc, WalkPart* w
         const uint8_t* r = u + o + 4;
         // (a device chunk's bytes come from the GPU, not from this core's inflate: the hop from header to header is a chain of cache
         // misses unless the lines a few records ahead are asked for early)
-        __builtin_prefetch(r + bs + 768); __builtin_prefetch(r + bs + 1280);
+        { const uint8_t* pf = r + 4096; __builtin_prefetch(pf); __builtin_prefetch(pf + 64); __builtin_prefetch(pf + 128); __builtin_prefetch(pf + 192); }   // (every line of the stretch ~18 records ahead: a header may sit on any of them)
         const RecRef rr{r, bs, (int32_t)le32(r), le32(r + 16), le16(r + 12)};
         const int32_t ctg = cm(rr.tid, (int32_t)le32(r + 4));
         if (ctg != cur_c) { wpp->runs.push_back({(uint32_t)wpp->recs.size(), ctg}); cur_c = ctg; }
