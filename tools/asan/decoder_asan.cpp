@@ -28,7 +28,6 @@ int  engine_umi_bits(const xck_engine* e) { return e ? e->umi_bits : 0; }
 int  engine_numa_node(const xck_engine*) { return -1; }
 int  engine_device(const xck_engine*) { return -1; }                          // no device: the decoder's GPU share of the inflate never starts
 GpuInflateSlot* gpu_inflate_slot_create(int, int, bool) { return nullptr; }
-void dev_inflate_set_variant(int) {}
 void gpu_inflate_slot_destroy(GpuInflateSlot*) {}
 bool gpu_inflate_slot_reserve(GpuInflateSlot*, size_t, size_t, size_t) { return false; }
 int  gpu_inflate_slot_launch(GpuInflateSlot*, size_t, size_t, size_t) { return -1; }

@@ -1,6 +1,6 @@
 // gpu_inflate_bench.hip - correctness + throughput of csrc/inflate_dev.hip against zlib on the BGZF blocks of a BAM.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ixcltk_amd/csrc tools/gpu_inflate_bench.hip xcltk_amd/csrc/inflate_dev.hip -lz -o tools/scratch/gpu_inflate_bench
-//   [INFLATE_VARIANT=0|1] tools/scratch/gpu_inflate_bench FILE.bam [max_bytes [blocks_per_launch]]     (variant: see dev_inflate_set_variant)
+//   [INFLATE_VARIANT=0|1] tools/scratch/gpu_inflate_bench FILE.bam [max_bytes [blocks_per_launch]]     (variant: see dev_inflate_launch)
 #include <zlib.h>
 #include <chrono>
 #include <cstdio>
@@ -12,7 +12,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
-    if (getenv("INFLATE_VARIANT")) xck::dev_inflate_set_variant(atoi(getenv("INFLATE_VARIANT")));
+    const int variant = getenv("INFLATE_VARIANT") ? atoi(getenv("INFLATE_VARIANT")) : 0;
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror("open"); return 1; }
     size_t maxb = argc > 2 ? strtoull(argv[2], nullptr, 10) : (size_t)2 << 30;
     std::vector<uint8_t> d(maxb); size_t n = fread(d.data(), 1, maxb, f); fclose(f);
@@ -32,10 +32,10 @@ int main(int argc, char** argv) {
         // chunks of 740 blocks like the ingest would launch them
         const int per = argc > 3 ? atoi(argv[3]) : (int)bl.size();
         for (size_t b0 = 0; b0 < bl.size(); b0 += per) { int nb = (int)std::min<size_t>(per, bl.size() - b0);
-            if (xck::dev_inflate_launch(s, d_in, d_bl + b0, nb, d_out, d_st + b0)) { fprintf(stderr, "launch failed\n"); return 1; } }
+            if (xck::dev_inflate_launch(s, d_in, d_bl + b0, nb, d_out, d_st + b0, nullptr, variant)) { fprintf(stderr, "launch failed\n"); return 1; } }
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (getenv("INFLATE_VARIANT") && atoi(getenv("INFLATE_VARIANT")) >= 10) { unsigned long long pr[8]; xck::dev_inflate_read_prof(pr); double t = 0; for (int k = 0; k < 8; k++) t += (double)pr[k];
+        if (variant >= 10) { unsigned long long pr[8]; xck::dev_inflate_read_prof(pr); double t = 0; for (int k = 0; k < 8; k++) t += (double)pr[k];
             static const char* nm[8] = {"header", "tables", "window", "decode", "walk", "scan+literals", "matches", "flush+rest"};
             printf("  wave cycles per block %.0f:", t / bl.size()); for (int k = 0; k < 8; k++) printf(" %s %.1f%%", nm[k], 100.0 * pr[k] / t); printf("\n"); }
         printf("rep %d: %.2f ms  = %.1f GB/s inflated, %.1f GB/s compressed\n", rep, ms, tot / ms / 1e6, o / ms / 1e6);

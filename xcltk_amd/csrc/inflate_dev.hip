@@ -491,8 +491,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING > 0 ? 3
     }
 }
 
-static int g_inflate_variant = 0;
-void dev_inflate_set_variant(int v) { g_inflate_variant = v; }
 
 // PROF variants (10, 11): the per-phase cycle sums since the last call (and zeroes them)
 void dev_inflate_read_prof(unsigned long long out[8]) {
@@ -500,10 +498,10 @@ void dev_inflate_read_prof(unsigned long long out[8]) {
     unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(d_prof), z, sizeof z);
 }
 
-int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status, uint8_t* host_out) {
+int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status, uint8_t* host_out, int variant) {
     if (n_blocks <= 0) return 0;
     const dim3 g((unsigned)n_blocks), t(64);
-    switch (g_inflate_variant) {
+    switch (variant) {
         case 0:  hipLaunchKernelGGL((k_inflate<0, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
         case 2:  hipLaunchKernelGGL((k_inflate<8192, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
         case 10: hipLaunchKernelGGL((k_inflate<0, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
@@ -579,7 +577,7 @@ int gpu_inflate_slot_launch(GpuInflateSlot* s, size_t in_bytes, size_t out_bytes
     if (hipSetDevice(s->device) != hipSuccess) return -1;
     for (size_t i = 0; i < n_blocks; i++) s->h_st[i] = -1;                  // (a block the kernel never reaches is left to the host)
     (void)out_bytes;
-    if (dev_inflate_launch(s->stream, s->a_in, s->a_bl, (int)n_blocks, s->d_out, s->a_st, s->a_out) != 0) { (void)hipGetLastError(); return -1; }
+    if (dev_inflate_launch(s->stream, s->a_in, s->a_bl, (int)n_blocks, s->d_out, s->a_st, s->a_out, s->variant) != 0) { (void)hipGetLastError(); return -1; }
     if (hipEventRecord(s->done, s->stream) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return 0;
 }
