@@ -32,8 +32,7 @@
  *                                         parse stay on the host).  auto (the default): files of at least XCK_GPU_INFLATE_MIN_MB (96) compressed MB keep
  *                                         XCK_GPU_INFLATE_DEPTH (10) chunks on the device and leave the rest to the host pool, XCK_GPU_INFLATE_RING (12)
  *                                         chunks in flight in all; <percent>: a fixed share; 0 = host only.  XCK_GPU_INFLATE_FREE_CUS (32): CUs the
- *                                         inflate streams never use.  XCK_GPU_INFLATE_LDS_RING=0|1|2: the kernel keeps its last 0 / 4 / 8 KB of output
- *                                         in LDS (default 0: more waves per CU).  Bit-identical results either way (a block the kernel does not finish, and every
+ *                                         inflate streams never use.  Bit-identical results either way (a block the kernel does not finish, and every
  *                                         chunk after a runtime error, is inflated by the host); off for handles without a device and with XCK_F_VERIFY_CRC.
  * Decoder (read when a BAM is opened or once per process): XCK_THREADS, XCK_NUMA=0, XCK_INFLATE=zlib, XCK_CHUNK_BYTES,
  * XCK_WRITE_THREADS (writer threads of xck_write_mtx), XCK_TEST_INTERN_LIMIT (tests). */

@@ -156,23 +156,29 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
     return x;
 }
 
-// Output bytes go straight to global memory and a match reads them back from there (behind a fence when they were stored since the
-// last one).  (A variant that kept the last 4 / 8 KB in an LDS ring - near matches as LDS-to-LDS copies, aligned 1 KB flushes - cost a
-// third of the occupancy and measured equal or slower: profiles/experiments/gpu_inflate/inflate_dev_with_lds_ring.hip.)
+// RING = 0: output bytes go straight to global memory and a match reads them back from there (behind a fence when they were stored
+// since the last one).  RING > 0: the last RING output bytes live in an LDS ring; a match whose source lies inside it - most do, the
+// record before this one is 230 - 450 bytes back - is an LDS-to-LDS copy without any global round trip; the ring is written out in
+// 1 KB segments of aligned 16-byte stores as soon as every byte of a segment is final, and only a match that reaches further back
+// than the ring loads from global memory (from segments that were stored - and, on first use, waited for - long before).
 __device__ unsigned long long d_prof[8];          // PROF builds only (tools/gpu_inflate_bench): cycles of wave-time per phase, summed over the blocks
 #define XCK_PROF_AT(k) do { if constexpr (PROF) { const long long t_ = clock64(); prof[k] += (unsigned long long)(t_ - t_prev); t_prev = t_; } } while (0)
 
-template <bool PROF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_inflate(const uint8_t* __restrict__ in, const DevBlock* __restrict__ blocks, int n_blocks,
+template <int RING, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING > 0 ? 3 : 4, 8))) void k_inflate(const uint8_t* __restrict__ in, const DevBlock* __restrict__ blocks, int n_blocks,
                                                 uint8_t* out, int32_t* __restrict__ status, uint8_t* host_out) {
     __shared__ Smem sm;
     __shared__ uint32_t win[IN_WIN / 4];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[RING > 0 ? RING : 16];
+    constexpr uint32_t RM = RING > 0 ? (uint32_t)RING - 1 : 0, SEG = 1024, CAP = 1024;    // CAP: output bytes per round (bounds what a round may evict from the ring)
+    static_assert(RING == 0 || (RING >= 4096 && (RING & (RING - 1)) == 0), "ring: a power of two >= 4096 (far matches must find their bytes flushed)");
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_blocks) return;
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long t_prev = PROF ? clock64() : 0;   // 0 header, 1 tables, 2 window, 3 decode, 4 walk, 5 scan + literals, 6 matches, 7 flush / rest
     const DevBlock blk = blocks[b];
-    uint8_t* const o0v = out + blk.out_off;                            // the block's output
-    const uint32_t out_end = blk.out_len;
+    const uint32_t A_out = RING > 0 ? (uint32_t)((uintptr_t)(out + blk.out_off) & 15u) : 0u;
+    uint8_t* const o0v = out + blk.out_off - A_out;                    // byte p of the block's output sits at o0v[A_out + p]
+    const uint32_t out_end = A_out + blk.out_len;
     if (blk.out_len == 0) { if (lane == 0) status[b] = 0; return; }
     const uint8_t* const sp = in + blk.in_off;
     const uint32_t A = (uint32_t)((uintptr_t)sp & 3u);
@@ -186,7 +192,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     BitIn bi; bi.pos = 0; bi.wlo = 0; bi.bb = 0; bi.bc = 0;            // (lane 0's state; the other lanes carry dead copies)
     fill(0);
     if (lane == 0) { bi.refill(win); bi.drop((int)(8 * A)); }          // skip the A bytes before the stream
-    uint32_t op = 0;                                                   // output position (wave-uniform)
+    uint32_t op = A_out;                                               // output position (wave-uniform), in coordinates of the 16-byte aligned base o0v
+    uint32_t flushed = 0;                                              // RING > 0: ring bytes below this position are in global memory (a multiple of SEG)
     int err = 0;
     for (;;) {
         // ---- block header (lane 0), broadcast; the window is moved first so that a whole header (< 400 bytes) fits ----
@@ -246,6 +253,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         btype = __builtin_amdgcn_readfirstlane(btype); bfinal = __builtin_amdgcn_readfirstlane(bfinal);
         hlit = __builtin_amdgcn_readfirstlane(hlit); hdist = __builtin_amdgcn_readfirstlane(hdist);
         __builtin_amdgcn_wave_barrier();
+        // RING > 0: every segment that ends at or below p is final -> global memory (the first one may start before the block's first byte)
+        auto flush_upto = [&](uint32_t p) {
+            if constexpr (RING > 0) {
+                while (flushed + SEG <= p) {
+                    if (flushed >= A_out) *(uint4*)(o0v + flushed + lane * 16) = *(const uint4*)&ring[(flushed & RM) + lane * 16];
+                    else for (uint32_t i = A_out + (uint32_t)lane; i < SEG; i += 64) o0v[i] = ring[i];
+                    flushed += SEG;
+                }
+            }
+        };
         XCK_PROF_AT(0);
         if (btype == 0) {                                              // stored block: lane 0 finds the byte position, the wave copies
             uint32_t len = 0, s_at = 0;
@@ -271,7 +288,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             if (err) break;
             len = __builtin_amdgcn_readfirstlane(len); s_at = __builtin_amdgcn_readfirstlane(s_at);
             const uint8_t* s0 = sp - A + s_at;
-            for (uint32_t i = lane; i < len; i += 64) o0v[op + i] = s0[i];
+            if constexpr (RING > 0) {
+                for (uint32_t done = 0; done < len;) {
+                    const uint32_t n = min(SEG, len - done);
+                    for (uint32_t i = lane; i < n; i += 64) ring[(op + done + i) & RM] = s0[done + i];
+                    done += n; flush_upto(op + done);
+                }
+            } else { for (uint32_t i = lane; i < len; i += 64) o0v[op + i] = s0[i]; }
             op += len;
             // re-prime the bit buffer for whatever follows the stored block
             { const uint32_t pos = __builtin_amdgcn_readfirstlane(bi.pos); fill(pos & ~3u); bi.wlo = pos & ~3u; }
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             // under profiles/experiments/gpu_inflate/; this loop is 2 - 2.9x faster on its own, r04_symbol_loop_ab.txt.)
             uint32_t bitpos = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bi.pos * 8u - (uint32_t)bi.bc));
             uint32_t wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi.wlo);
-            uint32_t dirty_lo = 0;                                     // lowest position stored since the last fence (0 = assume everything)
+            uint32_t dirty_lo = 0;                                     // RING == 0: lowest position stored since the last fence (0 = assume everything)
             bool eob = false;
             while (!eob) {
                 const uint32_t byte0 = bitpos >> 3;
@@ -325,9 +348,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const uint32_t packed = used | (kind << 6) | (olen << 8);
                 if constexpr (PROF) { asm volatile("" :: "v"(packed)); }
                 XCK_PROF_AT(3);
-                // the walk: which lanes start a symbol (scalar); a round ends after 64 offsets or at the end of the block
+                // the walk: which lanes start a symbol (scalar); a round ends after 64 offsets, at the end of the block, or (with the LDS
+                // ring) before the symbol that would take its output past CAP bytes
                 uint64_t starts = 0; uint32_t cur = 0, stop = 0, total = 0;
-                {
+                if constexpr (RING > 0) {
+                    while (cur < 64) {
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
+                        if (total + (p >> 8) > CAP && starts) break;
+                        starts |= 1ull << cur;
+                        total += p >> 8; cur += p & 63u;
+                        if (((p >> 6) & 3u) >= 2) { stop = (p >> 6) & 3u; break; }
+                    }
+                } else {
                     // ... four symbols per hop: every lane first learns, through two rounds of ds_bpermute, what a walk that STARTED at it would
                     // cross with its next four symbols (bits, output bytes, which lanes, whether it stops) - the scalar walk then needs
                     // three readlanes per four symbols instead of a readlane and two branches per symbol (the walk was 51 % of a round on the
@@ -360,11 +392,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const bool is_start = (starts >> lane) & 1;
                 olen = is_start ? olen : 0u;
                 const uint32_t off = op + wave_scan_incl(olen) - olen;  // where this lane's output goes
-                if (is_start && kind == 0) o0v[off] = (uint8_t)e;
+                if (is_start && kind == 0) { if constexpr (RING > 0) ring[off & RM] = (uint8_t)e; else o0v[off] = (uint8_t)e; }
                 uint64_t mm = starts & __ballot(kind == 1);
-                if (starts & ~mm) dirty_lo = min(dirty_lo, op);
+                if constexpr (RING == 0) { if (starts & ~mm) dirty_lo = min(dirty_lo, op); }
                 XCK_PROF_AT(5);
-                {
+                if constexpr (RING == 0) {
                     // All matches of the round in ONE load / store pair, lane j taking the j-th matched byte - when they fit 64 bytes and none
                     // reads what an earlier match of the same round writes (the usual case: a round makes 30 - 60 bytes and a BAM record's
                     // matches reach back a record or more).  The scalar loop over the matches only hands out (source, destination) per lane;
@@ -376,7 +408,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         const uint32_t mtot = (uint32_t)__builtin_amdgcn_readlane((int)minc, 63);
                         const uint32_t first_dst = (uint32_t)__builtin_amdgcn_readlane((int)off, __builtin_ctzll(mm));
                         const uint32_t src_lo = off - mdist, src_hi = src_lo + min(mlen, mdist);
-                        const bool bad = is_m && mdist > off;
+                        const bool bad = is_m && mdist > off - A_out;
                         const bool dep = is_m && off != first_dst && src_hi > first_dst;        // reads bytes an earlier match of this round makes
                         if (__ballot(bad)) { err = 33; break; }
                         if (mtot <= 64 && !__ballot(dep)) {
@@ -402,17 +434,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     const int l = __builtin_ctzll(mm); mm &= mm - 1;
                     const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, l), md = (uint32_t)__builtin_amdgcn_readlane((int)mdist, l);
                     const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)off, l);
-                    if (md > dst) { err = 33; break; }
-                    const uint32_t src_hi = dst - md + min(ml, md);
-                    if (src_hi > dirty_lo) { __threadfence_block(); dirty_lo = 0xffffffffu; }   // the bytes it reads were stored since the last fence
-                    const uint8_t* src = o0v + dst - md;
-                    if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) o0v[dst + i] = src[i]; }
-                    else { for (uint32_t i = lane; i < ml; i += 64) o0v[dst + i] = src[i % md]; }   // overlapping: the pattern repeats
-                    dirty_lo = min(dirty_lo, dst);
+                    if (md > dst - A_out) { err = 33; break; }
+                    if constexpr (RING > 0) {
+                        flush_upto(dst);                                   // everything below this match is final
+                        if (dst - md + (uint32_t)RING >= op + total) {     // its source stays in the ring until the round is over
+                            if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) ring[(dst + i) & RM] = ring[(dst - md + i) & RM]; }
+                            else { for (uint32_t i = lane; i < ml; i += 64) ring[(dst + i) & RM] = ring[(dst - md + i % md) & RM]; }   // overlapping: the pattern repeats
+                        } else {                                           // further back than the ring: those segments were flushed long ago (RING >= 4096, CAP)
+                            if (dst - md + ml > flushed) { err = 34; break; }
+                            __threadfence_block();                         // (waits for nothing unless a segment was stored just now)
+                            for (uint32_t i = lane; i < ml; i += 64) ring[(dst + i) & RM] = o0v[dst - md + i];
+                        }
+                    } else {
+                        const uint32_t src_hi = dst - md + min(ml, md);
+                        if (src_hi > dirty_lo) { __threadfence_block(); dirty_lo = 0xffffffffu; }   // the bytes it reads were stored since the last fence
+                        const uint8_t* src = o0v + dst - md;
+                        if (md >= ml) { for (uint32_t i = lane; i < ml; i += 64) o0v[dst + i] = src[i]; }
+                        else { for (uint32_t i = lane; i < ml; i += 64) o0v[dst + i] = src[i % md]; }
+                        dirty_lo = min(dirty_lo, dst);
+                    }
                 }
                 if (err) break;
                 XCK_PROF_AT(6);
                 op += total; bitpos += cur;
+                flush_upto(op);
                 XCK_PROF_AT(7);
             }
             if (err) break;
@@ -423,6 +468,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
         if (bfinal) break;
     }
+    if constexpr (RING > 0) { if (!err) for (uint32_t i = max(flushed, A_out) + (uint32_t)lane; i < op; i += 64) o0v[i] = ring[i & RM]; }   // the tail (and a block shorter than a segment)
     if constexpr (PROF) { XCK_PROF_AT(7); if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&d_prof[k], prof[k]); }
     {
         // consumed input must lie inside the stream (the window is zero beyond it: a truncated stream must not pass)
@@ -455,8 +501,13 @@ void dev_inflate_read_prof(unsigned long long out[8]) {
 int dev_inflate_launch(hipStream_t stream, const uint8_t* d_in, const DevBlock* d_blocks, int n_blocks, uint8_t* d_out, int32_t* d_status, uint8_t* host_out, int variant) {
     if (n_blocks <= 0) return 0;
     const dim3 g((unsigned)n_blocks), t(64);
-    if (variant >= 10) hipLaunchKernelGGL((k_inflate<true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out);
-    else hipLaunchKernelGGL((k_inflate<false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out);
+    switch (variant) {
+        case 0:  hipLaunchKernelGGL((k_inflate<0, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        case 2:  hipLaunchKernelGGL((k_inflate<8192, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        case 10: hipLaunchKernelGGL((k_inflate<0, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        case 11: hipLaunchKernelGGL((k_inflate<4096, true>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+        default: hipLaunchKernelGGL((k_inflate<4096, false>), g, t, 0, stream, d_in, d_blocks, n_blocks, d_out, d_status, host_out); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -15,7 +15,7 @@ from xcltk_amd.synth import soa
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = ("XCK_GPU_INFLATE", "XCK_GPU_INFLATE_DEPTH", "XCK_GPU_INFLATE_MIN_MB", "XCK_CHUNK_BYTES", "XCK_GPU_INFLATE_LDS_RING")
+KNOBS = ("XCK_GPU_INFLATE", "XCK_GPU_INFLATE_DEPTH", "XCK_GPU_INFLATE_MIN_MB", "XCK_CHUNK_BYTES")
 
 
 @pytest.fixture
@@ -68,14 +68,13 @@ def test_device_share_of_the_inflate_changes_nothing(level, knob_env, tmp_path):
     knob_env["XCK_GPU_INFLATE"] = "0"
     n0, host, st0 = _count(bam, regions, snps, names, bcs)
     assert n0 == 1500000 and st0["gpu_inflate_chunks"] == 0 and len(host["count"][0]) > 10000 and len(host["dp"][0]) > 100
-    # (the last two: the kernel's optional LDS ring of the last 4 / 8 KB of output, csrc/inflate_dev.hip)
-    for share, depth, ring in (("50", "4", "0"), ("auto", "3", "0"), ("100", "4", "0"), ("100", "4", "1"), ("50", "4", "2")):
-        knob_env["XCK_GPU_INFLATE"], knob_env["XCK_GPU_INFLATE_DEPTH"], knob_env["XCK_GPU_INFLATE_LDS_RING"] = share, depth, ring
+    for share, depth in (("50", "4"), ("auto", "3"), ("100", "4")):
+        knob_env["XCK_GPU_INFLATE"], knob_env["XCK_GPU_INFLATE_DEPTH"] = share, depth
         n1, dev, st1 = _count(bam, regions, snps, names, bcs, passes=2)
-        assert n1 == n0 and st1["gpu_inflate_chunks"] >= 5, (share, ring, st1["gpu_inflate_chunks"])
+        assert n1 == n0 and st1["gpu_inflate_chunks"] >= 5, (share, st1["gpu_inflate_chunks"])
         for k in host:
             for a, b in zip(host[k], dev[k]):
-                assert np.array_equal(a, b), (share, ring, k)
+                assert np.array_equal(a, b), (share, k)
     # CRC verification wanted: the inflate stays on the host (the device does not compute the checksum)
     knob_env["XCK_GPU_INFLATE"] = "50"
     n2, crc, st2 = _count(bam, regions, snps, names, bcs, flags=capi.XCK_F_VERIFY_CRC)
@@ -167,8 +166,8 @@ def _bgzf_block(payload, level=6, strategy=None, flushes=()):
 def test_device_decoder_on_crafted_streams(tmp_path):
     """csrc/inflate_dev.hip against zlib on streams the synthetic BAMs do not hold: stored blocks (incompressible bytes, level 0),
     fixed-Huffman blocks, Huffman-only and run-length streams, several DEFLATE blocks per BGZF block with empty stored blocks between
-    them, distance-1 and short-period overlapping matches of the maximum length, code lengths up to 15 bits, empty and tiny blocks -
-    for the default kernel and both LDS-ring variants.  Every block must equal zlib's output or be left to the host (status != 0);
+    them, distance-1 and short-period overlapping matches of the maximum length, code lengths up to 15 bits, empty and tiny blocks.
+    Every block must equal zlib's output or be left to the host (status != 0);
     none may be wrong, and no more than a handful may be left."""
     import zlib
     exe = os.path.join(ROOT, "xcltk_amd", "csrc", "xck_gpu_inflate_check")
@@ -206,7 +205,7 @@ def test_device_decoder_on_crafted_streams(tmp_path):
         add(rec[: 60000], level=lvl)
     fn = os.path.join(str(tmp_path), "crafted.bgzf")
     open(fn, "wb").write(b"".join(blocks))
-    for variant in ("0", "1", "2"):
+    for variant in ("0", "10"):                                       # (10: the same kernel with its phase clocks compiled in)
         r = subprocess.run([exe, fn], env=dict(os.environ, INFLATE_VARIANT=variant), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
         line = [l for l in r.stdout.splitlines() if l.startswith("verified against zlib")]
         assert r.returncode == 0 and line, r.stdout[-2000:]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-to-end A/B of decoder settings on the GPU box: every argument is one configuration - a quoted list of VAR=value pairs (or "base") -
 # and runs `bench.py` at a reduced size under it (headline file + the two side files, oracle check included); one line per run.
-#   usage: tools/ingest_sweep.sh OUTDIR READS "XCK_GPU_INFLATE=0" "XCK_GPU_INFLATE_DEPTH=6 XCK_GPU_INFLATE_LDS_RING=1" base ...
+#   usage: tools/ingest_sweep.sh OUTDIR READS "XCK_GPU_INFLATE=0" "XCK_GPU_INFLATE_DEPTH=6 XCK_GPU_INFLATE_FREE_CUS=16" base ...
 # (the sweeps behind profiles/experiments/gpu_inflate/README.md were made this way)
 out=$1; reads=$2; shift 2
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$REPO" || exit 1

@@ -58,7 +58,6 @@ Knobs xck::Knobs::from_env() {
     k.gpu_inflate_ring = (int)num("XCK_GPU_INFLATE_RING", 12);
     k.gpu_inflate_min_mb = (int)std::max(0ll, num("XCK_GPU_INFLATE_MIN_MB", 96));
     k.gpu_inflate_free_cus = (int)num("XCK_GPU_INFLATE_FREE_CUS", 32);
-    k.gpu_inflate_lds_ring = (int)num("XCK_GPU_INFLATE_LDS_RING", 0); if (k.gpu_inflate_lds_ring < 0 || k.gpu_inflate_lds_ring > 2) k.gpu_inflate_lds_ring = 0;
     return k;
 }
 

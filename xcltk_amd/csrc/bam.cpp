@@ -490,7 +490,6 @@ struct GpuShare {
     bool tried = false, on = false, broken = false, verbose = false; int pct = 0, acc = 0, device = -1, free_cus = 32, depth = 4;
     GpuInflateSlot* slot[N_CHUNK_GPU] = {nullptr}; bool inflight[N_CHUNK_GPU] = {false};   // slot[k]: the slot that holds ring chunk k (its inflated bytes live there until the chunk is consumed)
     std::vector<GpuInflateSlot*> free_slots;                             // slots of consumed chunks, reused before a new one is made
-    int variant = 0;                                                     // kernel form of this reader's launches (XCK_GPU_INFLATE_LDS_RING)
     int max_held = 10;                                                   // device chunks in the ring at a time (in flight + inflated, not yet consumed) = slots this reader ever holds
     uint64_t chunks = 0, blocks = 0, left_blocks = 0, wait_ns = 0, copy_ns = 0;
 };
@@ -845,7 +844,6 @@ static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const 
                 else gi.slot[ci] = take_gpu_slot(gi.device, gi.free_cus, gi.verbose && !gi.chunks);
             }
             gs = gi.slot[ci];
-            if (gs) gs->variant = gi.variant;
             if (gs && gi.inflight[ci]) { gpu_inflate_slot_wait(gs); gi.inflight[ci] = false; }   // (a chunk that was dropped unconsumed)
             if (!gs || !gpu_inflate_slot_reserve(gs, tin + 8, usz + 8, nb)) { gi.broken = true; gs = nullptr; }   // no device memory: the host does it all from here on
             else c.in_total = tin;
@@ -1164,7 +1162,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             uint64_t span = b->fsize;
             if (b->use_ranges) { span = 0; for (auto& r : b->ranges) span += (r.second >> 16) - (r.first >> 16); }
             const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20;
-            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = std::min(b->gi.depth + 2, 12); b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->gi.variant = e->knobs.gpu_inflate_lds_ring; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
+            if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = std::min(b->gi.depth + 2, 12); b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
         }
         bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
         std::vector<ScanRange> rg;

@@ -110,7 +110,6 @@ struct Knobs {
     int  gpu_inflate_depth = 10;         // XCK_GPU_INFLATE_DEPTH
     int  gpu_inflate_ring = 12;          // XCK_GPU_INFLATE_RING: chunks in flight (host + device) while the GPU share is on
     int  gpu_inflate_min_mb = 96;        // XCK_GPU_INFLATE_MIN_MB: auto mode only for files (index ranges) of at least this many compressed MB
-    int  gpu_inflate_lds_ring = 0;       // XCK_GPU_INFLATE_LDS_RING: 0 = the device decoder keeps its output in global memory only (15 waves per CU), 1 = + a 4 KB LDS ring of the last bytes (10 waves), 2 = 8 KB
     int  gpu_inflate_free_cus = 32;      // XCK_GPU_INFLATE_FREE_CUS: CUs the inflate streams never use (they stay free for the join kernels)
     static Knobs from_env();             // api.cpp
 };
