@@ -2,15 +2,20 @@
 //
 // Replaces, for the share of the chunks the host decoder hands over (csrc/bam.cpp, XCK_GPU_INFLATE), the inflate that pysam / htslib
 // do inside AlignmentFile.fetch (xcltk/rdr/fc/core.py:73-76, utils/sam.py:105-118); the record walk and the field parse stay on the host.
-// Why: end to end the engine is bound by the host's BGZF inflate (73 - 85 % of the ingest CPU time on 16 cores,
-// profiles/r02_d_ingest_*.log) while the GPU idles.  BGZF blocks are independent <= 64 KiB deflate streams, so a chunk of
-// ~750 blocks is 750 waves of work.  Inside a block DEFLATE is serial - symbol boundaries are only known after decoding the
-// previous symbol - so lane 0 runs the Huffman state machine and the OTHER 63 lanes do what is parallel:
-//   * decode tables are built by all lanes into LDS (10-bit primary + sub-tables; a code that needs more LDS than the block's
-//     budget marks the block "not done" and the host inflates it - the compressed bytes never left the host);
-//   * lane 0 decodes a run of literals into a 64-byte LDS buffer until it meets a match (or the buffer is full); the wave then
-//     stores the literals with ONE coalesced byte store and copies the match with one load + one store per 64 bytes:
-//     out[op + i] = out[op - dist + i % dist] reads only bytes that already exist, so overlapping matches need no serial loop.
+// Why: end to end the engine was bound by the host's BGZF inflate (73 - 85 % of the ingest CPU time on 16 cores,
+// profiles/r02_d_ingest_*.log) while the GPU idled.  BGZF blocks are independent <= 64 KiB deflate streams, so a chunk of
+// ~750 blocks is 750 waves of work.  Inside a block the SYMBOL BOUNDARIES are serial - they are only known after the previous
+// symbol - but what would be decoded at a given bit offset is not:
+//   * block headers and the code-length code: lane 0, serially (a few per cent of a block's time);
+//   * decode tables: built by all lanes into LDS (9-bit primary + sub-tables for literal / length, 8-bit for distance; a code that
+//     needs more LDS than the block's budget marks the block "not done" and the host inflates it - the compressed bytes never left
+//     the host);
+//   * symbols: 64 bit offsets per round - every lane decodes the code that would start at ITS offset, a scalar walk over the lanes'
+//     code lengths (four symbols per hop, prepared by two rounds of ds_bpermute) finds the offsets where symbols really start, those
+//     lanes store their literals at positions from a prefix sum, and the wave copies the matches
+//     (out[dst + i] = out[dst - dist + i % dist] reads only bytes that already exist, so overlapping matches need no serial loop);
+//   * the finished block goes to the chunk's pinned host block by the same wave (16-byte stores over PCIe).
+// Measured: DESIGN.md section 6, profiles/experiments/gpu_inflate/ (every step of the way, against zlib block by block).
 // Status per block: 0 = inflated (exactly isize bytes), non-zero = left to the host decoder (csrc/inflate_fast.h / zlib).
 #include <cstdint>
 #include <cstdio>
@@ -33,7 +38,6 @@ struct DHuff { uint16_t val; uint8_t len; uint8_t op; };
 constexpr int D_LIT_TB = XCK_D_LIT_TB, D_DIST_TB = 8;
 constexpr int D_LIT_MAX = (1 << D_LIT_TB) + 768;          // primary + sub-table budget (blocks that need more go to the host)
 constexpr int D_DIST_MAX = (1 << D_DIST_TB) + 256;
-constexpr int LITBUF = 64;
 
 __device__ const uint16_t d_len_base[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
 __device__ const uint8_t  d_len_extra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -48,7 +52,6 @@ struct Smem {
     uint16_t code[320];                   // canonical code (bit-reversed) of every symbol
     uint16_t sub_off[1 << D_LIT_TB];      // sub-table offset per primary index (0 = none)
     uint8_t  sub_bits[1 << D_LIT_TB];
-    uint8_t  litbuf[LITBUF];
     int32_t  count[16], first[16];
     int32_t  used, ok;
 };
