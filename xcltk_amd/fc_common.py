@@ -384,7 +384,9 @@ class Dist(object):
             # other rank's join kernels then wait behind them (measured on one GPU with two ranks: 40 M reads/s host-only, 4.8 M with the
             # device share).  One GPU per rank - the deployment - is not affected.  (The engine reads the knob at xck_create.)
             try:
-                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+                # (ranks on THIS node: torchrun says so; without it, a rendezvous on this host means all ranks are here - otherwise unknown, no guess)
+                one_node = os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1")
+                local_world = int(os.environ["LOCAL_WORLD_SIZE"]) if "LOCAL_WORLD_SIZE" in os.environ else (self.world if one_node else 0)
                 if self.world > 1 and torch.cuda.device_count() < local_world:
                     os.environ.setdefault("XCK_GPU_INFLATE", "0")
             except Exception:
