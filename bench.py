@@ -257,8 +257,7 @@ def whole_file_pass(eng, bams, out_dir, regions, cols, threads, rs=None):
     eng.reset()
     t0 = time.perf_counter()
     recs = 0
-    for i, bam in enumerate(bams):
-        recs += eng.ingest_bam(bam, sample=i, n_threads=threads, contig_mask=rs.mask if rs else None, use_index=bool(rs), windows=(rs.windows or None) if rs else None)
+    recs += eng.ingest_bams(list(bams), n_threads=threads, contig_mask=rs.mask if rs else None, use_index=bool(rs), windows=(rs.windows or None) if rs else None)
     t_ing = time.perf_counter() - t0
     coo = eng.finish(copy=False)
     t_fin = time.perf_counter() - t0

@@ -280,6 +280,12 @@ typedef struct xck_ingest_opts {
  * of records decoded so far (over all calls on this reader) through *n_records.
  * Returns 0 at the end of the file, 1 when paused by pause_records, <0 on error. */
 int  xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records);
+/* Read ahead: the reader's threads start on the first chunks of the file (scanner, inflate - on the host pool or the GPU) and the call
+ * returns at once; a later xck_ingest_bam / xck_bam_next_batch with the SAME options (which must stay valid until then) continues from
+ * there.  For callers that count many small files one after the other (a plate of per-cell BAMs, the reference's
+ * `for sam_fn in sam_fn_list` loops, rdr/fc/core.py:73-76): prefetch file k + 1 before ingesting file k, and the first inflate of the
+ * next file overlaps the parse and the joins of this one.  Nothing of the engine is touched.  Returns 0, or <0 on error. */
+int  xck_bam_prefetch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o);
 /* Pull-style decoding for tests / other consumers: fills *out with the next batch (arrays are
  * owned by the xck_bam and valid until the next call); returns 1 if a batch was produced,
  * 0 at end of file, <0 on error. */

@@ -135,6 +135,7 @@ SYMBOLS = [
     ("xck_bam_ref_records", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64), _P(C.c_int64)]),
     ("xck_bam_linear_index", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64), _P(_P(C.c_uint64))]),
     ("xck_ingest_bam", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts), _P(C.c_int64)]),
+    ("xck_bam_prefetch", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts)]),
     ("xck_bam_next_batch", C.c_int, [C.c_void_p, C.c_void_p, _P(IngestOpts), _P(Batch)]),
     ("xck_write_mtx", C.c_int, [C.c_char_p, _P(Coo), _P(C.c_int32), C.c_int32, C.c_int32]),
     ("xck_mtx_part_size", C.c_int, [_P(Coo), _P(C.c_int32), _P(C.c_int64), _P(C.c_int64)]),

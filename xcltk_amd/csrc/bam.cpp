@@ -510,6 +510,8 @@ struct xck_bam {
     Pool* pool = nullptr; int n_threads = 1;
     Chunk ch[N_CHUNK_GPU]; int n_ring = N_CHUNK, head = 0, n_sched = 0;      // ring of n_ring chunks: ch[head] is decoded next, n_sched chunks are inflating / inflated
     GpuShare gi;
+    bool started = false;              // a decode call has been made (xck_bam_prefetch alone does not count)
+    bool prefetching = false;          // inside xck_bam_prefetch
     Pusher* pusher = nullptr;          // made at the first push of a GPU-backed ingest
     // xck_ingest_bam on a GPU-backed handle (defer_parse): the parse of a chunk (pool tasks: record fields -> SoA block) and its push run
     // behind the coordinator (Pusher).  jobs[k % (PUSH_Q + 1)] belongs to the k-th chunk handed over; at most Pusher::MAXQ are outstanding.
@@ -835,7 +837,7 @@ static void schedule_chunk(xck_bam* b, Chunk& c, int ci, bool verify_crc, const 
             for (int k = 0; k < b->n_ring; k++) { if (!gi.slot[k]) continue; held++; if (gi.inflight[k] && !gpu_inflate_slot_done(gi.slot[k])) busy++; }
             // ... but never the chunk the coordinator needs next or the one after (a device chunk takes tens of milliseconds, the pool
             // delivers in three: the first chunks of a file, and whatever follows a drained ring, stay on the host)
-            want = busy < gi.depth && held < gi.max_held && b->n_sched >= 2;
+            want = busy < gi.depth && held < gi.max_held && (b->n_sched >= 2 || b->prefetching);   // (reading ahead: nobody waits for these chunks yet)
         }
         if (want) {
             size_t tin = 0; for (size_t i = 0; i < nb; i++) tin += ((size_t)c.blocks[i].data_len + 3) & ~size_t(3);
@@ -1145,15 +1147,19 @@ static void start_stage_two(xck_engine* e, xck_bam* b, int ci, ContigMap cm, boo
     c.stage2 = true;
 }
 
-static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
+static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, bool schedule_only = false) {
     const bool crc = e->dec.verify_crc;
     const int n_refs = (int)b->ref_names.size();
     const bool has_win = o->struct_size >= offsetof(xck_ingest_opts, tid_end) + sizeof(void*);
     ContigMap cm; cm.t2c = o->tid_to_contig; cm.n_refs = n_refs; cm.t_end = has_win ? o->tid_end : nullptr;
-    if (!b->ranges_set) {
+    if (!schedule_only && !b->started) {
+        b->started = true;
         // well mode without UMIs: the key is the read name and the column is the BAM itself, so names only
-        // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads)
+        // have to be unique within one file - restart the intern table per BAM (bounded memory for 384 x 2 M reads).
+        // (At the first DECODE call, not at xck_bam_prefetch: the file before this one may still be parsing.)
         if (!e->dec.use_barcodes && !e->dec.use_umi) e->intern.clear();
+    }
+    if (!b->ranges_set) {
         set_ranges(b, o);
         if (!b->gi.tried) {                                    // GPU share of the inflate: a handle with a device, XCK_GPU_INFLATE > 0, no CRC checks asked for
             b->gi.tried = true;
@@ -1161,7 +1167,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
             // (files of a few chunks - the per-cell BAMs of a well-based run - are done before the device has returned its first chunk)
             uint64_t span = b->fsize;
             if (b->use_ranges) { span = 0; for (auto& r : b->ranges) span += (r.second >> 16) - (r.first >> 16); }
-            const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20;
+            const bool big = span >= (uint64_t)e->knobs.gpu_inflate_min_mb << 20 || schedule_only;   // (a file that is read ahead has the time a device chunk takes, whatever its size)
             if (pct != 0 && dev >= 0 && !crc && (big || pct > 0)) { b->gi.on = true; b->gi.pct = pct < 0 ? 0 : std::min(pct, 100); b->gi.depth = e->knobs.gpu_inflate_depth; b->gi.max_held = std::min(b->gi.depth + 2, 12); b->gi.device = dev; b->gi.free_cus = e->knobs.gpu_inflate_free_cus; b->gi.verbose = e->knobs.debug_timing; b->n_ring = std::max(N_CHUNK + 1, std::min(N_CHUNK_GPU, e->knobs.gpu_inflate_ring)); }
         }
         bind_to_numa_node(e, b);                               // (before the scanner thread is made: it inherits the mask)
@@ -1185,6 +1191,7 @@ static int decode_next_chunk(xck_engine* e, xck_bam* b, const xck_ingest_opts* o
         b->n_sched++;
     }
     phase(b->tm.sched);
+    if (schedule_only) return 2;                                         // xck_bam_prefetch: the pool is inflating the first chunks now
     if (b->n_sched == 0) {
         if (!b->use_ranges && !b->carry.empty()) { b->err = "truncated BAM file (partial record at end of file)"; return XCK_E_IO; }
         return 0;
@@ -1488,6 +1495,17 @@ int xck_bam_open(const char* path, int n_threads, xck_bam** out, char* err, size
     catch (const std::exception& x) { if (err && errlen) snprintf(err, errlen, "%s: %s", path ? path : "(null)", x.what()); set_thread_error(x.what()); return XCK_E_IO; }
     catch (...) { if (err && errlen) snprintf(err, errlen, "%s: unknown C++ exception", path ? path : "(null)"); return XCK_E_IO; }
 }
+static int prefetch_impl(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) {
+    if (!e || !b || !o) return XCK_E_ARG;
+    if (b->done || b->started) return XCK_OK;
+    CallerBinding on_node(b);
+    b->prefetching = true;
+    const int rc = decode_next_chunk(e, b, o, true);
+    b->prefetching = false;
+    if (rc < 0) { e->err = b->path + ": " + b->err; return rc; }
+    return XCK_OK;
+}
+int xck_bam_prefetch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o) { XCK_GUARD(e, prefetch_impl(e, b, o)) }
 int xck_bam_next_batch(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, xck_batch* out) { XCK_GUARD(e, next_batch_impl(e, b, o, out)) }
 int xck_ingest_bam(xck_engine* e, xck_bam* b, const xck_ingest_opts* o, int64_t* n_records) { XCK_GUARD(e, ingest_impl(e, b, o, n_records)) }
 

@@ -252,6 +252,42 @@ class Engine(object):
         finally:
             self.lib.xck_bam_close(b)
 
+    def ingest_bams(self, paths, n_threads=0, contig_mask=None, use_index=False, windows=None, on_file=None, ahead=2):
+        """ingest_bam() over a list of files, sample = position in the list, with the next `ahead` files already open and reading
+        ahead (xck_bam_prefetch: scanner + inflate, on the host pool or the GPU) while this one is parsed and joined - what pays with
+        many small files (per-cell BAMs).  on_file(i, path, n_records) is called after each file.  Returns the total number of records."""
+        total, queue, nxt_i = 0, [], 0                             # queue: [(b, opts, keep-alive)] of files nxt_i - len(queue) .. nxt_i - 1
+
+        def prepare(i):
+            b, refs = self._open(paths[i], n_threads or self.cfg.n_threads)
+            try:
+                o, keep = self._opts(refs, i, 0, contig_mask, use_index, windows)
+            except Exception:
+                self.lib.xck_bam_close(b)
+                raise
+            return (b, o, keep)
+
+        try:
+            for i, path in enumerate(paths):
+                while nxt_i < len(paths) and nxt_i <= i + max(0, int(ahead)):
+                    queue.append(prepare(nxt_i))
+                    if nxt_i > i:
+                        self.lib.xck_bam_prefetch(self.h, queue[-1][0], C.byref(queue[-1][1]))   # (best effort: an error shows up when the file is ingested)
+                    nxt_i += 1
+                cur = queue.pop(0)
+                try:
+                    n = C.c_int64(0)
+                    self._check(self.lib.xck_ingest_bam(self.h, cur[0], C.byref(cur[1]), C.byref(n)), "xck_ingest_bam")
+                finally:
+                    self.lib.xck_bam_close(cur[0])
+                total += int(n.value)
+                if on_file:
+                    on_file(i, path, int(n.value))
+        finally:
+            for q in queue:
+                self.lib.xck_bam_close(q[0])
+        return total
+
     def open_stream(self, path, sample=0, n_threads=0, contig_mask=None, use_index=False, windows=None):
         """Resumable ingest of one BAM: -> BamStream whose advance(n) decodes and joins about n further
         records (whole decode chunks) and returns (records so far, done)."""

@@ -479,11 +479,11 @@ def stream_bams(eng, conf, log_prefix="[engine]", contig_mask=None, windows=None
     """One streaming pass over every BAM, in list order (= the reference's fetch order)."""
     t0 = time.time()
     n_tot = 0
-    for i, fn in enumerate(conf.sam_fn_list):
-        n = eng.ingest_bam(fn, sample=i, contig_mask=contig_mask, use_index=contig_mask is not None, windows=windows or None)
-        n_tot += n
+    def per_file(i, fn, n):
         if conf.debug > 0:
             info("%s %s: %d records" % (log_prefix, fn, n))
+    # (the next file reads ahead while this one is parsed and joined: Engine.ingest_bams)
+    n_tot = eng.ingest_bams(list(conf.sam_fn_list), contig_mask=contig_mask, use_index=contig_mask is not None, windows=windows or None, on_file=per_file)
     dt = max(time.time() - t0, 1e-9)
     info("%s %d BAM record(s) decoded and joined in %.2fs (%.0f reads/s)" % (log_prefix, n_tot, dt, n_tot / dt))
     return n_tot
