@@ -329,6 +329,46 @@ def test_indexed_contig_subset_decode(ds, mask):
     assert sum(b["n_reads"] for b in want) == int(counts[np.array(mask)].sum())
 
 
+def test_prefetched_reader_decodes_the_same_batches():
+    """xck_bam_prefetch (csrc/bam.cpp): a reader whose scanner and inflate were started ahead of time hands out exactly the batches
+    of a reader that was not; the engine's intern table (well mode: read names as keys, restarted per file) is untouched by the
+    prefetch of the NEXT file while this one is decoded; Engine.ingest_bams counts what the per-file calls count."""
+    import ctypes as C
+    import json
+    ddir = os.path.join(util.GOLDEN, "datasets", "multibam")
+    regions, snps = util.load_tables(ddir)
+    names = O.contig_table(regions, snps)
+    info = json.load(open(os.path.join(ddir, "dataset.json")))
+    bams = [os.path.join(ddir, b) for b in info["bams"]]
+    assert len(bams) >= 2
+    eng = Engine(capi.XCK_MODE_BAF, names, regions, len(bams), snps=snps, decode_only=True, n_threads=2)   # well mode: column = file, key = read name
+    try:
+        plain = [list(eng.decode_bam(fn, sample=i)) for i, fn in enumerate(bams)]
+        per_file = [eng.ingest_bam(fn, sample=i) for i, fn in enumerate(bams)]
+        assert eng.ingest_bams(bams) == sum(per_file) and eng.ingest_bams(bams, ahead=0) == sum(per_file)
+        # file 1 is prefetched BEFORE file 0 is decoded, then both are pulled batch by batch
+        b1, refs1 = eng._open(bams[1], 2)
+        o1, keep1 = eng._opts(refs1, 1, 0, None, False, None)
+        assert eng.lib.xck_bam_prefetch(eng.h, b1, C.byref(o1)) == 0
+        assert eng.lib.xck_bam_prefetch(eng.h, b1, C.byref(o1)) == 0          # (a second call is harmless)
+        first = list(eng.decode_bam(bams[0], sample=0))
+        bt, second = capi.Batch(), []
+        while eng.lib.xck_bam_next_batch(eng.h, b1, C.byref(o1), C.byref(bt)) > 0:
+            n = bt.n_reads
+            second.append(dict(contig=bt.contig, n_reads=n, ordinal_base=int(bt.ordinal_base), pos=np.ctypeslib.as_array(bt.pos, (n,)).copy(),
+                               cell=np.ctypeslib.as_array(bt.cell, (n,)).copy(), umi=np.ctypeslib.as_array(bt.umi, (n,)).copy()))
+        eng.lib.xck_bam_close(b1)
+        for got, want in ((first, plain[0]), (second, plain[1])):
+            assert [(g["contig"], g["n_reads"], g["ordinal_base"]) for g in got] == [(w["contig"], w["n_reads"], w["ordinal_base"]) for w in want]
+            for g, w in zip(got, want):
+                assert np.array_equal(g["pos"], w["pos"]) and np.array_equal(g["cell"], w["cell"])
+                # (interned read names: ids are per file and per decode - compare their equality pattern, not the ids)
+                first_seen = lambda a: [{v: i for i, v in reversed(list(enumerate(a.tolist())))}[v] for v in a.tolist()]
+                assert first_seen(g["umi"]) == first_seen(w["umi"])
+    finally:
+        eng.close()
+
+
 def test_fast_inflate_matches_zlib_on_every_block():
     """inflate_fast.h vs zlib: every BGZF block of the golden BAMs plus 600 synthetic streams (stored, fixed and
     dynamic blocks, all levels / strategies, corrupted and truncated inputs must not write out of bounds)."""
