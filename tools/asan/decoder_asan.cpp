@@ -104,6 +104,7 @@ int main(int argc, char** argv) {
                     if (xck_bam_open(argv[a], threads, &b, err, sizeof err) == 0) {
                         xck::g_push_sum = 0; xck::g_push_recs = 0;
                         e->n_impl = 1;                                   // (no engine behind it: engine_push_block is the stand-in)
+                        if (xck_bam_prefetch(e, b, &o) < 0) { /* the ingest below reports it */ }   // (read ahead first, as Engine.ingest_bams does for the next file of a list)
                         o.pause_records = 3000;
                         int64_t n = 0; int rc2;
                         while ((rc2 = xck_ingest_bam(e, b, &o, &n)) == 1) {}
